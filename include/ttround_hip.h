@@ -1,0 +1,143 @@
+/*
+ * ttround_hip.h -- C ABI of libttround_hip.so, the MI355X (gfx950) kernels behind
+ * tntorch's TT orthogonalisation / rounding hot path.
+ *
+ * The reference (rballester/tntorch) has NO native layer: the hot path reaches
+ * LAPACK/BLAS through torch operators.  Each entry point below therefore replaces
+ * one *operator call site* of the reference (file:line given per function), and
+ * is what a maintainer would bind with ctypes from tntorch/round.py and
+ * tntorch/tensor.py.
+ *
+ * Conventions
+ *   - all matrix pointers are DEVICE pointers; matrices are row-major with an
+ *     explicit leading dimension (elements) and a batch stride (elements);
+ *   - `dtype` is TTR_F32 or TTR_F64; scalars that select truncation (delta^2)
+ *     are passed as double;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on that stream, never synchronises, never
+ *     allocates: workspaces are caller-provided (sizes from *_workspace_bytes);
+ *   - return value: 0 on success, <0 on error (TTR_E_*); ttr_last_error() gives
+ *     a thread-local message.
+ */
+#ifndef TTROUND_HIP_H
+#define TTROUND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTR_F32 0
+#define TTR_F64 1
+
+#define TTR_OK 0
+#define TTR_E_INVALID (-1)     /* bad argument */
+#define TTR_E_UNSUPPORTED (-2) /* shape outside the kernels' envelope */
+#define TTR_E_HIP (-3)         /* HIP runtime error */
+#define TTR_E_WORKSPACE (-4)   /* workspace too small */
+
+/* scale modes for ttr_gemm epilogues */
+#define TTR_SCALE_NONE 0
+#define TTR_SCALE_MUL 1
+#define TTR_SCALE_DIV 2 /* x / s, and 0 where |s| is below the smallest normal */
+
+/* eigenvalue post-processing modes for ttr_eigh_trunc */
+#define TTR_EIG_RAW 0   /* sigma = sqrt(max(w, 0)) */
+#define TTR_EIG_REF 1   /* round.py:118-119: w < 0 -> 1e-8 before the sqrt */
+
+int ttr_version(void);
+const char* ttr_last_error(void);
+
+/* Limits of the LDS/register-resident kernels (queried by the host shim). */
+int ttr_qr_max_cols(int dtype);        /* widest panel ttr_qr factors (columns) */
+int ttr_eigh_max_n_lds(int dtype);     /* largest n solved out of LDS; above it the solver works out of L2/HBM */
+
+/*
+ * C[b] = scale( op(A[b]) * op(B[b]) ),  op(A) is M x K, op(B) is K x N.
+ * Replaces: `R @ right_unfolding(core)` tensor.py:1826-1832 (push right),
+ *           `M @ M^T` / `M^T @ M` round.py:104-109 (Gram),
+ *           `left^T @ M` with the 1/sigma row scaling round.py:163-172 (projection),
+ *           `einsum("ijk,kl")` tensor.py:2074-2083 (push left, with the sigma column scaling
+ *           of round.py:169-172 fused), `M @ left` round.py:175-181.
+ * transA/transB: 0 -> the stored matrix is op(X); 1 -> the stored matrix is op(X)^T.
+ * rowscale (length M per batch item) / colscale (length N per batch item) may be NULL.
+ * MFMA (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64) on LDS-staged tiles.
+ * `workspace` (may be NULL) enables split-K for few-tile / very-long-K products
+ * (Gram matrices of tall dense unfoldings); size from ttr_gemm_workspace_bytes.
+ */
+int64_t ttr_gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch);
+int ttr_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+             const void* A, int64_t lda, int64_t strideA,
+             const void* B, int64_t ldb, int64_t strideB,
+             void* C, int64_t ldc, int64_t strideC,
+             const void* rowscale, int64_t stride_rs, int rowscale_mode,
+             const void* colscale, int64_t stride_cs, int colscale_mode,
+             int64_t batch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Reduced Householder QR of batch tall (or square/wide) matrices: A[b] (m x n) = Q[b] (m x k) R[b] (k x n),
+ * k = min(m, n), LAPACK sign convention (geqrf: beta = -sign(alpha)*norm), R upper triangular/trapezoidal.
+ * Replaces: torch.linalg.qr at tensor.py:1816 (left_orthogonalize) and tensor.py:1853/1859
+ * (right_orthogonalize, on the transposed unfolding).
+ * Communication-avoiding TSQR: 256-row blocks factored in registers, R factors reduced over a tree,
+ * Q formed by walking the tree back.  n <= ttr_qr_max_cols(dtype).
+ */
+int64_t ttr_qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
+int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch,
+           const void* A, int64_t lda, int64_t strideA,
+           void* Q, int64_t ldq, int64_t strideQ,
+           void* R, int64_t ldr, int64_t strideR,
+           void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Symmetric eigen-decomposition + the rank rule of truncated_svd, batched, on device.
+ * Input  G[b]  (n x n symmetric, e.g. a Gram matrix).
+ * Output V[b]  (n x n): eigenvectors as COLUMNS, sorted by DEcreasing sigma,
+ *        sigma[b] (n): sqrt of the (clamped) eigenvalues, decreasing,
+ *        info[b]  (int32): the selected rank r >= 1, or 0 if sigma_max < 1e-13 (round.py:137-145 zero guard).
+ * Rank rule (round.py:147-158): drop the longest tail with sum(sigma^2) <= delta2, then
+ * r = max(1, min(rmax, n - tail)); with use_delta == 0 (batch mode, round.py:149-150) r = max(1, min(rmax, n)).
+ * Replaces: torch.linalg.eigh round.py:115, the clamp/sqrt/argsort of round.py:118-135 and the rank
+ * selection round.py:147-158 (and, in the two-pass 'svd' algorithm, torch.linalg.svd round.py:96).
+ * Parallel cyclic two-sided Jacobi; out of LDS for n <= ttr_eigh_max_n_lds(dtype), else out of `workspace`.
+ */
+int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
+int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
+                   const void* G, int64_t ldg, int64_t strideG,
+                   void* V, int64_t ldv, int64_t strideV,
+                   void* sigma, int64_t stride_sigma,
+                   int32_t* info,
+                   int eig_mode, int use_delta, double delta2, int64_t rmax,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * out[b] = sqrt(sum(x[b]^2)) over `count` contiguous elements (accumulated in double, stored in dtype).
+ * Replaces: torch.norm(cores[-1]) tensor.py:2039-2051 and torch.norm(M) round.py:80.
+ */
+int ttr_norm(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out, void* stream);
+
+/*
+ * out[b][i][j] = in[b][i][j] * s[b][j]   (mode TTR_SCALE_MUL)  or  / s[b][j]  (TTR_SCALE_DIV).
+ * Replaces: `left * svd[1][:rank]` round.py:169-172 and the 1/sigma column scaling round.py:175.
+ */
+int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
+                   const void* in, int64_t ldi, int64_t stride_in,
+                   const void* s, int64_t stride_s, int mode,
+                   void* out, int64_t ldo, int64_t stride_out, void* stream);
+
+/* Per-kernel device timing (HIP events on `stream`), used by bench.py for the roofline line. */
+#define TTR_PROF_GEMM 0
+#define TTR_PROF_QR_FACTOR 1
+#define TTR_PROF_QR_APPLY 2
+#define TTR_PROF_EIGH 3
+#define TTR_PROF_MISC 4
+#define TTR_PROF_NKINDS 5
+int ttr_prof_enable(int on);
+/* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */
+int ttr_prof_collect(double* ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTROUND_HIP_H */

@@ -1,0 +1,419 @@
+"""CPU oracle for the TT orthogonalisation / rounding hot path of tntorch.
+
+TEST INFRASTRUCTURE.  This file restates, function by function, the algorithm
+of the reference (``/root/reference/tntorch``) on plain lists of torch CPU
+tensors (no ``Tensor`` class), calling the same LAPACK entry points the
+reference reaches through ``torch.linalg`` (geqrf/orgqr, gesdd, syevd).  It is
+pinned against the reference itself: ``oracle/gen_golden.py`` imports the
+unmodified reference in the build container, records its outputs on seeded
+inputs under ``tests/golden/`` and ``tests/test_oracle_golden.py`` replays
+them against this file.  Parity status: PINNED (golden vectors + the
+known-answer values of ``docs/tutorials/decompositions.ipynb`` cells 3/18).
+
+A TT tensor is a ``list`` of cores ``[R_k, I_k, R_{k+1}]`` (``batch=True``
+prepends a batch dim to every core), as in ``tensor.py:111-117``.
+
+Every function names the reference lines it follows.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+__all__ = [
+    "left_unfolding",
+    "right_unfolding",
+    "unfolding",
+    "truncated_svd",
+    "left_orthogonalize",
+    "right_orthogonalize",
+    "orthogonalize",
+    "round_tt",
+    "full_rank_tt",
+    "dense_to_tt",
+    "tt_to_dense",
+    "tt_add",
+    "tt_scale",
+    "tt_randn",
+    "tt_rand",
+    "tt_ranks",
+    "tt_dot",
+    "tt_norm",
+    "bond_singular_values",
+    "gauge_align",
+]
+
+Cores = List[torch.Tensor]
+
+
+# --------------------------------------------------------------------------
+# unfoldings -- tools.py:211-258 (pure reshape views)
+# --------------------------------------------------------------------------
+def right_unfolding(core: torch.Tensor, batch: bool = False) -> torch.Tensor:
+    """tools.py:231-243: [r0, I, r1] -> [r0, I*r1]."""
+    if batch:
+        return core.reshape(core.shape[0], core.shape[1], -1)
+    return core.reshape(core.shape[0], -1)
+
+
+def left_unfolding(core: torch.Tensor, batch: bool = False) -> torch.Tensor:
+    """tools.py:246-258: [r0, I, r1] -> [r0*I, r1]."""
+    if batch:
+        return core.reshape(core.shape[0], -1, core.shape[-1])
+    return core.reshape(-1, core.shape[-1])
+
+
+def unfolding(data: torch.Tensor, n: int, batch: bool = False) -> torch.Tensor:
+    """tools.py:211-228: mode-n unfolding (mode n first, the rest flattened)."""
+    if batch:
+        order = [0, n + 1] + [d for d in range(1, data.dim()) if d != n + 1]
+        return data.permute(order).reshape(data.shape[0], data.shape[n + 1], -1)
+    order = [n] + [d for d in range(data.dim()) if d != n]
+    return data.permute(order).reshape(data.shape[n], -1)
+
+
+def _t(M: torch.Tensor) -> torch.Tensor:
+    return M.transpose(-1, -2)
+
+
+# --------------------------------------------------------------------------
+# truncated SVD -- round.py:52-187
+# --------------------------------------------------------------------------
+def truncated_svd(
+    M: torch.Tensor,
+    delta: Optional[float] = None,
+    eps: Optional[float] = None,
+    rmax: Optional[int] = None,
+    left_ortho: bool = True,
+    algorithm: str = "svd",
+    batch: bool = False,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """round.py:52-187.  Returns ``left (m x r)``, ``M2 (r x n)``, left@M2 ~= M."""
+    if delta is not None and eps is not None:  # round.py:77-78
+        raise ValueError("Provide either `delta` or `eps`")
+    if delta is None and eps is not None:  # round.py:79-80
+        delta = eps * torch.norm(M).item()
+    if delta is None:  # round.py:81-82
+        delta = 0
+    if rmax is None:  # round.py:83-84
+        rmax = torch.iinfo(torch.int32).max
+    assert rmax >= 1
+    assert algorithm in ("svd", "eig")
+
+    if algorithm == "svd":  # round.py:94-100 (full_matrices=True, Vh dropped)
+        U, sig = torch.linalg.svd(M)[:2]
+        side = "left"
+    else:  # round.py:101-135
+        if M.shape[-2] <= M.shape[-1]:
+            gram, side = M @ _t(M), "left"
+        else:
+            gram, side = _t(M) @ M, "right"
+        w, U = torch.linalg.eigh(gram)
+        w = torch.where(w < 0, torch.zeros_like(w) + 1e-8, w)  # quirk: -> 1e-8
+        sig = torch.sqrt(w)
+        # argsort ascending then reverse (round.py:121-135)
+        n = sig.shape[-1]
+        rev = torch.arange(n - 1, -1, -1)
+        if batch:
+            idx = torch.argsort(sig)[:, rev]
+            U = torch.stack([U[b][..., idx[b]] for b in range(len(idx))])
+            sig = torch.stack([sig[b][idx[b]] for b in range(len(idx))])
+        else:
+            idx = torch.argsort(sig)[rev]
+            U, sig = U[..., idx], sig[idx]
+
+    # zero guard (round.py:137-145); the reference allocates CPU/default-dtype
+    # zeros -- the oracle keeps M's dtype.
+    if batch:
+        if sig.max() < 1e-13:
+            B = M.shape[0]
+            return (
+                torch.zeros(B, M.shape[1], 1, dtype=M.dtype),
+                torch.zeros(B, 1, M.shape[2], dtype=M.dtype),
+            )
+    elif sig[0] < 1e-13:
+        return torch.zeros(M.shape[0], 1, dtype=M.dtype), torch.zeros(1, M.shape[1], dtype=M.dtype)
+
+    S = sig**2  # round.py:147
+    if batch:  # round.py:149-150 (eps/delta ignored)
+        rank = max(1, int(min(rmax, S.shape[-1])))
+    else:  # round.py:152-158
+        tail = torch.cumsum(torch.flip(S, [0]), dim=0) <= delta**2
+        where = torch.where(tail)[0]
+        if len(where) == 0:
+            rank = max(1, int(min(rmax, len(S))))
+        else:
+            rank = max(1, int(min(rmax, len(S) - 1 - int(where[-1]))))
+
+    left = U[..., :rank]
+    sr = sig[..., :rank]
+    if side == "left":  # round.py:164-172
+        if left_ortho:
+            M2 = _t(left) @ M
+        else:
+            M2 = (1.0 / sr)[..., None] * _t(left) @ M
+            left = left * sr[..., None, :]
+    else:  # round.py:173-182
+        if left_ortho:
+            newleft = M @ (left * (1.0 / sr)[..., None, :])
+            M2 = _t(left * sr[..., None, :])
+            left = newleft
+        else:
+            newleft = M @ left
+            M2 = _t(left)
+            left = newleft
+    return left, M2
+
+
+# --------------------------------------------------------------------------
+# orthogonalisation sweeps -- tensor.py:1800-1909 (pure TT cores, Us = None)
+# --------------------------------------------------------------------------
+def left_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Tensor:
+    """tensor.py:1800-1833: reduced QR of the left unfolding; R is pushed right."""
+    assert 0 <= mu < len(cores) - 1
+    core = cores[mu]
+    Q, R = torch.linalg.qr(left_unfolding(core, batch))
+    cores[mu] = Q.reshape(core.shape[:-1] + (Q.shape[-1],))
+    nxt = cores[mu + 1]
+    pushed = R @ right_unfolding(nxt, batch)
+    if batch:
+        cores[mu + 1] = pushed.reshape((R.shape[0], R.shape[1]) + nxt.shape[2:])
+    else:
+        cores[mu + 1] = pushed.reshape((R.shape[0],) + nxt.shape[1:])
+    return R
+
+
+def right_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Tensor:
+    """tensor.py:1835-1879: QR of the transposed right unfolding; L is pushed left."""
+    assert 1 <= mu < len(cores)
+    core = cores[mu]
+    Q, L = torch.linalg.qr(_t(right_unfolding(core, batch)))
+    Q, L = _t(Q), _t(L)
+    if batch:
+        cores[mu] = Q.reshape(Q.shape[:2] + core.shape[2:])
+    else:
+        cores[mu] = Q.reshape((Q.shape[0],) + core.shape[1:])
+    prev = cores[mu - 1]
+    cores[mu - 1] = (left_unfolding(prev, batch) @ L).reshape(prev.shape[:-1] + (L.shape[-1],))
+    return L
+
+
+def orthogonalize(cores: Cores, mu: int, batch: bool = False):
+    """tensor.py:1881-1909: make the train mu-orthogonal (in place on the list)."""
+    N = len(cores)
+    if mu < 0:
+        mu += N
+    R = L = None
+    for i in range(mu):
+        R = left_orthogonalize(cores, i, batch)
+    for i in range(N - 1, mu, -1):
+        L = right_orthogonalize(cores, i, batch)
+    return R, L
+
+
+# --------------------------------------------------------------------------
+# TT rounding -- tensor.py:2008-2083
+# --------------------------------------------------------------------------
+def round_tt(
+    cores: Sequence[torch.Tensor],
+    eps: float = 1e-14,
+    rmax: Union[None, int, Sequence[Optional[int]]] = None,
+    algorithm: str = "svd",
+    batch: bool = False,
+) -> Cores:
+    """tensor.py:2008-2083.  Returns the rounded cores (input list untouched)."""
+    cores = [c.clone() for c in cores]
+    N = len(cores)
+    if not hasattr(rmax, "__len__"):
+        rmax = [rmax] * (N - 1)
+    assert len(rmax) == N - 1  # tensor.py:2029
+
+    orthogonalize(cores, N - 1, batch)  # tensor.py:2033
+    if batch:  # tensor.py:2036-2037
+        delta = None
+    else:  # tensor.py:2039-2051 (float64 factor times the core's norm)
+        delta = (eps / max(1.0, math.sqrt(N - 1))) * torch.norm(cores[-1]).double()
+        delta = delta.item()
+
+    for mu in range(N - 1, 0, -1):  # tensor.py:2053-2083
+        core = cores[mu]
+        left, right = truncated_svd(
+            right_unfolding(core, batch),
+            delta=delta,
+            rmax=rmax[mu - 1],
+            left_ortho=False,
+            algorithm=algorithm,
+            batch=batch,
+        )
+        left, right = left.to(core.dtype), right.to(core.dtype)
+        if batch:
+            cores[mu] = right.reshape(core.shape[0], -1, core.shape[2], core.shape[3])
+        else:
+            cores[mu] = right.reshape(-1, core.shape[1], core.shape[2])
+        cores[mu - 1] = cores[mu - 1] @ left if not batch else torch.matmul(cores[mu - 1], left[:, None])
+    return cores
+
+
+# --------------------------------------------------------------------------
+# dense -> TT entry -- tensor.py:10-104 + ctor dense branch 401-408
+# --------------------------------------------------------------------------
+def full_rank_tt(data: torch.Tensor, batch: bool = False) -> Cores:
+    """tensor.py:10-104: exact TT padded with identity cores (no compression)."""
+    shape = list(data.shape[1:]) if batch else list(data.shape)
+    B = data.shape[0] if batch else None
+    N = len(shape)
+    lead = (B,) if batch else ()
+
+    def eye(n):
+        I = torch.eye(n, dtype=data.dtype)
+        return I.repeat(B, 1, 1) if batch else I
+
+    resh = data.reshape(lead + (shape[0], -1))
+    out: Cores = []
+    for n in range(1, N):
+        rows, cols = resh.shape[-2], resh.shape[-1]
+        if rows < cols:  # tensor.py:32-64: emit an identity core
+            out.append(eye(rows).reshape(lead + (rows // shape[n - 1], shape[n - 1], rows)))
+            resh = resh.reshape(lead + (rows * shape[n], cols // shape[n]))
+        else:  # tensor.py:65-96: emit the data, continue with an identity
+            out.append(resh.reshape(lead + (rows // shape[n - 1], shape[n - 1], cols)))
+            resh = eye(cols).reshape(lead + (cols * shape[n], cols // shape[n]))
+    rows = resh.shape[-2]
+    out.append(resh.reshape(lead + (rows // shape[N - 1], shape[N - 1], 1)))
+    return out
+
+
+def dense_to_tt(
+    data: torch.Tensor,
+    ranks_tt: Union[None, int, Sequence[int]] = None,
+    algorithm: str = "svd",
+    batch: bool = False,
+) -> Cores:
+    """tensor.py:401-408: ``tn.Tensor(data, ranks_tt=r)`` = full_rank_tt + round_tt(rmax=r)."""
+    cores = full_rank_tt(data, batch)
+    if ranks_tt is not None:
+        cores = round_tt(cores, rmax=ranks_tt, algorithm=algorithm, batch=batch)
+    return cores
+
+
+# --------------------------------------------------------------------------
+# helpers used by the parity harness (thin restatements)
+# --------------------------------------------------------------------------
+def tt_to_dense(cores: Sequence[torch.Tensor], batch: bool = False) -> torch.Tensor:
+    """tensor.py:1639-1687 for pure TT cores: chain the cores left to right."""
+    if batch:
+        B = cores[0].shape[0]
+        acc = cores[0].reshape(B, -1, cores[0].shape[-1])
+        for c in cores[1:]:
+            acc = torch.bmm(acc, c.reshape(B, c.shape[1], -1)).reshape(B, -1, c.shape[-1])
+        return acc.sum(-1).reshape([B] + [c.shape[2] for c in cores])
+    acc = cores[0].reshape(-1, cores[0].shape[-1])
+    for c in cores[1:]:
+        acc = (acc @ c.reshape(c.shape[0], -1)).reshape(-1, c.shape[-1])
+    return acc.sum(-1).reshape([c.shape[1] for c in cores])
+
+
+def tt_add(a: Sequence[torch.Tensor], b: Sequence[torch.Tensor], batch: bool = False) -> Cores:
+    """tensor.py:445-668 for TT+TT: first core [a b], middle blockdiag, last [a; b]."""
+    N = len(a)
+    if N == 1:
+        return [a[0] + b[0]]
+    out = []
+    for n in range(N):
+        ca, cb = a[n], b[n]
+        if n == 0:
+            out.append(torch.cat([ca, cb], dim=-1))
+        elif n == N - 1:
+            out.append(torch.cat([ca, cb], dim=-3))
+        else:
+            za = torch.zeros(ca.shape[:-1] + (cb.shape[-1],), dtype=ca.dtype)
+            zb = torch.zeros(cb.shape[:-1] + (ca.shape[-1],), dtype=ca.dtype)
+            out.append(torch.cat([torch.cat([ca, za], -1), torch.cat([zb, cb], -1)], dim=-3))
+    return out
+
+
+def tt_scale(cores: Sequence[torch.Tensor], s: float) -> Cores:
+    out = [c.clone() for c in cores]
+    out[0] = out[0] * s
+    return out
+
+
+def _tt_random(fn, shape, ranks, dtype, batch_size=None):
+    N = len(shape)
+    if not hasattr(ranks, "__len__"):
+        ranks = [ranks] * (N - 1)
+    r = [1] + list(ranks) + [1]
+    lead = () if batch_size is None else (batch_size,)
+    return [fn(lead + (r[n], shape[n], r[n + 1]), dtype=dtype) for n in range(N)]
+
+
+def tt_randn(shape, ranks, dtype=torch.float64, batch_size=None) -> Cores:
+    """create.py:60-65 / 210-357 for pure TT: i.i.d. N(0,1) cores, core by core."""
+    return _tt_random(torch.randn, tuple(shape), ranks, dtype, batch_size)
+
+
+def tt_rand(shape, ranks, dtype=torch.float64, batch_size=None) -> Cores:
+    """create.py (rand): i.i.d. U[0,1) cores."""
+    return _tt_random(torch.rand, tuple(shape), ranks, dtype, batch_size)
+
+
+def tt_ranks(cores: Sequence[torch.Tensor]) -> List[int]:
+    """tensor.py:861-883."""
+    return [cores[0].shape[-3]] + [c.shape[-1] for c in cores]
+
+
+def tt_dot(a: Sequence[torch.Tensor], b: Sequence[torch.Tensor]) -> torch.Tensor:
+    """metrics.py:28-116 (k = N, no Tucker factors): running Lprod contraction."""
+    L = torch.ones(b[0].shape[0], a[0].shape[0], dtype=a[0].dtype)
+    for ca, cb in zip(a, b):
+        U = torch.einsum("sr,rai->sai", L, ca)
+        L = left_unfolding(cb).t() @ left_unfolding(U)
+    return L.sum()
+
+
+def tt_norm(a: Sequence[torch.Tensor]) -> torch.Tensor:
+    """metrics.py:469-478."""
+    return torch.sqrt(torch.clamp(tt_dot(a, a), min=0))
+
+
+def bond_singular_values(cores: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Gauge-invariant fingerprint of a TT: singular values of every bond.
+
+    Left-orthogonalises a float64 copy (tensor.py:1881-1909) and reads the
+    singular values of the right unfolding while sweeping back (the quantities
+    round.py:96 computes), without truncating.
+    """
+    cs = [c.double().clone() for c in cores]
+    N = len(cs)
+    orthogonalize(cs, N - 1)
+    out = []
+    for mu in range(N - 1, 0, -1):
+        M = right_unfolding(cs[mu])
+        U, s, Vh = torch.linalg.svd(M, full_matrices=False)
+        out.append(s)
+        cs[mu] = Vh.reshape(-1, cs[mu].shape[1], cs[mu].shape[2])
+        cs[mu - 1] = cs[mu - 1] @ (U * s)
+    return out[::-1]
+
+
+def gauge_align(ref: Sequence[torch.Tensor], ours: Sequence[torch.Tensor]) -> Cores:
+    """Fix the per-bond +-1 sign gauge of ``ours`` against ``ref``.
+
+    For bond k the rows of the right unfolding of core k (= right singular
+    vectors) are compared; our core k rows and core k-1 columns are multiplied
+    by ``sign(<row_j(ref), row_j(ours)>)``.  Valid when both trains have the
+    same ranks and separated spectra.
+    """
+    out = [c.clone() for c in ours]
+    for k in range(len(out) - 1, 0, -1):
+        a = right_unfolding(ref[k]).double()
+        b = right_unfolding(out[k]).double()
+        s = torch.sign((a * b).sum(-1))
+        s[s == 0] = 1
+        s = s.to(out[k].dtype)
+        out[k] = out[k] * s[:, None, None]
+        out[k - 1] = out[k - 1] * s[None, None, :]
+    return out

@@ -1,0 +1,119 @@
+"""Pin the oracle (oracle/tt_oracle.py) against the golden vectors recorded from the
+unmodified reference (oracle/gen_golden.py) and the notebook known answers."""
+import pytest
+import torch
+
+import oracle
+from parity import analytic_128, load_case, load_meta
+
+
+def _max_abs(a, b):
+    return max((x - y).abs().max().item() for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_eps_f64(alg):
+    g = load_case("round_eps_f64")
+    out = oracle.round_tt(g["inp"], eps=1e-8, algorithm=alg)
+    assert oracle.tt_ranks(out) == oracle.tt_ranks(g[alg])
+    assert _max_abs(out, g[alg]) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_rmax_f32(alg):
+    g = load_case("round_rmax_f32")
+    out = oracle.round_tt(g["inp"], rmax=3, algorithm=alg)
+    assert oracle.tt_ranks(out) == [1, 3, 3, 3, 3, 1]
+    assert _max_abs(out, g[alg]) < 2e-3  # float32 LAPACK, flat randn spectrum
+    assert (oracle.tt_to_dense(out) - oracle.tt_to_dense(g[alg])).norm() / oracle.tt_to_dense(g[alg]).norm() < 1e-4
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_batch_f64(alg):
+    g = load_case("round_batch_f64")
+    out = oracle.round_tt(g["inp"], rmax=2, algorithm=alg, batch=True)
+    assert _max_abs(out, g[alg]) < 1e-10
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_dense_f64(alg):
+    g = load_case("dense_f64")
+    out = oracle.dense_to_tt(g["X"], 4, algorithm=alg)
+    assert oracle.tt_ranks(out) == [1, 4, 4, 4, 4, 1]
+    assert _max_abs(out, g[alg]) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_dense_batch_f32(alg):
+    g = load_case("dense_batch_f32")
+    out = oracle.dense_to_tt(g["X"], 3, algorithm=alg, batch=True)
+    d_out = oracle.tt_to_dense(out, batch=True)
+    d_ref = oracle.tt_to_dense(g[alg], batch=True)
+    assert (d_out - d_ref).norm() / d_ref.norm() < 1e-4
+
+
+def test_c0_input_checksum_and_result():
+    meta = load_meta()["cases"]["c0_16x4_rmax4_f32"]
+    g = load_case("c0_16x4_rmax4_f32")
+    torch.manual_seed(0)
+    X = torch.randn(16, 16, 16, 16, dtype=torch.float32)
+    assert abs(float(X.double().sum()) - meta["x_sum"]) < 1e-6
+    assert abs(float((X.double() ** 2).sum()) - meta["x_sumsq"]) < 1e-6
+    for alg in ("svd", "eig"):
+        out = oracle.round_tt(oracle.full_rank_tt(X), rmax=4, algorithm=alg)
+        assert oracle.tt_ranks(out) == [1, 4, 4, 4, 1]
+        d_out, d_ref = oracle.tt_to_dense(out), oracle.tt_to_dense(g[alg])
+        assert (d_out - d_ref).norm() / d_ref.norm() < 1e-4
+        # approximation error (gauge invariant) agrees with the reference's
+        e_out = (d_out - X).norm() / X.norm()
+        e_ref = (d_ref - X).norm() / X.norm()
+        assert abs(e_out - e_ref) < 1e-5
+
+
+def test_truncated_svd_calls():
+    g = load_case("truncated_svd_f64")
+    calls = load_meta()["cases"]["truncated_svd_f64"]["calls"]
+    for c in calls:
+        kw = {k: c[k] for k in ("eps", "rmax", "delta") if k in c}
+        u, v = oracle.truncated_svd(g["M_" + c["M"]], left_ortho=c["left_ortho"], algorithm=c["algorithm"], **kw)
+        assert u.shape == g[f"call{c['i']}_left"].shape, c
+        assert (u - g[f"call{c['i']}_left"]).abs().max() < 1e-10, c
+        assert (v - g[f"call{c['i']}_right"]).abs().max() < 1e-10, c
+    for alg in ("svd", "eig"):
+        u, v = oracle.truncated_svd(g["Mb"], batch=True, algorithm=alg)
+        assert (u - g[f"batch_{alg}_left"]).abs().max() < 1e-9
+        assert (v - g[f"batch_{alg}_right"]).abs().max() < 1e-9
+
+
+def test_truncated_svd_errors():
+    M = torch.rand(4, 5)
+    with pytest.raises(ValueError):
+        oracle.truncated_svd(M, delta=0.1, eps=0.1)
+    with pytest.raises(AssertionError):
+        oracle.truncated_svd(M, algorithm="qr")
+
+
+def test_orthogonalize():
+    g = load_case("orthogonalize_f64")
+    a = [c.clone() for c in g["inp"]]; oracle.left_orthogonalize(a, 0)
+    b = [c.clone() for c in g["inp"]]; oracle.right_orthogonalize(b, 4)
+    c = [x.clone() for x in g["inp"]]; oracle.orthogonalize(c, 2)
+    d = [x.clone() for x in g["inp"]]; oracle.orthogonalize(d, 4)
+    assert _max_abs(a, g["left0"]) < 1e-12
+    assert _max_abs(b, g["right4"]) < 1e-12
+    assert _max_abs(c, g["orth2"]) < 1e-12
+    assert _max_abs(d, g["orth4"]) < 1e-12
+
+
+def test_known_answers_notebook():
+    """decompositions.ipynb cell 3 (ranks_tt=3) and cell 18 (round_tt(eps=1e-5))."""
+    ka = load_meta()["known_answers"]["measured_with_reference_here"]
+    full = analytic_128()
+    t3 = oracle.dense_to_tt(full, 3)
+    assert oracle.tt_ranks(t3) == [1, 3, 3, 1] == ka["ranks_tt3"]
+    e3 = ((oracle.tt_to_dense(t3) - full).norm() / full.norm()).item()
+    assert abs(e3 - ka["relerr_tt3"]) < 1e-9 and abs(e3 - 0.0005) < 5e-5
+    t = oracle.round_tt(oracle.full_rank_tt(full), eps=1e-5)
+    assert oracle.tt_ranks(t) == [1, 4, 6, 1] == ka["ranks_eps1e-5_svd"]
+    e = ((oracle.tt_to_dense(t) - full).norm() / full.norm()).item()
+    assert abs(e - 8.3358e-06) < 1e-9

@@ -1,0 +1,23 @@
+"""Backend selection: CPU tensors -> host mirror, device tensors -> HIP kernels (no fallback)."""
+
+import torch
+
+from . import _hostops
+
+
+def ops_for(t: torch.Tensor):
+    """Return the module implementing the sweeps for tensor ``t``.
+
+    A CUDA/HIP tensor ALWAYS maps to the hand-written kernels; if the library is missing
+    or the dtype is unsupported this raises -- it never silently computes on the CPU or
+    through torch's own GPU linear algebra.
+    """
+    if t.device.type == "cpu":
+        return _hostops
+    if t.device.type != "cuda":
+        raise RuntimeError(f"tntorch_amd: unsupported device {t.device}")
+    from . import _hip, _hipops
+
+    _hip.lib()  # raises RuntimeError if libttround_hip.so has not been built
+    _hip.dtype_code(t.dtype)  # raises TypeError for dtypes the kernels do not implement
+    return _hipops

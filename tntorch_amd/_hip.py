@@ -1,0 +1,263 @@
+"""ctypes binding of ``libttround_hip.so`` (the C ABI declared in ``include/ttround_hip.h``).
+
+There is no fallback: a CUDA/HIP tensor reaching the hot path without the built
+library raises ``RuntimeError``.  Torch is used here only for device memory
+(``torch.empty``) and to obtain the current HIP stream.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttround_hip.so")
+
+F32, F64 = 0, 1
+SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
+EIG_RAW, EIG_REF = 0, 1
+PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/ttround_hip.h one to one
+_SIGNATURES = {
+    "ttr_version": (c_int, []),
+    "ttr_last_error": (c_char_p, []),
+    "ttr_qr_max_cols": (c_int, [c_int]),
+    "ttr_eigh_max_n_lds": (c_int, [c_int]),
+    "ttr_gemm_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "ttr_gemm": (
+        c_int,
+        [c_int, c_int, c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
+         c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_qr_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "ttr_qr": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_eigh_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
+    "ttr_eigh_trunc": (
+        c_int,
+        [c_int, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+         c_int, c_int, c_double, c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_norm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ttr_scale_cols": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
+         c_void_p, c_int64, c_int64, c_void_p],
+    ),
+    "ttr_prof_enable": (c_int, [c_int]),
+    "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load the shared library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP kernels are not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C tntorch_amd/csrc`). "
+                "tntorch_amd has no CPU/torch fallback for GPU tensors."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = lib().ttr_last_error().decode(errors="replace")
+        if code == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        if code == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed ({code}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.float64:
+        return F64
+    raise TypeError(f"tntorch_amd HIP path supports float32/float64 tensors only, got {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _mat(t: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+    """Return (tensor, ld, batch_stride) of a [B, r, c] tensor whose rows are contiguous."""
+    assert t.dim() == 3 and t.is_cuda
+    B, r, c = t.shape
+    ok = (c == 1 or t.stride(2) == 1) and (r == 1 or t.stride(1) >= max(c, 1)) and (B == 1 or t.stride(0) >= 0)
+    if not ok:
+        t = t.contiguous()
+    ld = t.stride(1) if r > 1 else max(c, 1)
+    bs = t.stride(0) if B > 1 else r * ld
+    return t, int(ld), int(bs)
+
+
+def max_qr_cols(dt: torch.dtype) -> int:
+    return lib().ttr_qr_max_cols(dtype_code(dt))
+
+
+def max_eigh_n() -> int:
+    return 1024
+
+
+# ----------------------------------------------------------------------------------------------
+def gemm(
+    A: torch.Tensor,
+    B: torch.Tensor,
+    transA: bool = False,
+    transB: bool = False,
+    rowscale: Optional[torch.Tensor] = None,
+    rowscale_mode: int = SCALE_NONE,
+    colscale: Optional[torch.Tensor] = None,
+    colscale_mode: int = SCALE_NONE,
+) -> torch.Tensor:
+    """C[b] = scale(op(A[b]) @ op(B[b])) for [batch, ., .] tensors; returns a fresh tensor."""
+    L = lib()
+    dt = dtype_code(A.dtype)
+    assert A.dtype == B.dtype and A.shape[0] == B.shape[0]
+    A, lda, sA = _mat(A)
+    B, ldb, sB = _mat(B)
+    batch = A.shape[0]
+    M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
+    K2, N = (B.shape[2], B.shape[1]) if transB else (B.shape[1], B.shape[2])
+    if K != K2:
+        raise ValueError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    C = torch.empty((batch, M, N), dtype=A.dtype, device=A.device)
+    if M == 0 or N == 0 or batch == 0:
+        return C
+    rs_ptr, rs_stride = None, 0
+    if rowscale is not None:
+        rowscale = rowscale.contiguous()
+        rs_ptr, rs_stride = rowscale.data_ptr(), rowscale.shape[-1]
+    cs_ptr, cs_stride = None, 0
+    if colscale is not None:
+        colscale = colscale.contiguous()
+        cs_ptr, cs_stride = colscale.data_ptr(), colscale.shape[-1]
+    wsb = L.ttr_gemm_workspace_bytes(dt, M, N, K, batch)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=A.device) if wsb > 0 else None
+    code = L.ttr_gemm(
+        dt, int(transA), int(transB), M, N, K,
+        A.data_ptr(), lda, sA, B.data_ptr(), ldb, sB, C.data_ptr(), N, M * N,
+        rs_ptr, rs_stride, rowscale_mode if rowscale is not None else SCALE_NONE,
+        cs_ptr, cs_stride, colscale_mode if colscale is not None else SCALE_NONE,
+        batch, ws.data_ptr() if ws is not None else None, wsb, _stream(),
+    )
+    _check(code, "ttr_gemm")
+    return C
+
+
+def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Reduced Householder QR of [batch, m, n] -> Q [batch, m, k], R [batch, k, n]."""
+    L = lib()
+    dt = dtype_code(A.dtype)
+    A, lda, sA = _mat(A)
+    batch, m, n = A.shape
+    k = min(m, n)
+    Q = torch.empty((batch, m, k), dtype=A.dtype, device=A.device)
+    R = torch.empty((batch, k, n), dtype=A.dtype, device=A.device)
+    if batch == 0:
+        return Q, R
+    wsb = L.ttr_qr_workspace_bytes(dt, m, n, batch)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=A.device)
+    code = L.ttr_qr(dt, m, n, batch, A.data_ptr(), lda, sA, Q.data_ptr(), k, m * k, R.data_ptr(), n, k * n,
+                    ws.data_ptr(), wsb, _stream())
+    _check(code, "ttr_qr")
+    return Q, R
+
+
+def eigh_trunc(
+    G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
+    decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard)."""
+    L = lib()
+    dt = dtype_code(G.dtype)
+    G, ldg, sG = _mat(G)
+    batch, n, _ = G.shape
+    V = torch.empty((batch, n, n), dtype=G.dtype, device=G.device)
+    sigma = torch.empty((batch, n), dtype=G.dtype, device=G.device)
+    info = torch.empty((batch,), dtype=torch.int32, device=G.device)
+    if batch == 0:
+        return V, sigma, info
+    wsb = L.ttr_eigh_workspace_bytes(dt, n, batch)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=G.device) if wsb > 0 else None
+    rmax = int(min(max(int(rmax), 1), 2**31 - 1))
+    code = L.ttr_eigh_trunc(
+        dt, n, batch, G.data_ptr(), ldg, sG, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
+        eig_mode, int(bool(use_delta)), float(delta2), rmax,
+        ws.data_ptr() if ws is not None else None, wsb, _stream(),
+    )
+    _check(code, "ttr_eigh_trunc")
+    return V, sigma, info
+
+
+def norm(x: torch.Tensor) -> torch.Tensor:
+    """Frobenius norm per batch item of a [batch, ...] tensor -> [batch]."""
+    L = lib()
+    dt = dtype_code(x.dtype)
+    x = x.contiguous()
+    batch = x.shape[0]
+    count = x[0].numel() if batch > 0 else 0
+    out = torch.empty((batch,), dtype=x.dtype, device=x.device)
+    if batch == 0:
+        return out
+    _check(L.ttr_norm(dt, count, batch, x.data_ptr(), count, out.data_ptr(), _stream()), "ttr_norm")
+    return out
+
+
+def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
+    """out[b, i, j] = X[b, i, j] * s[b, j] (SCALE_MUL) or / s[b, j] (SCALE_DIV)."""
+    L = lib()
+    dt = dtype_code(X.dtype)
+    X, ldx, sX = _mat(X)
+    s = s.contiguous()
+    batch, rows, cols = X.shape
+    out = torch.empty((batch, rows, cols), dtype=X.dtype, device=X.device)
+    if out.numel() == 0:
+        return out
+    code = L.ttr_scale_cols(dt, rows, cols, batch, X.data_ptr(), ldx, sX, s.data_ptr(), s.shape[-1], mode,
+                            out.data_ptr(), cols, rows * cols, _stream())
+    _check(code, "ttr_scale_cols")
+    return out
+
+
+def prof_enable(on: bool):
+    lib().ttr_prof_enable(int(on))
+
+
+def prof_collect():
+    n = len(PROF_KINDS)
+    ms = (c_double * n)()
+    cnt = (c_int64 * n)()
+    lib().ttr_prof_collect(ms, cnt)
+    return {k: {"ms": ms[i], "launches": cnt[i]} for i, k in enumerate(PROF_KINDS)}

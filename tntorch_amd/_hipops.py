@@ -1,0 +1,243 @@
+"""Device-side (HIP) implementation of the TT sweeps: orchestration of the C-ABI kernels.
+
+Everything here works on batch-normalised tensors (``[B, ...]``; the non-batch API adds
+a leading 1).  Arithmetic is done exclusively by ``libttround_hip.so``; torch only
+allocates, reshapes, slices and copies.
+
+Algorithms (reference call sites in brackets):
+
+* ``qr``            Householder TSQR                               [tensor.py:1816]
+* ``truncate``      truncated SVD of ``M`` [round.py:52-187]:
+    - ``algorithm='eig'``: Gram -> Jacobi eigh (with the reference's 1e-8 clamp) ->
+      rank rule -> projection; one pass, Gram accuracy (sigma resolved down to
+      ~sqrt(eps)*sigma_max), exactly what round.py:101-135 computes.
+    - ``algorithm='svd'``: two Gram/Jacobi passes.  Pass 1 rotates ``M`` into nearly
+      orthogonal rows (columns); pass 2 re-computes the Gram matrix of the rotated
+      matrix, which is now graded/diagonally dominant, so Jacobi resolves every sigma to
+      high *relative* accuracy -- the accuracy class of LAPACK gesdd [round.py:96]
+      without ever forming the (I r)x(I r) right factor the reference throws away.
+* ``round_tt``      L2R QR sweep + R2L truncation sweep            [tensor.py:2008-2083]
+* ``dense_tt_svd``  right-to-left TT-SVD on the dense unfoldings; mathematically equal to
+                    the reference's identity-padded ``_full_rank_tt`` + ``round_tt``
+                    [tensor.py:10-104, 401-408], but feasible at scale.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+
+INT32_MAX = 2**31 - 1
+
+
+def _rank_cap(rmax: Optional[int], k: int) -> int:
+    if rmax is None:
+        rmax = INT32_MAX
+    return max(1, int(min(int(rmax), k)))
+
+
+def qr(A3: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _hip.qr(A3)
+
+
+class Truncation:
+    """Result of ``truncate``: ``left_core`` (m x r), optional column scale, ``right`` (r x n)."""
+
+    __slots__ = ("left", "colscale", "right", "rank", "zero")
+
+    def __init__(self, left, colscale, right, rank, zero=False):
+        self.left, self.colscale, self.right, self.rank, self.zero = left, colscale, right, rank, zero
+
+    def left_scaled(self) -> torch.Tensor:
+        if self.colscale is None:
+            return self.left
+        return _hip.scale_cols(self.left, self.colscale, _hip.SCALE_MUL)
+
+
+def _select_rank(info: torch.Tensor, batch: bool, rmax: Optional[int], k: int) -> int:
+    if batch:  # round.py:149-150: no eps truncation, no device->host sync
+        return _rank_cap(rmax, k)
+    return int(info[0].item())  # one readback per truncation, as round.py:150-158
+
+
+def truncate(
+    M: torch.Tensor,
+    delta: Optional[float],
+    rmax: Optional[int],
+    left_ortho: bool,
+    algorithm: str,
+    batch: bool,
+) -> Truncation:
+    """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
+
+    ``left_ortho=False`` (the branch round_tt uses): ``right`` has orthonormal rows,
+    ``left * colscale`` carries the singular values.  ``left_ortho=True``: ``left`` is
+    orthonormal, ``right`` carries them.
+    """
+    Bt, m, n = M.shape
+    k = min(m, n)
+    use_delta = not batch
+    delta2 = float(delta) ** 2 if (delta is not None and use_delta) else 0.0
+    cap = INT32_MAX if rmax is None else int(rmax)
+    left_side = m <= n  # round.py:104-109; the 'svd' path is orientation-free
+    ref_clamp = algorithm == "eig"
+
+    if algorithm == "svd":
+        # ---- pass 1: rotate into (nearly) orthogonal rows / columns
+        if left_side:
+            G = _hip.gemm(M, M, transB=True)
+            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k)
+            Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
+            G = _hip.gemm(Mw, Mw, transB=True)
+        else:
+            G = _hip.gemm(M, M, transA=True)
+            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k)
+            Mw = _hip.gemm(M, V1)                        # M V1
+            G = _hip.gemm(Mw, Mw, transA=True)
+    else:
+        V1 = None
+        Mw = M
+        G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+
+    V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap)
+    r = _select_rank(info, batch, rmax, k)
+    if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
+        z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)
+        z_r = torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device)
+        return Truncation(z_l, None, z_r, 1, zero=True)
+    Vr = V[:, :, :r]
+
+    if left_side:
+        # right = diag(1/sigma) Vr^T Mw   (or Vr^T Mw when left_ortho)
+        if left_ortho:
+            right = _hip.gemm(Vr, Mw, transA=True)
+        else:
+            right = _hip.gemm(Vr, Mw, transA=True, rowscale=sig, rowscale_mode=_hip.SCALE_DIV)
+        U = _hip.gemm(V1, Vr) if V1 is not None else Vr
+        return Truncation(U, None if left_ortho else sig, right, r)
+    # right side: left = Mw Vr (= U sigma); right = (V1 Vr)^T
+    if left_ortho:
+        left = _hip.gemm(Mw, Vr, colscale=sig, colscale_mode=_hip.SCALE_DIV)
+        if V1 is not None:
+            right = _hip.gemm(Vr, V1, transA=True, transB=True, rowscale=sig, rowscale_mode=_hip.SCALE_MUL)
+        else:
+            right = _hip.scale_cols(Vr, sig, _hip.SCALE_MUL).transpose(1, 2).contiguous()
+    else:
+        left = _hip.gemm(Mw, Vr)
+        if V1 is not None:
+            right = _hip.gemm(Vr, V1, transA=True, transB=True)
+        else:
+            right = Vr.transpose(1, 2).contiguous()
+    return Truncation(left, None, right, r)
+
+
+def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
+    """round.py:52-187 on a [B, m, n] device tensor -> (left [B, m, r], M2 [B, r, n])."""
+    if delta is None and eps is not None:  # round.py:79-80
+        delta = eps * float(_hip.norm(M3.reshape(1, -1))[0].item())
+    if delta is None:
+        delta = 0.0
+    t = truncate(M3, delta, rmax, left_ortho, algorithm, batch)
+    left = t.left_scaled()
+    if not left.is_contiguous():
+        left = left.contiguous()
+    return left, t.right
+
+
+# ----------------------------------------------------------------------------------------------
+def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+    """tensor.py:1800-1833 on [B, r0, I, r1] cores (in place on the list); returns R [B, k, r1]."""
+    Bt, r0, I, r1 = c[mu].shape
+    Q, R = qr(c[mu].reshape(Bt, r0 * I, r1))
+    k = Q.shape[2]
+    c[mu] = Q.reshape(Bt, r0, I, k)
+    nxt = c[mu + 1]
+    pushed = _hip.gemm(R, nxt.reshape(Bt, nxt.shape[1], nxt.shape[2] * nxt.shape[3]))
+    c[mu + 1] = pushed.reshape(Bt, k, nxt.shape[2], nxt.shape[3])
+    return R
+
+
+def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+    """tensor.py:1835-1879: QR of the transposed right unfolding; returns L [B, r0, k]."""
+    Bt, r0, I, r1 = c[mu].shape
+    Mt = c[mu].reshape(Bt, r0, I * r1).transpose(1, 2).contiguous()  # layout only
+    Q, Lt = qr(Mt)  # Mt (I r1 x r0) = Q (I r1 x k) Lt (k x r0)
+    k = Q.shape[2]
+    c[mu] = Q.transpose(1, 2).contiguous().reshape(Bt, k, I, r1)
+    L = Lt.transpose(1, 2).contiguous()  # r0 x k
+    prev = c[mu - 1]
+    pushed = _hip.gemm(prev.reshape(Bt, prev.shape[1] * prev.shape[2], r0), L)
+    c[mu - 1] = pushed.reshape(Bt, prev.shape[1], prev.shape[2], k)
+    return L
+
+
+def round_tt(
+    cores4: Sequence[torch.Tensor],
+    eps: float,
+    rmax: Sequence[Optional[int]],
+    algorithm: str,
+    batch: bool,
+) -> List[torch.Tensor]:
+    """tensor.py:2008-2083 on [B, r0, I, r1] cores.  Returns new cores (inputs untouched)."""
+    c = list(cores4)
+    N = len(c)
+    for mu in range(N - 1):  # tensor.py:1905-1906
+        left_orthogonalize(c, mu)
+    if batch:  # tensor.py:2036-2037
+        delta = None
+    else:  # tensor.py:2039-2051
+        nrm = float(_hip.norm(c[-1].reshape(1, -1))[0].item())
+        delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
+    for mu in range(N - 1, 0, -1):  # tensor.py:2053-2083
+        Bt, R, I, rn = c[mu].shape
+        t = truncate(c[mu].reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch)
+        c[mu] = t.right.reshape(Bt, t.rank, I, rn)
+        prev = c[mu - 1]
+        p2 = prev.reshape(Bt, prev.shape[1] * prev.shape[2], R)
+        if t.colscale is not None:  # fused (core @ U) * sigma
+            pushed = _hip.gemm(p2, t.left, colscale=t.colscale, colscale_mode=_hip.SCALE_MUL)
+        else:
+            pushed = _hip.gemm(p2, t.left)
+        c[mu - 1] = pushed.reshape(Bt, prev.shape[1], prev.shape[2], t.rank)
+    return c
+
+
+def dense_tt_svd(
+    X: torch.Tensor,
+    eps: float,
+    rmax: Sequence[Optional[int]],
+    algorithm: str,
+    batch: bool,
+) -> List[torch.Tensor]:
+    """Dense [B, I_1..I_N] -> TT cores [B, r, I, r'] by a right-to-left TT-SVD on the unfoldings.
+
+    Equivalent to ``_full_rank_tt`` + ``round_tt(eps, rmax)`` of the reference
+    (tensor.py:10-104, 401-408): after the full left orthogonalisation the right unfolding
+    of the last core has the singular values / right singular vectors of the dense
+    unfolding, and ||last core|| = ||X|| (so delta is identical).
+    """
+    Bt = X.shape[0]
+    shape = list(X.shape[1:])
+    N = len(shape)
+    if N == 1:
+        return [X.reshape(Bt, 1, shape[0], 1).clone()]
+    if batch:
+        delta = None
+    else:
+        nrm = float(_hip.norm(X.reshape(1, -1))[0].item())
+        delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
+    cores: List[Optional[torch.Tensor]] = [None] * N
+    C = X.reshape(Bt, -1, shape[-1])
+    rn = 1
+    for kdim in range(N - 1, 0, -1):
+        Mk = C.reshape(Bt, -1, shape[kdim] * rn)
+        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch)
+        cores[kdim] = t.right.reshape(Bt, t.rank, shape[kdim], rn)
+        C = t.left_scaled()
+        rn = t.rank
+    cores[0] = C.reshape(Bt, 1, shape[0], rn).contiguous()
+    return cores  # type: ignore[return-value]

@@ -1,0 +1,157 @@
+"""Host (CPU tensor) mirror of the hot path, on batch-normalised ``[B, ...]`` tensors.
+
+This is the "plumbing" path of BASELINE config C0 (``tn.Tensor(torch.randn(16,16,16,16))
+.round_tt(rmax=4)`` on CPU PyTorch): same operator sequence as the reference
+(torch.linalg.qr / svd / eigh on the CPU), so CPU results agree with the reference to
+round-off.  It is selected ONLY for CPU tensors; device tensors never come here
+(``_dispatch.ops_for`` raises instead of falling back).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+INT32_MAX = 2**31 - 1
+
+
+def _t(M):
+    return M.transpose(-1, -2)
+
+
+def qr(A3: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return torch.linalg.qr(A3)  # tensor.py:1816 (reduced)
+
+
+def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
+    """round.py:52-187 with the batch dim always present ([B, m, n]; B == 1 when not batch)."""
+    if delta is None and eps is not None:  # round.py:79-80
+        delta = eps * torch.norm(M3).item()
+    if delta is None:
+        delta = 0
+    if rmax is None:
+        rmax = INT32_MAX
+    Bt, m, n = M3.shape
+
+    if algorithm == "svd":  # round.py:94-100
+        U, sig = torch.linalg.svd(M3)[:2]
+        side = "left"
+    else:  # round.py:101-135
+        if m <= n:
+            gram, side = M3 @ _t(M3), "left"
+        else:
+            gram, side = _t(M3) @ M3, "right"
+        w, U = torch.linalg.eigh(gram)
+        w = torch.where(w < 0, torch.zeros_like(w) + 1e-8, w)
+        sig = torch.sqrt(w)
+        sig, idx = torch.sort(sig, dim=-1, descending=True)
+        U = torch.gather(U, 2, idx[:, None, :].expand(-1, U.shape[1], -1))
+
+    if sig.max() < 1e-13:  # round.py:137-145 (kept on M's device/dtype)
+        return M3.new_zeros(Bt, m, 1), M3.new_zeros(Bt, 1, n)
+
+    S = sig**2
+    k = S.shape[-1]
+    if batch:  # round.py:149-150
+        rank = max(1, int(min(rmax, k)))
+    else:  # round.py:152-158
+        tail = torch.cumsum(torch.flip(S[0], [0]), dim=0) <= delta**2
+        where = torch.where(tail)[0]
+        if len(where) == 0:
+            rank = max(1, int(min(rmax, k)))
+        else:
+            rank = max(1, int(min(rmax, k - 1 - int(where[-1]))))
+
+    left = U[..., :rank]
+    sr = sig[..., :rank].to(M3.dtype)
+    if side == "left":  # round.py:164-172
+        if left_ortho:
+            M2 = _t(left) @ M3
+        else:
+            M2 = (1.0 / sr)[..., None] * _t(left) @ M3
+            left = left * sr[..., None, :]
+    else:  # round.py:173-182
+        if left_ortho:
+            newleft = M3 @ (left * (1.0 / sr)[..., None, :])
+            M2 = _t(left * sr[..., None, :])
+            left = newleft
+        else:
+            newleft = M3 @ left
+            M2 = _t(left)
+            left = newleft
+    return left, M2
+
+
+def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+    """tensor.py:1800-1833 on [B, r0, I, r1] cores."""
+    Bt, r0, I, r1 = c[mu].shape
+    Q, R = qr(c[mu].reshape(Bt, r0 * I, r1))
+    k = Q.shape[2]
+    c[mu] = Q.reshape(Bt, r0, I, k)
+    nxt = c[mu + 1]
+    c[mu + 1] = (R @ nxt.reshape(Bt, nxt.shape[1], -1)).reshape(Bt, k, nxt.shape[2], nxt.shape[3])
+    return R
+
+
+def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+    """tensor.py:1835-1879."""
+    Bt, r0, I, r1 = c[mu].shape
+    Q, Lt = qr(_t(c[mu].reshape(Bt, r0, I * r1)))
+    Q, L = _t(Q), _t(Lt)
+    k = Q.shape[1]
+    c[mu] = Q.reshape(Bt, k, I, r1)
+    prev = c[mu - 1]
+    c[mu - 1] = (prev.reshape(Bt, prev.shape[1] * prev.shape[2], r0) @ L).reshape(Bt, prev.shape[1], prev.shape[2], k)
+    return L
+
+
+def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch) -> List[torch.Tensor]:
+    """tensor.py:2008-2083."""
+    c = list(cores4)
+    N = len(c)
+    for mu in range(N - 1):
+        left_orthogonalize(c, mu)
+    if batch:
+        delta = None
+    else:
+        delta = (eps / max(1.0, math.sqrt(N - 1))) * float(torch.norm(c[-1]).double().item())
+    for mu in range(N - 1, 0, -1):
+        Bt, R, I, rn = c[mu].shape
+        left, right = truncated_svd(c[mu].reshape(Bt, R, I * rn), delta, None, rmax[mu - 1], False, algorithm, batch)
+        left, right = left.to(c[mu].dtype), right.to(c[mu].dtype)
+        r = right.shape[1]
+        c[mu] = right.reshape(Bt, r, I, rn)
+        prev = c[mu - 1]
+        c[mu - 1] = (prev.reshape(Bt, prev.shape[1] * prev.shape[2], R) @ left).reshape(Bt, prev.shape[1], prev.shape[2], r)
+    return c
+
+
+def full_rank_tt(X: torch.Tensor) -> List[torch.Tensor]:
+    """tensor.py:10-104 on a batch-normalised dense tensor [B, I_1..I_N] (views/eye only)."""
+    Bt = X.shape[0]
+    shape = list(X.shape[1:])
+    N = len(shape)
+
+    def eye(n):
+        return torch.eye(n, dtype=X.dtype, device=X.device).repeat(Bt, 1, 1)
+
+    resh = X.reshape(Bt, shape[0], -1)
+    out = []
+    for n in range(1, N):
+        rows, cols = resh.shape[1], resh.shape[2]
+        if rows < cols:
+            out.append(eye(rows).reshape(Bt, rows // shape[n - 1], shape[n - 1], rows))
+            resh = resh.reshape(Bt, rows * shape[n], cols // shape[n])
+        else:
+            out.append(resh.reshape(Bt, rows // shape[n - 1], shape[n - 1], cols))
+            resh = eye(cols).reshape(Bt, cols * shape[n], cols // shape[n])
+    rows = resh.shape[1]
+    out.append(resh.reshape(Bt, rows // shape[N - 1], shape[N - 1], 1))
+    return out
+
+
+def dense_tt_svd(X: torch.Tensor, eps, rmax, algorithm, batch) -> List[torch.Tensor]:
+    """tensor.py:401-408 exactly as the reference does it: full-rank TT, then round_tt."""
+    return round_tt(full_rank_tt(X), eps, rmax, algorithm, batch)

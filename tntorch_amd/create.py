@@ -1,0 +1,77 @@
+"""Random / constant TT constructors used to feed the rounding path.
+
+Mirror of the TT subset of ``tntorch/create.py`` (``rand``, ``randn``, ``ones``, ``zeros``,
+``_create`` at create.py:210-357): cores of shape ``[R_k, I_k, R_{k+1}]`` filled core by core
+in order, so a seeded call reproduces the reference's cores exactly.
+"""
+
+from typing import Any, Optional, Sequence, Union
+
+import torch
+
+from .tensor import Tensor
+
+__all__ = ["rand", "randn", "rand_like", "randn_like", "ones", "zeros", "full"]
+
+
+def _create(function, *shape, ranks_tt=None, ranks_cp=None, ranks_tucker=None, requires_grad=False, device=None,
+            batch=False, dtype=None):
+    if ranks_cp is not None or ranks_tucker is not None:
+        raise NotImplementedError("tntorch_amd creates pure TT tensors only (ranks_cp/ranks_tucker are out of scope)")
+    if hasattr(shape[0], "__len__"):
+        shape = shape[0]
+    shape = [int(s) for s in shape]
+    N = len(shape) - 1 if batch else len(shape)
+    spatial = shape[1:] if batch else shape
+    if ranks_tt is None:
+        raise ValueError("Specify at least one of: ranks_tt ranks_cp, ranks_tucker")
+    if not hasattr(ranks_tt, "__len__"):
+        ranks_tt = [ranks_tt] * (N - 1)
+    ranks = [1] + [int(r) for r in ranks_tt] + [1]
+    assert len(ranks) == N + 1
+    lead = [shape[0]] if batch else []
+    cores = [
+        function(lead + [ranks[n], spatial[n], ranks[n + 1]], requires_grad=requires_grad, device=device, dtype=dtype)
+        for n in range(N)
+    ]
+    return Tensor(cores, batch=batch)
+
+
+def rand(*shape, **kwargs):
+    """TT tensor whose cores are i.i.d. U[0,1) (create.py:38-57)."""
+    return _create(torch.rand, *shape, **kwargs)
+
+
+def randn(*shape, **kwargs):
+    """TT tensor whose cores are i.i.d. N(0,1) (create.py:60-79)."""
+    return _create(torch.randn, *shape, **kwargs)
+
+
+def rand_like(t, **kwargs):
+    return _create(torch.rand, t.shape, batch=t.batch, **kwargs)
+
+
+def randn_like(t, **kwargs):
+    return _create(torch.randn, t.shape, batch=t.batch, **kwargs)
+
+
+def full(shape, fill_value, device=None, batch=False, dtype=None):
+    """Rank-1 TT tensor filled with ``fill_value`` (create.py: ones/zeros/full)."""
+    shape = [int(s) for s in shape]
+    spatial = shape[1:] if batch else shape
+    lead = [shape[0]] if batch else []
+    cores = [torch.ones(lead + [1, s, 1], device=device, dtype=dtype) for s in spatial]
+    cores[0] = cores[0] * fill_value
+    return Tensor(cores, batch=batch)
+
+
+def ones(*shape, **kwargs):
+    if hasattr(shape[0], "__len__"):
+        shape = shape[0]
+    return full(list(shape), 1.0, **kwargs)
+
+
+def zeros(*shape, **kwargs):
+    if hasattr(shape[0], "__len__"):
+        shape = shape[0]
+    return full(list(shape), 0.0, **kwargs)

@@ -1,0 +1,267 @@
+// extern "C" surface of libttround_hip.so + the small streaming kernels (norm, column scaling),
+// error reporting and the per-kernel HIP-event profiler used by bench.py.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "ttr_common.h"
+
+namespace ttr {
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return TTR_E_HIP;
+}
+
+// ------------------------------------------------------------------ profiler
+struct ProfRec {
+  int kind;
+  hipEvent_t start, stop;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+ProfScope::ProfScope(int kind_, hipStream_t s) : kind(kind_), stream(s), slot(nullptr) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.kind = kind;
+  if (!g_prof_pool.empty()) {
+    r.start = g_prof_pool.back().first;
+    r.stop = g_prof_pool.back().second;
+    g_prof_pool.pop_back();
+  } else {
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  }
+  (void)hipEventRecord(r.start, stream);
+  g_prof_recs.push_back(r);
+  slot = (void*)(uintptr_t)g_prof_recs.size();  // index + 1
+}
+
+ProfScope::~ProfScope() {
+  if (!slot) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const size_t idx = (size_t)(uintptr_t)slot - 1;
+  if (idx < g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, stream);
+}
+
+// ------------------------------------------------------------------ small kernels
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_kernel(const T* __restrict__ x, int64_t count, int64_t stride_x,
+                                                        T* __restrict__ out) {
+  __shared__ double red[kThreads / kWave];
+  const int64_t b = blockIdx.x;
+  const T* __restrict__ xb = x + b * stride_x;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < count; i += kThreads) {
+    const double v = (double)xb[i];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) s += red[w];
+    out[b] = (T)sqrt(s);
+  }
+}
+
+// Large single vectors: two-stage (partials per workgroup, then a finishing workgroup).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sumsq_partial_kernel(const T* __restrict__ x, int64_t count,
+                                                                 double* __restrict__ part) {
+  __shared__ double red[kThreads / kWave];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads) {
+    const double v = (double)x[i];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) s += red[w];
+    part[blockIdx.x] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scale_cols_kernel(int64_t rows, int64_t cols, const T* __restrict__ in,
+                                                              int64_t ldi, int64_t stride_in, const T* __restrict__ s,
+                                                              int64_t stride_s, int mode, T* __restrict__ out,
+                                                              int64_t ldo, int64_t stride_out) {
+  const int64_t b = blockIdx.y;
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = idx / cols, j = idx % cols;
+    const T v = in[b * stride_in + i * ldi + j];
+    const T sj = s[b * stride_s + j];
+    T r;
+    if (mode == TTR_SCALE_MUL) r = v * sj;
+    else r = (fabs((double)sj) < (double)Num<T>::tiny()) ? T(0) : v / sj;
+    out[b * stride_out + i * ldo + j] = r;
+  }
+}
+
+// implemented in the other translation units
+int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                  int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
+                  const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
+                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream);
+int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch);
+int qr_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
+                int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes,
+                hipStream_t stream);
+int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
+int qr_max_cols(int dtype);
+int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+                  int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
+                  int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream);
+int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
+int eigh_max_n_lds(int dtype);
+
+static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
+
+}  // namespace ttr
+
+using namespace ttr;
+
+extern "C" {
+
+int ttr_version(void) { return 1; }
+
+const char* ttr_last_error(void) { return g_err.c_str(); }
+
+int ttr_qr_max_cols(int dtype) { return qr_max_cols(dtype); }
+int ttr_eigh_max_n_lds(int dtype) { return eigh_max_n_lds(dtype); }
+
+int64_t ttr_gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch) {
+  return gemm_workspace_bytes(dtype, M, N, K, batch);
+}
+
+int ttr_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+             int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
+             const void* rowscale, int64_t stride_rs, int rowscale_mode, const void* colscale, int64_t stride_cs,
+             int colscale_mode, int64_t batch, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_gemm: bad dtype %d", dtype);
+  TTR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, TTR_E_INVALID, "ttr_gemm: negative dimension");
+  if (M == 0 || N == 0 || batch == 0) return TTR_OK;
+  TTR_REQUIRE(K >= 1, TTR_E_INVALID, "ttr_gemm: K must be >= 1");
+  TTR_REQUIRE(A && B && C, TTR_E_INVALID, "ttr_gemm: null operand");
+  return gemm_dispatch(dtype, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rowscale,
+                       stride_rs, rowscale_mode, colscale, stride_cs, colscale_mode, batch, workspace, workspace_bytes,
+                       (hipStream_t)stream);
+}
+
+int64_t ttr_qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
+  return qr_workspace_bytes(dtype, m, n, batch);
+}
+
+int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
+           int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* workspace,
+           int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr: bad dtype %d", dtype);
+  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_qr: bad shape %lld x %lld", (long long)m, (long long)n);
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(A && Q && R && workspace, TTR_E_INVALID, "ttr_qr: null pointer");
+  return qr_dispatch(dtype, m, n, batch, A, lda, strideA, Q, ldq, strideQ, R, ldr, strideR, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return eigh_workspace_bytes(dtype, n, batch); }
+
+int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
+                   int use_delta, double delta2, int64_t rmax, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_trunc: bad dtype %d", dtype);
+  TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(G && V && sigma && info, TTR_E_INVALID, "ttr_eigh_trunc: null pointer");
+  return eigh_dispatch(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
+                       use_delta, delta2, rmax, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttr_norm(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_norm: bad dtype %d", dtype);
+  TTR_REQUIRE(count >= 0 && batch >= 0, TTR_E_INVALID, "ttr_norm: negative size");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(x && out, TTR_E_INVALID, "ttr_norm: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(norm_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (const float*)x, count,
+                       stride_x, (float*)out);
+  else
+    hipLaunchKernelGGL(norm_kernel<double>, dim3((unsigned)batch), dim3(kThreads), 0, s, (const double*)x, count,
+                       stride_x, (double*)out);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const void* in, int64_t ldi,
+                   int64_t stride_in, const void* sc, int64_t stride_s, int mode, void* out, int64_t ldo,
+                   int64_t stride_out, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_scale_cols: bad dtype %d", dtype);
+  TTR_REQUIRE(mode == TTR_SCALE_MUL || mode == TTR_SCALE_DIV, TTR_E_INVALID, "ttr_scale_cols: bad mode");
+  if (rows <= 0 || cols <= 0 || batch <= 0) return TTR_OK;
+  TTR_REQUIRE(in && sc && out, TTR_E_INVALID, "ttr_scale_cols: null pointer");
+  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_scale_cols: batch > 65535");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t gx = ceil_div(rows * cols, kThreads);
+  if (gx > 2048) gx = 2048;
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(scale_cols_kernel<float>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, s, rows, cols,
+                       (const float*)in, ldi, stride_in, (const float*)sc, stride_s, mode, (float*)out, ldo, stride_out);
+  else
+    hipLaunchKernelGGL(scale_cols_kernel<double>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, s, rows,
+                       cols, (const double*)in, ldi, stride_in, (const double*)sc, stride_s, mode, (double*)out, ldo,
+                       stride_out);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int ttr_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return TTR_OK;
+}
+
+int ttr_prof_collect(double* ms, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int k = 0; k < TTR_PROF_NKINDS; ++k) {
+    if (ms) ms[k] = 0.0;
+    if (launches) launches[k] = 0;
+  }
+  for (auto& r : g_prof_recs) {
+    if (hipEventSynchronize(r.stop) == hipSuccess) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess && r.kind >= 0 && r.kind < TTR_PROF_NKINDS) {
+        if (ms) ms[r.kind] += (double)t;
+        if (launches) launches[r.kind] += 1;
+      }
+    }
+    g_prof_pool.push_back({r.start, r.stop});
+  }
+  g_prof_recs.clear();
+  return TTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Shared device/host helpers for libttround_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ttround_hip.h"
+
+namespace ttr {
+
+constexpr int kThreads = 256;  // every kernel here runs 4 wave64 per workgroup
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------ errors
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+#define TTR_HIP_CHECK(expr)                                  \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return ::ttr::hip_fail(_e, #expr); \
+  } while (0)
+#define TTR_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      ::ttr::set_error(__VA_ARGS__);  \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+// ------------------------------------------------------------------ profiling (HIP events per kernel kind)
+struct ProfScope {
+  int kind;
+  hipStream_t stream;
+  void* slot;
+  ProfScope(int kind, hipStream_t s);
+  ~ProfScope();
+};
+
+// ------------------------------------------------------------------ MFMA 16x16x4 wrappers
+// A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<float> {
+  using Acc = f32x4;
+  static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+template <>
+struct Mfma<double> {
+  using Acc = f64x4;
+  static __device__ __forceinline__ Acc zero() { return Acc{0., 0., 0., 0.}; }
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // f64 C/D: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+
+// ------------------------------------------------------------------ wave reductions
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T>
+struct Num;
+template <>
+struct Num<float> {
+  static __device__ __forceinline__ float eps() { return 1.1920929e-07f; }
+  static __device__ __forceinline__ float tiny() { return 1.17549435e-38f; }
+  static __device__ __forceinline__ float big_theta() { return 1e18f; }
+};
+template <>
+struct Num<double> {
+  static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
+  static __device__ __forceinline__ double tiny() { return 2.2250738585072014e-308; }
+  static __device__ __forceinline__ double big_theta() { return 1e150; }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+}  // namespace ttr

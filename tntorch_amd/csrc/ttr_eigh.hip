@@ -1,0 +1,259 @@
+// Batched symmetric eigensolver + truncated_svd's rank rule, on device (gfx950).
+//
+// One workgroup per matrix runs a parallel-order cyclic two-sided Jacobi iteration on
+// G (n x n, symmetric PSD Gram matrix) with the eigenvector matrix V accumulated
+// alongside; both live in LDS (leading dimension n+1: row and column walks are both
+// bank-conflict free) when they fit, otherwise in a caller workspace that stays
+// L2-resident.  A round rotates n/2 disjoint (p,q) pairs (round-robin tournament):
+//   phase 1  one thread per pair computes (c, s) from G_pp, G_qq, G_pq
+//   phase 2  columns p,q of G and V are rotated (lanes walk the rows)
+//   phase 3  rows p,q of G are rotated (lanes walk the columns)
+// Rotations are skipped when |G_pq| <= eps * sqrt(G_pp G_qq) (the relative criterion
+// that gives Jacobi its high relative accuracy on graded Gram matrices); the sweep
+// loop ends when a whole sweep rotates nothing.
+//
+// Epilogue = round.py:118-158 of the reference, fused: clamp, sqrt, sort by
+// decreasing sigma (counting sort, one thread per eigenvalue), permute V's columns,
+// tail-energy scan (accumulated in double like torch.cumsum on CPU), rank selection.
+#include "ttr_common.h"
+
+namespace ttr {
+
+template <typename T>
+struct EighArgs {
+  int n;
+  const T* G;
+  int64_t ldg, strideG;
+  T* V;
+  int64_t ldv, strideV;
+  T* sigma;
+  int64_t stride_sigma;
+  int32_t* info;
+  int eig_mode;
+  int use_delta;
+  double delta2;
+  int64_t rmax;
+  T* ws;  // global-memory variant: per matrix 2 * n * (n + 1) elements
+  int max_sweeps;
+};
+
+constexpr int kMaxPairs = 512;  // n <= 1024 in the global-memory variant
+
+template <typename T, bool LDSRES>
+__global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int64_t bt = blockIdx.x;
+  const int n = p.n;
+  const int ld = n + 1;
+  const int ne = n + (n & 1);  // even number of players (phantom index n if n is odd)
+  const int np = ne / 2;
+
+  // carve the dynamic LDS
+  T* cs_c = reinterpret_cast<T*>(smem_raw);          // [np]
+  T* cs_s = cs_c + kMaxPairs;                        // [np]
+  int* pq_p = reinterpret_cast<int*>(cs_s + kMaxPairs);
+  int* pq_q = pq_p + kMaxPairs;
+  int* flags = pq_q + kMaxPairs;                     // [0]: rotated-this-sweep
+  T* sg = reinterpret_cast<T*>(flags + 16);          // sigma / ordering scratch [2 * n]
+  T* Gs;
+  T* Vs;
+  if (LDSRES) {
+    Gs = sg + 2 * ((n + 1) & ~1) + 2;
+    Vs = Gs + (size_t)n * ld;
+  } else {
+    Gs = p.ws + bt * (int64_t)2 * n * ld;
+    Vs = Gs + (size_t)n * ld;
+  }
+
+  const T* __restrict__ G = p.G + bt * p.strideG;
+  for (int idx = tid; idx < n * n; idx += kThreads) {
+    const int i = idx / n, j = idx % n;
+    Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
+    Vs[i * ld + j] = (i == j) ? T(1) : T(0);
+  }
+  if (tid == 0) flags[0] = 0;
+  __syncthreads();
+
+  const T eps = Num<T>::eps();
+  const T tiny = Num<T>::tiny();
+  const int m1 = ne - 1;
+
+  for (int sweep = 0; sweep < p.max_sweeps && n > 1; ++sweep) {
+    for (int r = 0; r < m1; ++r) {
+      // ---- phase 1: rotations of this round
+      for (int k = tid; k < np; k += kThreads) {
+        int pp, qq;
+        if (k == 0) { pp = ne - 1; qq = r % m1; }
+        else { pp = (r + k) % m1; qq = (r - k + m1) % m1; }
+        T c = T(1), s = T(0);
+        if (pp < n && qq < n) {
+          const T app = Gs[pp * ld + pp], aqq = Gs[qq * ld + qq], apq = Gs[pp * ld + qq];
+          const T aabs = fabs(apq);
+          if (aabs > eps * sqrt(fabs(app) * fabs(aqq)) && aabs > tiny) {
+            const T theta = (aqq - app) / (T(2) * apq);
+            T t;
+            if (fabs(theta) > Num<T>::big_theta()) t = T(0.5) / theta;
+            else t = copysign(T(1), theta) / (fabs(theta) + sqrt(T(1) + theta * theta));
+            c = T(1) / sqrt(T(1) + t * t);
+            s = t * c;
+            flags[0] = 1;
+          }
+        }
+        cs_c[k] = c; cs_s[k] = s; pq_p[k] = pp; pq_q[k] = qq;
+      }
+      __syncthreads();
+      // ---- phase 2: G <- G J, V <- V J  (columns p,q; lanes walk rows)
+      for (int item = tid; item < np * n; item += kThreads) {
+        const int k = item / n, i = item % n;
+        const T s = cs_s[k];
+        if (s != T(0)) {
+          const T c = cs_c[k];
+          const int pp = pq_p[k], qq = pq_q[k];
+          const T gp = Gs[i * ld + pp], gq = Gs[i * ld + qq];
+          Gs[i * ld + pp] = c * gp - s * gq;
+          Gs[i * ld + qq] = s * gp + c * gq;
+          const T vp = Vs[i * ld + pp], vq = Vs[i * ld + qq];
+          Vs[i * ld + pp] = c * vp - s * vq;
+          Vs[i * ld + qq] = s * vp + c * vq;
+        }
+      }
+      __syncthreads();
+      // ---- phase 3: G <- J^T G  (rows p,q; lanes walk columns)
+      for (int item = tid; item < np * n; item += kThreads) {
+        const int k = item / n, i = item % n;
+        const T s = cs_s[k];
+        if (s != T(0)) {
+          const T c = cs_c[k];
+          const int pp = pq_p[k], qq = pq_q[k];
+          const T gp = Gs[pp * ld + i], gq = Gs[qq * ld + i];
+          Gs[pp * ld + i] = c * gp - s * gq;
+          Gs[qq * ld + i] = s * gp + c * gq;
+        }
+      }
+      __syncthreads();
+    }
+    const int rotated = flags[0];
+    __syncthreads();
+    if (tid == 0) flags[0] = 0;
+    __syncthreads();
+    if (!rotated) break;
+  }
+
+  // ---- epilogue: clamp / sqrt / sort / permute / rank rule
+  T* sig = sg;            // [n] unsorted sigma
+  T* sig_sorted = sg + n; // [n]
+  for (int i = tid; i < n; i += kThreads) {
+    T w = Gs[i * ld + i];
+    if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
+    else { if (!(w > T(0))) w = T(0); }
+    sig[i] = sqrt(w);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kThreads) {
+    const T si = sig[i];
+    int pos = 0;
+    for (int j = 0; j < n; ++j) {
+      const T sj = sig[j];
+      pos += (sj > si) || (sj == si && j < i);
+    }
+    sig_sorted[pos] = si;
+    // permute the eigenvector: column i -> column pos
+    T* __restrict__ V = p.V + bt * p.strideV;
+    for (int row = 0; row < n; ++row) V[(int64_t)row * p.ldv + pos] = Vs[row * ld + i];
+  }
+  __syncthreads();
+  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
+  for (int i = tid; i < n; i += kThreads) sout[i] = sig_sorted[i];
+  if (tid == 0) {
+    int rank;
+    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
+    if (sig_sorted[0] < T(1e-13)) {
+      rank = 0;  // zero guard, round.py:137-145
+    } else if (!p.use_delta) {
+      rank = (int)(cap < 1 ? 1 : cap);
+    } else {
+      const T d2 = (T)p.delta2;
+      double acc = 0.0;
+      int tail = 0;
+      for (int k = n - 1; k >= 0; --k) {
+        const double s2 = (double)(sig_sorted[k] * sig_sorted[k]);
+        acc += s2;
+        if ((T)acc <= d2) tail = n - k; else break;
+      }
+      int64_t rk = n - tail;
+      if (rk > cap) rk = cap;
+      if (rk < 1) rk = 1;
+      rank = (int)rk;
+    }
+    p.info[bt] = rank;
+  }
+}
+
+static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
+  size_t bytes = 2 * kMaxPairs * elem + 2 * kMaxPairs * sizeof(int) + 16 * sizeof(int);
+  bytes += (2 * ((n + 1) & ~1) + 2) * elem;
+  if (ldsres) bytes += 2 * (size_t)n * (n + 1) * elem;
+  return (bytes + 15) & ~size_t(15);
+}
+
+int eigh_max_n_lds(int dtype) {
+  // 160 KiB LDS per CU; G and V are (n x (n+1)) each
+  const size_t elem = dtype == TTR_F64 ? 8 : 4;
+  int n = 8;
+  while (eigh_lds_bytes(elem, n + 1, true) <= 160 * 1024) ++n;
+  return n;
+}
+
+int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
+  if (n <= eigh_max_n_lds(dtype)) return 0;
+  return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
+}
+
+template <typename T>
+static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+                      int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
+                      int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  TTR_REQUIRE(n >= 1 && n <= 2 * kMaxPairs, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %d]", (long long)n,
+              2 * kMaxPairs);
+  EighArgs<T> p;
+  p.n = (int)n;
+  p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
+  p.V = (T*)V; p.ldv = ldv; p.strideV = strideV;
+  p.sigma = (T*)sigma; p.stride_sigma = stride_sigma;
+  p.info = info;
+  p.eig_mode = eig_mode; p.use_delta = use_delta; p.delta2 = delta2; p.rmax = rmax;
+  p.ws = (T*)ws;
+  p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
+  const bool ldsres = n <= eigh_max_n_lds(dtype);
+  if (!ldsres) {
+    const int64_t need = eigh_workspace_bytes(dtype, n, batch);
+    TTR_REQUIRE(ws && ws_bytes >= need, TTR_E_WORKSPACE, "ttr_eigh_trunc: workspace %lld < %lld bytes",
+                (long long)ws_bytes, (long long)need);
+  }
+  const size_t lds = eigh_lds_bytes(sizeof(T), n, ldsres);
+  ProfScope prof(TTR_PROF_EIGH, stream);
+  if (ldsres) {
+    auto kern = eigh_jacobi_kernel<T, true>;
+    if (lds > 64 * 1024)
+      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, stream, p);
+  } else {
+    auto kern = eigh_jacobi_kernel<T, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, stream, p);
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+                  int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
+                  int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (dtype == TTR_F32)
+    return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
+                             use_delta, delta2, rmax, ws, ws_bytes, stream);
+  return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
+                            use_delta, delta2, rmax, ws, ws_bytes, stream);
+}
+
+}  // namespace ttr

@@ -1,0 +1,240 @@
+// Batched small/tall-skinny GEMM on MFMA for the TT sweeps (gfx950).
+//
+//   C[b] = scale( op(A[b]) (M x K) * op(B[b]) (K x N) )
+//
+// Every GEMM of the rounding path has one small dimension (a TT rank, <= ~128) and
+// one long one (I * R), so the kernels are HBM/L2-bound: the design goal is coalesced
+// streaming of the long operand, not peak MFMA rate.  One workgroup (4 wave64) owns a
+// 64 x 64 tile of C; K is walked in steps of 16 through LDS; each wave owns a 32 x 32
+// sub-tile = 2 x 2 MFMA 16x16x4 accumulators (exact f32 / f64 arithmetic).
+//
+// Operands are addressed through (row stride, col stride) pairs so that both
+// transposes come for free; the LDS image of a tile is chosen per operand so that the
+// global read is coalesced along the unit-stride axis AND the MFMA fragment reads are
+// bank-conflict free:
+//   k-contiguous operand  -> LDS [mn][k], leading dim 17   (fragment read: 17*i + k)
+//   mn-contiguous operand -> LDS [k][mn], leading dim 80   (fragment read: 80*k + i)
+// Optional split-K (blockIdx.y) writes partial tiles to a workspace, reduced (and
+// scaled) by a second kernel -- used for the Gram matrices of very tall unfoldings.
+#include "ttr_common.h"
+
+namespace ttr {
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDS_TILE = 1280;  // max(64 * 17, 16 * 80)
+
+template <typename T>
+struct GemmArgs {
+  int64_t M, N, K;
+  const T* A;
+  int64_t a_rs, a_cs, strideA;  // op(A)(i,k) = A[i * a_rs + k * a_cs]
+  const T* B;
+  int64_t b_rs, b_cs, strideB;  // op(B)(k,j) = B[k * b_rs + j * b_cs]
+  T* C;
+  int64_t ldc, strideC;
+  const T* rs;
+  int64_t stride_rs;
+  int rs_mode;
+  const T* cs;
+  int64_t stride_cs;
+  int cs_mode;
+  int tilesN;
+  int nsplit;
+  int64_t k_chunk;  // K range per split (multiple of BK)
+  T* part;          // [nsplit][batch][M][N] when nsplit > 1
+  int64_t batch;
+};
+
+template <typename T>
+__device__ __forceinline__ T apply_scale(T v, const T* s, int64_t idx, int mode) {
+  if (mode == TTR_SCALE_NONE) return v;
+  T x = s[idx];
+  if (mode == TTR_SCALE_MUL) return v * x;
+  return (fabs((double)x) < (double)Num<T>::tiny()) ? T(0) : v / x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
+  __shared__ T As[LDS_TILE];
+  __shared__ T Bs[LDS_TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t b = blockIdx.z;
+  const int tm_idx = blockIdx.x / p.tilesN;
+  const int tn_idx = blockIdx.x % p.tilesN;
+  const int64_t m0 = (int64_t)tm_idx * BM;
+  const int64_t n0 = (int64_t)tn_idx * BN;
+  const int split = blockIdx.y;
+  const int64_t k_begin = (int64_t)split * p.k_chunk;
+  const int64_t k_end = (k_begin + p.k_chunk < p.K) ? (k_begin + p.k_chunk) : p.K;
+
+  const T* __restrict__ A = p.A + b * p.strideA;
+  const T* __restrict__ B = p.B + b * p.strideB;
+
+  const bool a_kc = (p.a_cs == 1);   // op(A) contiguous along k
+  const bool b_kc = (p.b_rs == 1);   // op(B) contiguous along k
+  const int sa_i = a_kc ? 17 : 1, sa_k = a_kc ? 1 : 80;
+  const int sb_j = b_kc ? 17 : 1, sb_k = b_kc ? 1 : 80;
+
+  // per-thread staging coordinates (4 elements of each operand per K step)
+  int ai[4], ak[4], bj[4], bk[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + kThreads * e;
+    if (a_kc) { ak[e] = idx & 15; ai[e] = idx >> 4; } else { ai[e] = idx & 63; ak[e] = idx >> 6; }
+    if (b_kc) { bk[e] = idx & 15; bj[e] = idx >> 4; } else { bj[e] = idx & 63; bk[e] = idx >> 6; }
+  }
+
+  typename Mfma<T>::Acc acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::zero();
+
+  T ra[4], rb[4];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t gi = m0 + ai[e], gk = k0 + ak[e];
+      ra[e] = (gi < p.M && gk < k_end) ? A[gi * p.a_rs + gk * p.a_cs] : T(0);
+      const int64_t gj = n0 + bj[e], gk2 = k0 + bk[e];
+      rb[e] = (gj < p.N && gk2 < k_end) ? B[gk2 * p.b_rs + gj * p.b_cs] : T(0);
+    }
+  };
+
+  if (k_begin < k_end) fetch(k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      As[ai[e] * sa_i + ak[e] * sa_k] = ra[e];
+      Bs[bj[e] * sb_j + bk[e] * sb_k] = rb[e];
+    }
+    __syncthreads();
+    if (k0 + BK < k_end) fetch(k0 + BK);  // overlaps the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kf = kk * 4 + (lane >> 4);
+      T a[2], bb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[(wm * 32 + t * 16 + (lane & 15)) * sa_i + kf * sa_k];
+        bb[t] = Bs[(wn * 32 + t * 16 + (lane & 15)) * sb_j + kf * sb_k];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::mma(a[i], bb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  const bool direct = (p.nsplit == 1);
+  T* __restrict__ C = direct ? (p.C + b * p.strideC) : (p.part + ((int64_t)split * p.batch + b) * p.M * p.N);
+  const int64_t ldc = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 32 + i * 16 + Mfma<T>::row(lane, r);
+        const int64_t col = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (row < p.M && col < p.N) {
+          T v = acc[i][j][r];
+          if (direct) {
+            v = apply_scale(v, p.rs ? p.rs + b * p.stride_rs : nullptr, row, p.rs ? p.rs_mode : TTR_SCALE_NONE);
+            v = apply_scale(v, p.cs ? p.cs + b * p.stride_cs : nullptr, col, p.cs ? p.cs_mode : TTR_SCALE_NONE);
+          }
+          C[row * ldc + col] = v;
+        }
+      }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(GemmArgs<T> p) {
+  const int64_t b = blockIdx.y;
+  const int64_t mn = p.M * p.N;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < mn; idx += (int64_t)gridDim.x * kThreads) {
+    T s = 0;
+    for (int sp = 0; sp < p.nsplit; ++sp) s += p.part[((int64_t)sp * p.batch + b) * mn + idx];
+    const int64_t row = idx / p.N, col = idx % p.N;
+    s = apply_scale(s, p.rs ? p.rs + b * p.stride_rs : nullptr, row, p.rs ? p.rs_mode : TTR_SCALE_NONE);
+    s = apply_scale(s, p.cs ? p.cs + b * p.stride_cs : nullptr, col, p.cs ? p.cs_mode : TTR_SCALE_NONE);
+    p.C[b * p.strideC + row * p.ldc + col] = s;
+  }
+}
+
+// Split only when the plain launch would leave most of the 256 CUs idle and K is long.
+static int pick_nsplit(int64_t tiles, int64_t batch, int64_t K) {
+  const int64_t wgs = tiles * batch;
+  if (wgs >= 512 || K < 2048) return 1;
+  int64_t want = ceil_div(1024, wgs);
+  int64_t maxs = K / 512;
+  if (maxs < 1) maxs = 1;
+  int64_t s = want < maxs ? want : maxs;
+  if (s > 256) s = 256;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <typename T>
+static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                     int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc,
+                     int64_t strideC, const void* rs, int64_t stride_rs, int rs_mode, const void* cs,
+                     int64_t stride_cs, int cs_mode, int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  GemmArgs<T> p;
+  p.M = M; p.N = N; p.K = K;
+  p.A = (const T*)A; p.strideA = strideA;
+  if (!transA) { p.a_rs = lda; p.a_cs = 1; } else { p.a_rs = 1; p.a_cs = lda; }
+  p.B = (const T*)B; p.strideB = strideB;
+  if (!transB) { p.b_rs = ldb; p.b_cs = 1; } else { p.b_rs = 1; p.b_cs = ldb; }
+  p.C = (T*)C; p.ldc = ldc; p.strideC = strideC;
+  p.rs = (const T*)rs; p.stride_rs = stride_rs; p.rs_mode = rs_mode;
+  p.cs = (const T*)cs; p.stride_cs = stride_cs; p.cs_mode = cs_mode;
+  p.batch = batch;
+  const int64_t tilesM = ceil_div(M, BM), tilesN = ceil_div(N, BN);
+  p.tilesN = (int)tilesN;
+  int nsplit = pick_nsplit(tilesM * tilesN, batch, K);
+  if (nsplit > 1) {
+    const int64_t need = (int64_t)nsplit * batch * M * N * (int64_t)sizeof(T);
+    if (!ws || ws_bytes < need) nsplit = 1;  // no workspace: plain launch
+  }
+  p.nsplit = nsplit;
+  p.k_chunk = nsplit == 1 ? align_up(K > 0 ? K : 1, BK) : align_up(ceil_div(K, nsplit), BK);
+  p.part = (T*)ws;
+  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_gemm: batch %lld > 65535", (long long)batch);
+  TTR_REQUIRE(tilesM * tilesN <= 2147483647LL, TTR_E_UNSUPPORTED, "ttr_gemm: too many tiles");
+  dim3 grid((unsigned)(tilesM * tilesN), (unsigned)nsplit, (unsigned)batch);
+  {
+    ProfScope prof(TTR_PROF_GEMM, stream);
+    hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(kThreads), 0, stream, p);
+    if (nsplit > 1) {
+      int64_t gx = ceil_div(M * N, kThreads);
+      if (gx > 1024) gx = 1024;
+      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, stream, p);
+    }
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch) {
+  const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  const int ns = pick_nsplit(tiles, batch, K);
+  if (ns == 1) return 0;
+  return (int64_t)ns * batch * M * N * (dtype == TTR_F64 ? 8 : 4);
+}
+
+int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                  int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
+                  const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
+                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (dtype == TTR_F32)
+    return gemm_impl<float>(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rs, stride_rs,
+                            rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream);
+  return gemm_impl<double>(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rs, stride_rs,
+                           rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream);
+}
+
+}  // namespace ttr

@@ -1,0 +1,72 @@
+"""Free-function entry points of the rounding path.
+
+Mirror of ``tntorch/round.py`` (same names, keyword arguments, defaults and error
+behaviour): ``round_tt`` / ``round`` clone and call the in-place methods
+(round.py:7-49), ``truncated_svd`` is round.py:52-187.
+"""
+
+import time
+from typing import Optional
+
+import torch
+
+from ._dispatch import ops_for
+
+__all__ = ["round_tt", "round_tucker", "round", "truncated_svd"]
+
+
+def round_tt(t, **kwargs):
+    """Copies and rounds a tensor (round.py:7-19)."""
+    t2 = t.clone()
+    t2.round_tt(**kwargs)
+    return t2
+
+
+def round_tucker(t, **kwargs):
+    """Copies and Tucker-rounds a tensor (round.py:22-34)."""
+    t2 = t.clone()
+    t2.round_tucker(**kwargs)
+    return t2
+
+
+def round(t, **kwargs):
+    """Copies and rounds a tensor (round.py:37-49)."""
+    t2 = t.clone()
+    t2.round(**kwargs)
+    return t2
+
+
+def truncated_svd(
+    M: torch.Tensor,
+    delta: Optional[float] = None,
+    eps: Optional[float] = None,
+    rmax: Optional[int] = None,
+    left_ortho: Optional[bool] = True,
+    algorithm: Optional[str] = "svd",
+    verbose: Optional[bool] = False,
+    batch: Optional[bool] = False,
+):
+    """Decompose ``M (m x n)`` into ``U (m x r)`` and ``V (r x n)`` with bounded error or given ``r``.
+
+    Same contract as round.py:52-187: ``delta`` (absolute) xor ``eps`` (relative) error bound,
+    ``rmax`` cap, ``left_ortho`` chooses the orthonormal side, ``algorithm`` is ``'svd'``
+    (backward-stable accuracy) or ``'eig'`` (Gram matrix; faster, less accurate), ``batch``
+    adds a leading batch dimension and ignores the error bound (round.py:149-150).
+    """
+    if delta is not None and eps is not None:
+        raise ValueError("Provide either `delta` or `eps`")
+    if rmax is None:
+        rmax = torch.iinfo(torch.int32).max
+    assert rmax >= 1
+    assert algorithm in ("svd", "eig")
+    ops = ops_for(M)
+    start = time.time()
+    M3 = M if batch else M[None]
+    left, M2 = ops.truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch)
+    if verbose:
+        if M.is_cuda:
+            torch.cuda.synchronize()
+        print("Time (truncated SVD, {}):".format(algorithm), time.time() - start)
+    if batch:
+        return left, M2
+    return left[0], M2[0]

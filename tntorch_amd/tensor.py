@@ -1,0 +1,347 @@
+"""``Tensor``: the tensor-train container behind which the MI355X sweeps sit.
+
+Drop-in for the TT subset of ``tntorch.Tensor`` (tntorch/tensor.py:107-2287): same
+constructor keywords, attributes (``cores``, ``Us``, ``batch``, ``idxs``) and methods on
+the orthogonalisation / rounding path -- ``left_orthogonalize`` / ``right_orthogonalize`` /
+``orthogonalize`` (tensor.py:1800-1909), ``round_tt`` (tensor.py:2008-2083), the dense
+``ranks_tt=`` constructor (tensor.py:401-408) -- plus the thin helpers the reference's
+tests use around them (``torch()``, ``clone()``, ``ranks_tt``, ``+``, scalar ``* /``).
+
+Cores are ``[R_k, I_k, R_{k+1}]`` row-major tensors (``batch=True`` prepends ``B``); the
+methods REBIND list entries and never write into the storage of the tensors they were
+given (tensor.py:1818-1832, 2066-2083).  CPU cores run the host mirror, device cores run
+the HIP kernels; CP cores, Tucker factors and the other tensor-network formats of the
+reference are outside this package's scope and raise ``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+import time
+from typing import Any, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from ._dispatch import ops_for
+
+__all__ = ["Tensor"]
+
+
+def _not_in_scope(what: str):
+    raise NotImplementedError(
+        f"tntorch_amd implements the TT orthogonalisation/rounding hot path only; {what} is out of scope "
+        "(see DESIGN.md, 'Out of scope')"
+    )
+
+
+class Tensor(object):
+    """Tensor train with the API of ``tntorch.Tensor`` on the rounding path."""
+
+    def __init__(
+        self,
+        data: Union[torch.Tensor, np.ndarray, Sequence[torch.Tensor]],
+        Us: Optional[Sequence[Any]] = None,
+        idxs: Optional[Any] = None,
+        device: Optional[Any] = None,
+        requires_grad: Optional[bool] = None,
+        ranks_cp: Optional[int] = None,
+        ranks_tucker: Optional[Sequence[int]] = None,
+        ranks_tt: Optional[Union[int, Sequence[int]]] = None,
+        eps: Optional[float] = None,
+        max_iter: Optional[int] = 25,
+        tol: Optional[float] = 1e-4,
+        verbose: Optional[bool] = False,
+        batch: Optional[bool] = False,
+        algorithm: Optional[str] = "svd",
+    ):
+        self.batch = bool(batch)
+        nb = 1 if self.batch else 0
+        if ranks_cp is not None:
+            _not_in_scope("CP-ALS (ranks_cp)")
+        if ranks_tucker is not None:
+            _not_in_scope("Tucker rounding (ranks_tucker)")
+
+        if isinstance(data, (list, tuple)):  # explicit cores (tensor.py:165-192)
+            cores = list(data)
+            if not all(isinstance(c, torch.Tensor) and nb + 2 <= c.dim() <= nb + 3 for c in cores):
+                raise ValueError("All tensor cores must have 2 (for CP) or 3 (for TT) dimensions")
+            if any(c.dim() == nb + 2 for c in cores):
+                _not_in_scope("CP cores (2-D factor matrices)")
+            for n in range(len(cores) - 1):
+                if cores[n].shape[-1] != cores[n + 1].shape[nb]:
+                    raise ValueError("Core ranks do not match")
+            if device is not None:
+                cores = [c.to(device) for c in cores]
+            self.cores = cores
+        else:
+            if isinstance(data, np.ndarray):  # tensor.py:195-203
+                data = torch.tensor(data, device=device)
+            elif isinstance(data, torch.Tensor):
+                data = data.to(device)
+            else:
+                raise ValueError(
+                    "A tntorch.Tensor may be built either from a list of cores, one NumPy ndarray, or one PyTorch tensor"
+                )
+            if data.dim() == 0:
+                data = data * torch.ones(1, device=data.device, dtype=data.dtype)
+            if eps is not None and ranks_tt is not None:
+                raise ValueError("Specify eps or ranks, but not both")
+            self.cores = self._from_dense(data, ranks_tt, eps, algorithm)
+
+        N = len(self.cores)
+        if Us is None:
+            Us = [None] * N
+        if any(U is not None for U in Us):
+            _not_in_scope("Tucker factors (Us)")
+        self.Us = list(Us)
+        if requires_grad:
+            for n in range(N):
+                self.cores[n].requires_grad_()
+        if idxs is None:
+            idxs = [torch.arange(sh, device=self.cores[0].device) for sh in self.shape]
+        self.idxs = idxs
+
+    # ------------------------------------------------------------------ dense -> TT
+    def _from_dense(self, data: torch.Tensor, ranks_tt, eps, algorithm) -> List[torch.Tensor]:
+        """tensor.py:401-408 / 436-439 for the TT format."""
+        from . import _hostops
+
+        X = data if self.batch else data[None]
+        N = X.dim() - 1
+        if ranks_tt is None and eps is None:  # exact, identity-padded TT (tensor.py:10-104)
+            return self._denorm(_hostops.full_rank_tt(X))
+        if N == 1:
+            return self._denorm([X.reshape(X.shape[0], 1, X.shape[1], 1)])
+        if eps is not None:
+            # tensor.py:436-439 goes through round(): TT rounding, then Tucker rounding with the
+            # remaining budget.  Only the TT part belongs to this path.
+            rmax = [None] * (N - 1)
+            e = eps
+        else:
+            rmax = list(ranks_tt) if hasattr(ranks_tt, "__len__") else [ranks_tt] * (N - 1)
+            assert len(rmax) == N - 1
+            e = 1e-14  # round_tt's default applies on the ctor path (tensor.py:408)
+        ops = ops_for(X)
+        return self._denorm(ops.dense_tt_svd(X, e, rmax, algorithm, self.batch))
+
+    # ------------------------------------------------------------------ layout helpers
+    def _norm4(self) -> List[torch.Tensor]:
+        """Cores as [B, r0, I, r1] views (B = 1 for non-batch tensors)."""
+        return list(self.cores) if self.batch else [c[None] for c in self.cores]
+
+    def _denorm(self, cores4: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        return list(cores4) if self.batch else [c[0] for c in cores4]
+
+    def _check_tt(self):
+        if any(U is not None for U in self.Us):
+            _not_in_scope("Tucker factors (Us)")
+
+    # ------------------------------------------------------------------ properties (tensor.py:836-919)
+    @property
+    def shape(self):
+        shape = []
+        if self.batch:
+            shape.append(len(self.cores[0]))
+        for c in self.cores:
+            shape.append(c.shape[-2])
+        return torch.Size(shape)
+
+    def size(self):
+        return self.shape
+
+    def b(self):
+        if not self.batch:
+            raise ValueError
+        return self.cores[0].shape[0]
+
+    def dim(self):
+        return len(self.cores)
+
+    @property
+    def ranks_tt(self):
+        """tensor.py:861-883: CPU int64 tensor ``[R_0, R_1, ..., R_N]``."""
+        first = self.cores[0].shape[1 if self.batch else 0]
+        return torch.tensor([first] + [c.shape[-1] for c in self.cores])
+
+    @ranks_tt.setter
+    def ranks_tt(self, value):
+        self.round_tt(rmax=value)
+
+    @property
+    def ranks_tucker(self):
+        return torch.tensor([c.shape[-2] for c in self.cores])
+
+    def numel(self):
+        return torch.round(torch.prod(torch.tensor(self.shape).double()))
+
+    def numcoef(self):
+        return sum(c.numel() for c in self.cores)
+
+    def __repr__(self):
+        fmt = "{}D TT tensor (batch)" if self.batch else "{}D TT tensor"
+        return fmt.format(self.dim()) + ": shape {}, TT ranks {}, device {}, dtype {}".format(
+            list(self.shape), self.ranks_tt.tolist(), self.cores[0].device, self.cores[0].dtype
+        )
+
+    # ------------------------------------------------------------------ copies / conversion
+    def clone(self):
+        """tensor.py:2213-2229."""
+        return Tensor([c.clone() for c in self.cores], idxs=self.idxs, batch=self.batch)
+
+    def to(self, device):
+        """tensor.py:1689-1700 (in place, returns self)."""
+        self.cores = [c.to(device) for c in self.cores]
+        return self
+
+    def torch(self):
+        """Decompress into a dense torch tensor (tensor.py:1639-1687, TT cores only)."""
+        c = self._norm4()
+        Bt = c[0].shape[0]
+        acc = c[0].reshape(Bt, -1, c[0].shape[-1])
+        for core in c[1:]:
+            acc = torch.bmm(acc, core.reshape(Bt, core.shape[1], -1)).reshape(Bt, -1, core.shape[-1])
+        # ranks_tt[0] and ranks_tt[-1] may exceed 1: the reference sums the boundary indices away
+        r0 = c[0].shape[1]
+        acc = acc.reshape(Bt, r0, -1, c[-1].shape[-1]).sum(dim=(1, 3))
+        out = acc.reshape([Bt] + [core.shape[2] for core in c])
+        return out if self.batch else out[0]
+
+    def numpy(self):
+        return self.torch().detach().cpu().numpy()
+
+    # ------------------------------------------------------------------ arithmetic used around the hot path
+    def _scalar_like(self, value):
+        c0 = self.cores[0]
+        lead = (c0.shape[0],) if self.batch else ()
+        cores = [torch.ones(lead + (1, c.shape[-2], 1), dtype=c0.dtype, device=c0.device) for c in self.cores]
+        cores[0] = cores[0] * value
+        return Tensor(cores, batch=self.batch)
+
+    def __add__(self, other):
+        """TT + TT: block-diagonal core concatenation, ranks add (tensor.py:445-668)."""
+        if not isinstance(other, Tensor):
+            other = self._scalar_like(other)
+        if self.batch != other.batch:
+            raise ValueError("Tensors with the same batch mode are supported")
+        if self.shape != other.shape:
+            raise ValueError("tntorch_amd: + requires equal shapes (broadcasting is out of scope)")
+        N = self.dim()
+        if N == 1:
+            return Tensor([self.cores[0] + other.cores[0]], batch=self.batch)
+        cores = []
+        for n in range(N):
+            a, b = self.cores[n], other.cores[n]
+            if n == 0:
+                cores.append(torch.cat([a, b], dim=-1))
+            elif n == N - 1:
+                cores.append(torch.cat([a, b], dim=-3))
+            else:
+                za = a.new_zeros(a.shape[:-1] + (b.shape[-1],))
+                zb = b.new_zeros(b.shape[:-1] + (a.shape[-1],))
+                cores.append(torch.cat([torch.cat([a, za], dim=-1), torch.cat([zb, b], dim=-1)], dim=-3))
+        return Tensor(cores, batch=self.batch)
+
+    def __radd__(self, other):
+        return self + other
+
+    def __neg__(self):
+        return self * (-1)
+
+    def __sub__(self, other):
+        return self + (other * (-1) if isinstance(other, Tensor) else -other)
+
+    def __rsub__(self, other):
+        return (self * (-1)) + other
+
+    def __mul__(self, other):
+        if isinstance(other, Tensor):
+            _not_in_scope("the Hadamard product of two tensor trains")
+        cores = [c.clone() for c in self.cores]
+        cores[0] = cores[0] * other
+        return Tensor(cores, batch=self.batch)
+
+    def __rmul__(self, other):
+        return self * other
+
+    def __truediv__(self, other):
+        if isinstance(other, Tensor):
+            _not_in_scope("the quotient of two tensor trains")
+        return self * (1.0 / other)
+
+    # ------------------------------------------------------------------ orthogonalisation (tensor.py:1771-1909)
+    def left_orthogonalize(self, mu: int):
+        """Make core ``mu`` left-orthogonal, push ``R`` into core ``mu+1`` (tensor.py:1800-1833)."""
+        assert 0 <= mu < self.dim() - 1
+        self._check_tt()
+        c = self._norm4()
+        R = ops_for(c[mu]).left_orthogonalize(c, mu)
+        self.cores = self._denorm(c)
+        return R if self.batch else R[0]
+
+    def right_orthogonalize(self, mu: int):
+        """Make core ``mu`` right-orthogonal, push ``L`` into core ``mu-1`` (tensor.py:1835-1879)."""
+        assert 1 <= mu < self.dim()
+        self._check_tt()
+        c = self._norm4()
+        L = ops_for(c[mu]).right_orthogonalize(c, mu)
+        self.cores = self._denorm(c)
+        return L if self.batch else L[0]
+
+    def orthogonalize(self, mu: int):
+        """Make the train ``mu``-orthogonal; returns the last ``R, L`` (tensor.py:1881-1909)."""
+        if mu < 0:
+            mu += self.dim()
+        dev = self.cores[0].device
+        one = (self.cores[0].shape[0], 1, 1) if self.batch else (1, 1)
+        L = torch.ones(one, device=dev, dtype=self.cores[0].dtype)
+        R = torch.ones(one, device=dev, dtype=self.cores[0].dtype)
+        for i in range(mu):
+            R = self.left_orthogonalize(i)
+        for i in range(self.dim() - 1, mu, -1):
+            L = self.right_orthogonalize(i)
+        return R, L
+
+    # ------------------------------------------------------------------ rounding (tensor.py:2008-2098)
+    def round_tt(
+        self,
+        eps: float = 1e-14,
+        rmax: Optional[Union[int, Sequence[int]]] = None,
+        algorithm: Optional[str] = "svd",
+        verbose: Optional[bool] = False,
+    ):
+        """Recompress in place by reducing the TT ranks (tensor.py:2008-2083).
+
+        ``eps``: relative error bound (ignored when ``batch=True``, tensor.py:2036-2037);
+        ``rmax``: rank cap (int or one per bond); ``algorithm``: ``'svd'`` or ``'eig'``.
+        """
+        N = self.dim()
+        if not hasattr(rmax, "__len__"):
+            rmax = [rmax] * (N - 1)
+        assert len(rmax) == N - 1
+        assert algorithm in ("svd", "eig")
+        for r in rmax:
+            assert r is None or r >= 1
+        self._check_tt()
+        if N == 1:
+            return
+        c = self._norm4()
+        ops = ops_for(c[0])
+        start = time.time()
+        out = ops.round_tt(c, eps, list(rmax), algorithm, self.batch)
+        if verbose:
+            if c[0].is_cuda:
+                torch.cuda.synchronize()
+            print("round_tt time (orthogonalization + truncation sweeps):", time.time() - start)
+        self.cores = self._denorm(out)
+
+    def round_tucker(self, *args, **kwargs):
+        _not_in_scope("round_tucker (SURVEY 8f-2)")
+
+    def round(self, eps: float = 1e-14, **kwargs):
+        """tensor.py:2085-2098 restricted to the TT format: ``round_tt(eps)``.
+
+        The reference spends any leftover error budget on a Tucker rounding of the modes;
+        that second stage is outside this package's scope, so the result here keeps
+        ``Us = None`` and satisfies the same error bound with TT ranks only.
+        """
+        self.round_tt(eps, **kwargs)
