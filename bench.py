@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the TT rounding hot path on MI355X.
+
+Workload (BASELINE.json `metric`, SURVEY 8d "M"): round_tt(rmax=32) of 64^8 tensors held in TT
+format with rank 64 (t = g+g, g = randn-core TT of rank 32, float32) -- a dense 64^8 tensor
+(1.1 PB) cannot exist, so "64^8 -> rank 32" is a TT-to-TT rounding.  One "step" rounds a batch
+of B independent tensors resident in HBM (B per GPU; weak scaling over ranks) and, for N > 1,
+gathers the rounded cores on rank 0 with a single RCCL gather.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definition of every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CORES, MODE, R_IN, R_OUT = 8, 64, 64, 32
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FLOP_PER_TENSOR = 8.72e8   # SURVEY 8d, algorithmic flops of one 64^8 r64->r32 rounding
+BYTES_PER_TENSOR = 2.69e7  # SURVEY 8d, algorithmic bytes (every core read once / written once per sweep)
+
+
+def make_input(B, device, seed):
+    """t = g + g with g = tn.randn([64]*8, ranks_tt=32) per batch item, built on the device."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    r = [1] + [R_OUT] * (N_CORES - 1) + [1]
+    cores = []
+    for k in range(N_CORES):
+        g = torch.randn((B, r[k], MODE, r[k + 1]), generator=gen, device=device, dtype=torch.float32)
+        if k == 0:
+            c = torch.cat([g, g], dim=-1)
+        elif k == N_CORES - 1:
+            c = torch.cat([g, g], dim=-3)
+        else:
+            z = torch.zeros_like(g)
+            c = torch.cat([torch.cat([g, z], dim=-1), torch.cat([z, g], dim=-1)], dim=-3)
+        cores.append(c.contiguous())
+    return cores
+
+
+def algorithmic_bytes_per_tensor():
+    """Per-stage split of SURVEY 8d's byte model for the M workload (float32).
+
+    L2R: every core is read once by the QR (-> `qr_factor`) and written once as Q (-> `qr_apply`);
+    R2L: per bond, M (m x n) read once, V^T (r x n) written, previous core read (R I m) and written (R I r)
+    (-> `gemm` + `eigh`, the Gram/projection/push GEMMs).  Sum = 2.69e7 B.
+    """
+    s = 4
+    numel = [1 * MODE * R_IN] + [R_IN * MODE * R_IN] * (N_CORES - 2) + [R_IN * MODE * 1]
+    l2r_read = s * sum(numel[:-1])   # cores 0..N-2 enter a QR
+    l2r_write = s * sum(numel[:-1])
+    r2l = 0
+    rn = 1
+    for k in range(N_CORES - 1, 0, -1):
+        m, n = R_IN, MODE * rn
+        rk = min(R_OUT, m, n)
+        Rprev = 1 if k - 1 == 0 else R_IN
+        r2l += s * (m * n + rk * n + Rprev * MODE * (m + rk))
+        rn = rk
+    last = s * numel[-1] * 2  # last core: written by the last push, read by the first truncation
+    return {"qr_factor": l2r_read, "qr_apply": l2r_write, "gemm+eigh": r2l + last,
+            "total": l2r_read + l2r_write + r2l + last}
+
+
+def cpu_baseline(sample_eig=8, sample_svd=2):
+    """Time the CPU oracle (restatement of the reference, same LAPACK calls) on a bounded sample."""
+    import oracle
+
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    g = oracle.tt_randn([MODE] * N_CORES, R_OUT, dtype=torch.float32)
+    inp = oracle.tt_add(g, g)
+    out = {}
+    for alg, reps in (("eig", sample_eig), ("svd", sample_svd)):
+        oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)  # warm-up (MKL init)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[alg] = ts[len(ts) // 2]
+    return {
+        "value": N_CORES / out["eig"],
+        "unit": "cores/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle.round_tt(rmax=32) of ONE 64^8 rank-64 float32 TT, median of {sample_eig} runs, "
+                  f"algorithm='eig' (the faster reference algorithm); the reference default 'svd' "
+                  f"(median of {sample_svd}) is reported next to it",
+        "sec_per_tensor_eig": out["eig"],
+        "sec_per_tensor_svd": out["svd"],
+        "value_svd": N_CORES / out["svd"],
+        "gflops_eig": FLOP_PER_TENSOR / out["eig"] / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="tensors per GPU per step")
+    ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import tntorch_amd as tn
+    from tntorch_amd import _hip
+    from tntorch_amd.dist_batch import gather_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with WORLD_SIZE={args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _hip.lib()  # fail loudly if the kernels are not built
+
+    B = args.batch
+    inp = make_input(B, dev, seed=1234 + rank)
+
+    def step():
+        t = tn.Tensor(inp, batch=True)
+        t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+        if world > 1:
+            return gather_batch(t, dst=0)
+        return t
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel device time over an identical pass (HIP events on the launch stream)
+    _hip.prof_enable(True)
+    for _ in range(args.steps):
+        t = tn.Tensor(inp, batch=True)
+        t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+    torch.cuda.synchronize()
+    prof = _hip.prof_collect()
+    _hip.prof_enable(False)
+
+    if rank == 0:
+        if out is not None:
+            assert list(out.ranks_tt) == [1] + [R_OUT] * (N_CORES - 1) + [1], out.ranks_tt
+        tensors = B * world * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        cores_per_s = tensors * N_CORES / elapsed
+        abytes = algorithmic_bytes_per_tensor()
+        kinds = {k: v for k, v in prof.items() if v["launches"] > 0}
+        dom = max(kinds, key=lambda k: kinds[k]["ms"])
+        stage_key = dom if dom in abytes else "gemm+eigh"
+        stage_ms = kinds[dom]["ms"] if dom in abytes else kinds.get("gemm", {"ms": 0})["ms"] + kinds.get("eigh", {"ms": 0})["ms"]
+        launches = kinds[dom]["launches"]
+        avg_launch_ms = kinds[dom]["ms"] / launches
+        bytes_per_launch = abytes[stage_key] * B * args.steps / launches
+        achieved = abytes[stage_key] * B * args.steps / (stage_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "TT rounding 64^8 rank-64 -> rank-32 (round_tt rmax=32), cores/s",
+            "value": cores_per_s,
+            "unit": "cores/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "round_tt(rmax=32) of 64^8 TT tensors, rank 64 (g+g, g randn rank 32), fp32, batch-resident in HBM",
+                "tensors_per_gpu_per_step": B,
+                "algorithm": args.algorithm,
+                "parallelism": f"batch-sharded x{world}, one gather of packed cores" if world > 1 else "single GPU",
+            },
+            "tensors_per_s": tensors / elapsed,
+            "gflops": FLOP_PER_TENSOR * tensors / elapsed / 1e9,
+            "whole_sweep_hbm_frac": BYTES_PER_TENSOR * tensors / elapsed / 1e9 / HBM_PEAK_GBS,
+            "roofline": {
+                "kernel": dom,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_launch_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "launches": launches,
+            },
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in kinds.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline()
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu_eig"] = cores_per_s / cb["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,10 @@ int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch,
  * Replaces: torch.linalg.eigh round.py:115, the clamp/sqrt/argsort of round.py:118-135 and the rank
  * selection round.py:147-158 (and, in the two-pass 'svd' algorithm, torch.linalg.svd round.py:96).
  * Parallel cyclic two-sided Jacobi; out of LDS for n <= ttr_eigh_max_n_lds(dtype), else out of `workspace`.
+ * Rotations are skipped when |G_pq| <= sqrt(n)*eps*sqrt(G_pp*G_qq) (relative criterion: high relative
+ * accuracy on graded, accurately formed Gram matrices -- pass 2 of the 'svd' algorithm).  abs_floor = 1
+ * additionally skips |G_pq| <= sqrt(n)*eps*max|G_ii| (for a plain Gram matrix, whose entries are only
+ * accurate to eps*||G||).  `sweeps` (optional, [batch]) receives the number of sweeps used.
  */
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
@@ -109,6 +113,7 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
                    void* sigma, int64_t stride_sigma,
                    int32_t* info,
                    int eig_mode, int use_delta, double delta2, int64_t rmax,
+                   int abs_floor, int32_t* sweeps,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /*

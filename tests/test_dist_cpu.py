@@ -1,0 +1,74 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes shard a batch, round their shard with no
+communication and gather the packed cores once; the result equals the single-process rounding."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tntorch_amd as tn
+    from tntorch_amd.dist_batch import round_tt_sharded, shard_range
+
+    torch.manual_seed(0)  # every rank builds the same full batch, then keeps its block
+    full = tn.randn([total, 6, 6, 6, 6], ranks_tt=5, batch=True, dtype=torch.float64)
+    lo, hi = shard_range(total, world, rank)
+    out = round_tt_sharded([c[lo:hi] for c in full.cores], rmax=3, algorithm="svd")
+    if rank == 0:
+        q.put([c.numpy() for c in out.cores])
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5])  # even and ragged split
+def test_gloo_world2_matches_single_process(total):
+    import tntorch_amd as tn
+    from tntorch_amd.dist_batch import shard_range
+
+    assert shard_range(5, 2, 0) == (0, 3) and shard_range(5, 2, 1) == (3, 5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    full = tn.randn([total, 6, 6, 6, 6], ranks_tt=5, batch=True, dtype=torch.float64)
+    full.round_tt(rmax=3)
+    for a, b in zip(got, full.cores):
+        assert a.shape == tuple(b.shape)
+        assert abs(torch.from_numpy(a) - b).max() < 1e-12
+
+
+def test_pack_unpack_roundtrip():
+    from tntorch_amd.dist_batch import pack_cores, unpack_cores
+
+    cores = [torch.rand(3, 1, 4, 2), torch.rand(3, 2, 4, 5), torch.rand(3, 5, 4, 1)]
+    flat = pack_cores(cores)
+    back = unpack_cores(flat, [c.shape for c in cores])
+    assert all(torch.equal(a, b) for a, b in zip(cores, back))

@@ -1,0 +1,183 @@
+"""Kernel-level numerics of the C-ABI entry points on a real MI355X, each against a plain
+float64 torch reference of the same operation (asymmetric operands, ragged sizes)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.float64]
+
+
+def tol(dt, f32, f64):
+    return f32 if dt == torch.float32 else f64
+
+
+def _hip():
+    from tntorch_amd import _hip
+
+    _hip.lib()
+    return _hip
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize(
+    "M,N,K,tA,tB,B",
+    [
+        (64, 64, 64, False, False, 1),
+        (64, 4096, 64, False, False, 3),
+        (4096, 32, 64, False, False, 2),
+        (64, 64, 2048, False, True, 4),   # Gram, left side
+        (33, 33, 1000, True, False, 2),   # Gram, right side
+        (17, 129, 5, False, False, 2),
+        (1, 1, 1, False, False, 1),
+        (70, 45, 19, True, True, 3),
+        (32, 2048, 64, True, False, 2),   # projection V^T M
+        (48, 48, 70000, True, False, 1),  # split-K path
+    ],
+)
+def test_gemm(dt, M, N, K, tA, tB, B):
+    h = _hip()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((B, K, M) if tA else (B, M, K), generator=g, dtype=torch.float64)
+    Bm = torch.randn((B, N, K) if tB else (B, K, N), generator=g, dtype=torch.float64)
+    ref = (A.transpose(1, 2) if tA else A) @ (Bm.transpose(1, 2) if tB else Bm)
+    out = h.gemm(A.to(dt).cuda(), Bm.to(dt).cuda(), transA=tA, transB=tB).cpu().double()
+    err = (out - ref).abs().max() / ref.abs().max()
+    assert err < tol(dt, 3e-5 if K > 10000 else 5e-6, 1e-12), err
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_scales_and_views(dt):
+    h = _hip()
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(2, 40, 64, generator=g, dtype=torch.float64)   # used as A[:, :, :24]^T: 24 x 40
+    Bm = torch.randn(2, 40, 300, generator=g, dtype=torch.float64)
+    rs = torch.rand(2, 64, generator=g, dtype=torch.float64) + 0.5
+    cs = torch.rand(2, 300, generator=g, dtype=torch.float64) + 0.5
+    ref = (A[:, :, :24].transpose(1, 2) @ Bm) / rs[:, :24, None] * cs[:, None, :]
+    Ad, Bd = A.to(dt).cuda(), Bm.to(dt).cuda()
+    out = h.gemm(Ad[:, :, :24], Bd, transA=True, rowscale=rs.to(dt).cuda(), rowscale_mode=h.SCALE_DIV,
+                 colscale=cs.to(dt).cuda(), colscale_mode=h.SCALE_MUL).cpu().double()
+    assert (out - ref).abs().max() / ref.abs().max() < tol(dt, 5e-6, 1e-12)
+    # division by an exactly zero scale yields 0 (guarded), not inf/nan
+    rs0 = rs.clone(); rs0[:, 3] = 0
+    out = h.gemm(Ad[:, :, :24], Bd, transA=True, rowscale=rs0.to(dt).cuda(), rowscale_mode=h.SCALE_DIV).cpu()
+    assert torch.isfinite(out).all() and (out[:, 3] == 0).all()
+
+
+QR_SHAPES = [(64, 64), (4096, 64), (300, 17), (16, 16), (10, 40), (256, 16), (257, 16), (1000, 33), (5000, 64),
+             (1, 1), (1, 7), (7, 1), (513, 32), (70000, 8)]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("m,n", QR_SHAPES)
+def test_qr(dt, m, n):
+    h = _hip()
+    g = torch.Generator().manual_seed(m * 31 + n)
+    B = 2 if m * n < 400000 else 1
+    A = torch.randn(B, m, n, generator=g, dtype=torch.float64).to(dt)
+    Q, R = h.qr(A.cuda())
+    Q, R = Q.cpu().double(), R.cpu().double()
+    k = min(m, n)
+    assert Q.shape == (B, m, k) and R.shape == (B, k, n)
+    eye = torch.eye(k, dtype=torch.float64)
+    assert (Q.transpose(1, 2) @ Q - eye).abs().max() < tol(dt, 2e-5, 5e-13)
+    assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 1e-5, 1e-13)
+    assert R.tril(-1).abs().max() == 0
+    # same factorisation as LAPACK up to the per-row sign of R
+    Rref = torch.linalg.qr(A.double())[1]
+    assert (R.abs() - Rref.abs()).abs().max() / Rref.abs().max() < tol(dt, 2e-4, 1e-11)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_qr_rank_deficient(dt):
+    """Left unfolding of g+g: exactly rank-deficient; Q must still be orthonormal."""
+    h = _hip()
+    g = torch.Generator().manual_seed(3)
+    G = torch.randn(1, 2048, 16, generator=g, dtype=torch.float64)
+    A = torch.cat([G, G, torch.zeros(1, 2048, 4, dtype=torch.float64), 2 * G[:, :, :8]], dim=2).to(dt)  # 2048 x 44, rank 16
+    Q, R = h.qr(A.cuda())
+    Q, R = Q.cpu().double(), R.cpu().double()
+    assert (Q.transpose(1, 2) @ Q - torch.eye(44, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 5e-13)
+    assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 1e-5, 1e-13)
+    A0 = torch.zeros(1, 500, 20, dtype=dt)
+    Q, R = h.qr(A0.cuda())
+    assert (R == 0).all() and (Q.cpu().double().transpose(1, 2) @ Q.cpu().double() - torch.eye(20, dtype=torch.float64)).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [1, 2, 5, 16, 63, 64, 100, 200])
+def test_eigh(dt, n):
+    h = _hip()
+    if dt == torch.float64 and n == 200:
+        pass  # global-memory variant in f64 as well
+    g = torch.Generator().manual_seed(n)
+    B = 3
+    Mx = torch.randn(B, n, 3 * n + 1, generator=g, dtype=torch.float64)
+    Mx = Mx * (0.7 ** torch.arange(n, dtype=torch.float64))[None, :, None]  # graded rows
+    G = (Mx @ Mx.transpose(1, 2)).to(dt)
+    V, sig, info = h.eigh_trunc(G.cuda(), h.EIG_RAW, False, 0.0, n)
+    V, sig, info = V.cpu().double(), sig.cpu().double(), info.cpu()
+    wref = torch.linalg.eigvalsh(G.double()).flip(-1).clamp_min(0)
+    assert (info == n).all()
+    assert (sig[:, :-1] >= sig[:, 1:]).all()
+    assert ((sig**2 - wref).abs().max(dim=1).values / wref[:, 0]).max() < tol(dt, 2e-6, 1e-13)
+    eye = torch.eye(n, dtype=torch.float64)
+    assert (V.transpose(1, 2) @ V - eye).abs().max() < tol(dt, 3e-5, 1e-12)
+    resid = (G.double() @ V - V * (sig**2)[:, None, :]).abs().max() / wref.max()
+    assert resid < tol(dt, 2e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_eigh_rank_rule(dt):
+    """Rank rule of round.py:147-158 on a diagonal matrix with known sigma."""
+    h = _hip()
+    sig = torch.tensor([8.0, 4.0, 2.0, 1.0, 0.5, 0.25], dtype=torch.float64)
+    perm = torch.tensor([3, 0, 5, 1, 4, 2])
+    G = torch.diag(sig[perm] ** 2).to(dt)[None]
+    cases = [
+        (0.0, 100, 6), (0.25, 100, 5), (0.2499, 100, 6), (0.56, 100, 4),
+        (100.0, 100, 1), (0.0, 3, 3), (0.6, 2, 2),
+    ]
+    for delta, rmax, expect in cases:
+        V, s, info = h.eigh_trunc(G.cuda(), h.EIG_RAW, True, float(delta) ** 2, rmax)
+        assert int(info[0]) == expect, (delta, rmax, int(info[0]), expect)
+        assert torch.allclose(s.cpu().double()[0], sig, rtol=1e-6)
+        # column j of V is the (signed) unit vector of the j-th largest eigenvalue
+        expect_V = torch.zeros(6, 6, dtype=torch.float64)
+        expect_V[torch.arange(6), perm] = 1.0
+        assert torch.allclose(V.cpu().double()[0].abs(), expect_V, atol=1e-6)
+    # batch mode: delta ignored
+    V, s, info = h.eigh_trunc(G.cuda(), h.EIG_RAW, False, 1e9, 4)
+    assert int(info[0]) == 4
+    # zero guard
+    V, s, info = h.eigh_trunc(torch.zeros(1, 5, 5, dtype=dt).cuda(), h.EIG_RAW, True, 0.0, 9)
+    assert int(info[0]) == 0
+    # reference clamp: a negative eigenvalue becomes sigma = 1e-4 (round.py:118-119)
+    Gn = torch.diag(torch.tensor([4.0, -1e-9, 1.0], dtype=torch.float64)).to(dt)[None]
+    V, s, info = h.eigh_trunc(Gn.cuda(), h.EIG_REF, True, 0.0, 9)
+    assert torch.allclose(s.cpu().double()[0], torch.tensor([2.0, 1.0, 1e-4], dtype=torch.float64), rtol=1e-5)
+    V, s, info = h.eigh_trunc(Gn.cuda(), h.EIG_RAW, True, 0.0, 9)
+    assert s.cpu()[0, 2] == 0
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_norm_and_scale(dt):
+    h = _hip()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 3, 777, generator=g, dtype=torch.float64)
+    out = h.norm(x.to(dt).cuda()).cpu().double()
+    assert torch.allclose(out, x.reshape(5, -1).norm(dim=1), rtol=tol(dt, 1e-6, 1e-14))
+    s = torch.rand(5, 777, generator=g, dtype=torch.float64) + 0.1
+    o = h.scale_cols(x.to(dt).cuda(), s.to(dt).cuda(), h.SCALE_MUL).cpu().double()
+    assert torch.allclose(o, x * s[:, None, :], rtol=tol(dt, 1e-6, 1e-14))
+    o = h.scale_cols(x.to(dt).cuda(), s.to(dt).cuda(), h.SCALE_DIV).cpu().double()
+    assert torch.allclose(o, x / s[:, None, :], rtol=tol(dt, 1e-6, 1e-14))
+
+
+def test_unsupported_shapes_raise():
+    h = _hip()
+    with pytest.raises(NotImplementedError):
+        h.qr(torch.randn(1, 300, h.max_qr_cols(torch.float32) + 1).cuda())
+    with pytest.raises(TypeError):
+        h.qr(torch.randn(1, 8, 4).cuda().half())

@@ -1,0 +1,279 @@
+"""Parity of the HIP path (through the drop-in API -> C ABI) against the CPU oracle and the
+golden vectors recorded from the reference, on a real MI355X.
+
+Tolerances (stated per SURVEY 8c, measured margins in DESIGN.md):
+  float64: ranks identical; bond singular values <= 1e-11 rel. to sigma_max; dense
+           reconstruction <= 1e-10; sign-gauged cores <= 1e-8 (separated spectra).
+  float32: ranks identical in rmax mode; approximation error agrees to <= 1e-5 absolute;
+           bond singular values <= 2e-5 rel. to sigma_max; reconstruction <= 2e-5 when the
+           spectrum is separated (flat `randn` spectra make the truncated subspace itself
+           ill-conditioned: the reference's own f32-vs-f64 results differ by up to 7e-4 there).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import tntorch_amd as tn
+from parity import assert_tt_close, dense, load_case, load_meta, ranks, rel_diff, to_list
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_tensor(cores, batch=False):
+    return tn.Tensor([c.cuda() for c in cores], batch=batch)
+
+
+def tt_rel_err(a, b):
+    """||a-b||/||b|| of two CPU trains through float64 inner products (valid down to ~1e-8)."""
+    a = [c.double() for c in a]
+    b = [c.double() for c in b]
+    aa, bb, ab = oracle.tt_dot(a, a), oracle.tt_dot(b, b), oracle.tt_dot(a, b)
+    return math.sqrt(max((aa + bb - 2 * ab).item(), 0.0) / bb.item())
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_round_eps_f64(alg):
+    g = load_case("round_eps_f64")
+    t = gpu_tensor(g["inp"])
+    t.round_tt(eps=1e-8, algorithm=alg)
+    assert_tt_close(to_list(t.cores), g[alg], tol_dense=1e-10, tol_sv=1e-11, tol_cores=1e-8, what=f"round_eps_f64/{alg}")
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_round_rmax_f32(alg):
+    g = load_case("round_rmax_f32")
+    t = gpu_tensor(g["inp"])
+    t.round_tt(rmax=3, algorithm=alg)
+    ours, ref = to_list(t.cores), g[alg]
+    assert ranks(ours) == ranks(ref) == [1, 3, 3, 3, 3, 1]
+    X = dense(g["inp"])
+    e_ours, e_ref = rel_diff(dense(ours), X), rel_diff(dense(ref), X)
+    assert abs(e_ours - e_ref) <= 1e-5, (e_ours, e_ref)
+    for a, b in zip(oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)):
+        assert ((a - b).abs().max() / b.max()).item() <= 2e-5
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_round_batch_f64(alg):
+    g = load_case("round_batch_f64")
+    t = gpu_tensor(g["inp"], batch=True)
+    t.round_tt(rmax=2, algorithm=alg)
+    assert t.batch and list(t.ranks_tt) == [1, 2, 2, 2, 1]
+    for i in range(3):
+        assert_tt_close(to_list(t.cores, i), [c[i] for c in g[alg]], tol_dense=1e-10, tol_sv=1e-11, what=f"batch item {i}")
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_dense_f64(alg):
+    g = load_case("dense_f64")
+    t = tn.Tensor(g["X"].cuda(), ranks_tt=4, algorithm=alg)
+    assert_tt_close(to_list(t.cores), g[alg], tol_dense=1e-10, tol_sv=1e-11, tol_cores=1e-8, what=f"dense_f64/{alg}")
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_dense_batch_f32(alg):
+    g = load_case("dense_batch_f32")
+    X = g["X"]
+    t = tn.Tensor(X.cuda(), ranks_tt=3, batch=True, algorithm=alg)
+    assert list(t.ranks_tt) == [1, 3, 3, 3, 1]
+    ours = t.torch().cpu().double()
+    ref = oracle.tt_to_dense([c.double() for c in g[alg]], batch=True)
+    for i in range(3):
+        e_o = rel_diff(ours[i], X[i]); e_r = rel_diff(ref[i], X[i])
+        assert abs(e_o - e_r) <= 1e-5, (i, e_o, e_r)
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_c0_on_device(alg):
+    """BASELINE config C0's tensor through the device dense entry (tn.Tensor(X, ranks_tt=4))."""
+    g = load_case("c0_16x4_rmax4_f32")
+    torch.manual_seed(0)
+    X = torch.randn(16, 16, 16, 16)
+    t = tn.Tensor(X.cuda(), ranks_tt=4, algorithm=alg)
+    ours = to_list(t.cores)
+    assert ranks(ours) == [1, 4, 4, 4, 1]
+    e_o, e_r = rel_diff(dense(ours), X), rel_diff(dense(g[alg]), X)
+    assert abs(e_o - e_r) <= 1e-5, (e_o, e_r)
+
+
+def test_golden_truncated_svd():
+    g = load_case("truncated_svd_f64")
+    for c in load_meta()["cases"]["truncated_svd_f64"]["calls"]:
+        kw = {k: c[k] for k in ("eps", "rmax", "delta") if k in c}
+        M = g["M_" + c["M"]]
+        u, v = tn.truncated_svd(M.cuda(), left_ortho=c["left_ortho"], algorithm=c["algorithm"], **kw)
+        u, v = u.cpu(), v.cpu()
+        ur, vr = g[f"call{c['i']}_left"], g[f"call{c['i']}_right"]
+        assert u.shape == ur.shape and v.shape == vr.shape, c
+        assert (u @ v - ur @ vr).abs().max() <= 1e-11, c
+        r = u.shape[1]
+        if c["left_ortho"]:
+            assert (u.t() @ u - torch.eye(r, dtype=u.dtype)).abs().max() <= 1e-9, c
+        else:
+            assert (v @ v.t() - torch.eye(r, dtype=u.dtype)).abs().max() <= 1e-9, c
+    for alg in ("svd", "eig"):
+        u, v = tn.truncated_svd(g["Mb"].cuda(), batch=True, algorithm=alg)
+        assert u.shape == (2, 32, 32) and v.shape == (2, 32, 32)
+        assert (u.cpu() @ v.cpu() - g["Mb"]).abs().max() <= 1e-10
+        for i in range(2):  # batch == loop over items (tests/test_round.py:21-38)
+            u1, v1 = tn.truncated_svd(g["Mb"][i].cuda(), batch=False, algorithm=alg)
+            assert (u1.cpu() @ v1.cpu() - u[i].cpu() @ v[i].cpu()).abs().max() <= 1e-10
+
+
+def test_truncated_svd_errors():
+    M = torch.rand(4, 5).cuda()
+    with pytest.raises(ValueError):
+        tn.truncated_svd(M, delta=0.1, eps=0.1)
+    with pytest.raises(AssertionError):
+        tn.truncated_svd(M, algorithm="qr")
+    with pytest.raises(AssertionError):
+        tn.truncated_svd(M, rmax=0)
+
+
+def test_golden_orthogonalize():
+    g = load_case("orthogonalize_f64")
+    X = dense(g["inp"])
+    for name, fn in [("left0", lambda t: t.left_orthogonalize(0)), ("right4", lambda t: t.right_orthogonalize(4)),
+                     ("orth2", lambda t: t.orthogonalize(2)), ("orth4", lambda t: t.orthogonalize(4))]:
+        t = gpu_tensor(g["inp"])
+        fn(t)
+        ours = to_list(t.cores)
+        assert ranks(ours) == ranks(g[name]), name
+        assert rel_diff(dense(ours), X) <= 1e-12, name
+        # |core| agrees with the reference wherever the reference core is orthogonal (sign gauge only)
+    t = gpu_tensor(g["inp"]); t.orthogonalize(2)
+    c = to_list(t.cores)
+    for k in (0, 1):
+        L = c[k].reshape(-1, c[k].shape[-1])
+        assert (L.t() @ L - torch.eye(L.shape[1], dtype=L.dtype)).abs().max() <= 1e-12
+    for k in (3, 4):
+        Rm = c[k].reshape(c[k].shape[0], -1)
+        assert (Rm @ Rm.t() - torch.eye(Rm.shape[0], dtype=Rm.dtype)).abs().max() <= 1e-12
+
+
+# ------------------------------------------------------------------ the reference's own property tests, on device
+def test_ref_orthogonalization_property():
+    """tests/test_round.py:7-18 (fewer trials, float64, device cores)."""
+    rng = np.random.RandomState(0)
+    torch.manual_seed(0)
+    for _ in range(12):
+        shape = rng.randint(1, 8, rng.randint(2, 6))
+        gt = tn.rand(shape, ranks_tt=int(rng.randint(1, 6)), dtype=torch.float64, device="cuda")
+        X = gt.torch()
+        t = gt.clone()
+        t.left_orthogonalize(0)
+        assert tn.relative_error(X, t) <= 1e-7
+        t.right_orthogonalize(t.dim() - 1)
+        assert tn.relative_error(X, t) <= 1e-7
+        t.orthogonalize(int(rng.randint(t.dim())))
+        assert tn.relative_error(X, t) <= 1e-7
+
+
+@pytest.mark.parametrize("alg,tol", [("svd", 1e-4), ("eig", 1e-7)])
+def test_ref_round_tt_rank_recovery(alg, tol):
+    """tests/test_round.py:41-59: gt+gt rounds back to gt's ranks ('svd' asserts the ranks)."""
+    rng = np.random.RandomState(1)
+    torch.manual_seed(1)
+    for _ in range(8):
+        shape = rng.randint(1, 8, rng.randint(8, 10))
+        gt = tn.rand(shape, ranks_tt=int(rng.randint(1, 10)), dtype=torch.float64, device="cuda")
+        gt.round_tt(1e-8, algorithm=alg)
+        t = gt + gt
+        t.round_tt(1e-8, algorithm=alg)
+        assert tn.relative_error(gt, t / 2) <= tol
+        if alg == "svd":
+            assert max(gt.ranks_tt) == max(t.ranks_tt)
+
+
+def test_ref_gpu_tt():
+    """tests/test_gpu.py:9-13."""
+    torch.manual_seed(0)
+    X = torch.randn(16, 16, 16, dtype=torch.float64)
+    y1 = oracle.tt_to_dense(oracle.dense_to_tt(X, 3))
+    y2 = tn.Tensor(X, ranks_tt=3, device="cuda").torch().cpu()
+    assert torch.abs(y1 - y2).max() < 1e-5
+
+
+def test_quirks():
+    # default eps=1e-14 drops exactly-zero tails even with rmax (SURVEY A-1)
+    t = tn.Tensor(torch.ones(4, 4, 4, dtype=torch.float64).cuda(), ranks_tt=3)
+    assert list(t.ranks_tt) == [1, 1, 1, 1]
+    assert torch.allclose(t.torch().cpu(), torch.ones(4, 4, 4, dtype=torch.float64))
+    # all-zero train rounds to rank 1 zeros (SURVEY A-5)
+    z = tn.Tensor([torch.zeros(1, 5, 3).cuda(), torch.zeros(3, 5, 3).cuda(), torch.zeros(3, 5, 1).cuda()])
+    z.round_tt()
+    assert list(z.ranks_tt) == [1, 1, 1, 1] and z.torch().abs().max() == 0
+    # rounding rebinds list entries: tensors held by the caller are not modified
+    g = oracle.tt_randn([6] * 4, 3, dtype=torch.float32)
+    held = [c.cuda() for c in g]
+    copies = [c.clone() for c in held]
+    t = tn.Tensor(held); t.round_tt(rmax=2)
+    for a, b in zip(held, copies):
+        assert torch.equal(a, b)
+    # rmax list length is checked (tensor.py:2029)
+    with pytest.raises(AssertionError):
+        tn.Tensor(held).round_tt(rmax=[2, 2])
+
+
+# ------------------------------------------------------------------ BASELINE-size configs
+def _metric_input(B, seed=0):
+    """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""
+    torch.manual_seed(seed)
+    g = oracle.tt_randn([64] * 8, 32, dtype=torch.float32, batch_size=B)
+    return oracle.tt_add(g, g, batch=True)
+
+
+def test_metric_config_vs_oracle():
+    """64^8 rank 64 -> 32 fp32, batch of 2: ranks, bond singular values and the train itself vs the oracle."""
+    inp = _metric_input(2)
+    t = gpu_tensor(inp, batch=True)
+    t.round_tt(rmax=32)
+    assert list(t.ranks_tt) == [1] + [32] * 7 + [1]
+    for i in range(2):
+        ref = oracle.round_tt([c[i] for c in inp], rmax=32, algorithm="eig")
+        ours = to_list(t.cores, i)
+        assert ranks(ours) == ranks(ref)
+        assert tt_rel_err(ours, ref) <= 2e-5
+        assert tt_rel_err(ours, [c[i] for c in inp]) <= 2e-5  # rank-32 redundant input is reproduced
+
+
+def test_metric_config_properties():
+    """Size-independent properties at the metric's full size (batch of 8)."""
+    inp = _metric_input(8, seed=1)
+    t = gpu_tensor(inp, batch=True)
+    t.round_tt(rmax=32)
+    c = [x.cpu().double() for x in t.cores]
+    for k in range(1, 8):  # cores 1..N-1 right-orthonormal
+        Rm = c[k].reshape(8, c[k].shape[1], -1)
+        err = (Rm @ Rm.transpose(1, 2) - torch.eye(Rm.shape[1], dtype=torch.float64)).abs().max().item()
+        assert err <= 5e-5, (k, err)
+    # all the norm sits in core 0: ||t|| = ||core_0||
+    for i in range(8):
+        n0 = c[0][i].norm().item()
+        nt = math.sqrt(oracle.tt_dot([x[i] for x in c], [x[i] for x in c]).item())
+        assert abs(n0 - nt) / nt <= 1e-5
+    # idempotence: rounding the rounded train again changes nothing
+    t2 = t.clone(); t2.round_tt(rmax=32)
+    for i in range(8):
+        assert tt_rel_err(to_list(t2.cores, i), to_list(t.cores, i)) <= 2e-5
+
+
+def test_c2_config_vs_oracle():
+    """BASELINE config C2: round_tt(eps=1e-4) of a rank-64 TT, 10 cores x mode 128, float64."""
+    torch.manual_seed(0)
+    g = oracle.tt_randn([128] * 10, 32, dtype=torch.float64)
+    inp = oracle.tt_add(g, g)
+    ref = oracle.round_tt(inp, eps=1e-4, algorithm="eig")
+    for alg in ("svd", "eig"):
+        t = gpu_tensor(inp)
+        t.round_tt(eps=1e-4, algorithm=alg)
+        ours = to_list(t.cores)
+        assert ranks(ours) == ranks(ref) == [1] + [32] * 9 + [1]
+        assert tt_rel_err(ours, ref) <= 1e-7
+        so, sr = oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)
+        for a, b in zip(so, sr):
+            assert ((a - b).abs().max() / b.max()).item() <= 1e-10

@@ -1,0 +1,198 @@
+"""Drop-in API on CPU tensors (the host mirror): golden vectors + the reference's own
+property tests (tests/test_round.py, tests/test_tensor.py, tests/test_init.py, tests/test_tools.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import tntorch_amd as tn
+from parity import analytic_128, load_case, load_meta
+
+
+def _max_abs(a, b):
+    return max((x - y).abs().max().item() for x, y in zip(a, b))
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_round(alg):
+    g = load_case("round_eps_f64")
+    t = tn.round_tt(tn.Tensor(g["inp"]), eps=1e-8, algorithm=alg)
+    assert t.ranks_tt.tolist() == [1, 4, 4, 4, 4, 4, 4, 4, 1]
+    assert _max_abs(t.cores, g[alg]) < 1e-9
+    g = load_case("round_batch_f64")
+    t = tn.Tensor(g["inp"], batch=True)
+    t.round_tt(rmax=2, algorithm=alg)
+    assert _max_abs(t.cores, g[alg]) < 1e-10
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_dense(alg):
+    g = load_case("dense_f64")
+    t = tn.Tensor(g["X"], ranks_tt=4, algorithm=alg)
+    assert _max_abs(t.cores, g[alg]) < 1e-9
+    g = load_case("dense_batch_f32")
+    t = tn.Tensor(g["X"], ranks_tt=3, batch=True, algorithm=alg)
+    ref = oracle.tt_to_dense(g[alg], batch=True)
+    assert (t.torch() - ref).norm() / ref.norm() < 1e-4
+
+
+def test_c0_config_cpu():
+    """BASELINE config C0: tn.Tensor(torch.randn(16,16,16,16)).round_tt(rmax=4) on CPU PyTorch."""
+    g = load_case("c0_16x4_rmax4_f32")
+    torch.manual_seed(0)
+    X = torch.randn(16, 16, 16, 16, dtype=torch.float32)
+    t = tn.Tensor(X)
+    assert [tuple(c.shape) for c in t.cores] == [(1, 16, 16), (16, 16, 256), (256, 16, 16), (16, 16, 1)]
+    assert torch.equal(t.torch(), X)
+    t.round_tt(rmax=4)
+    assert t.ranks_tt.tolist() == [1, 4, 4, 4, 1]
+    d, dref = t.torch(), oracle.tt_to_dense(g["svd"])
+    assert (d - dref).norm() / dref.norm() < 1e-4
+    assert abs((d - X).norm() / X.norm() - (dref - X).norm() / X.norm()) < 1e-5
+
+
+def test_golden_truncated_svd_and_orthogonalize():
+    g = load_case("truncated_svd_f64")
+    for c in load_meta()["cases"]["truncated_svd_f64"]["calls"]:
+        kw = {k: c[k] for k in ("eps", "rmax", "delta") if k in c}
+        u, v = tn.truncated_svd(g["M_" + c["M"]], left_ortho=c["left_ortho"], algorithm=c["algorithm"], **kw)
+        assert (u - g[f"call{c['i']}_left"]).abs().max() < 1e-10 and (v - g[f"call{c['i']}_right"]).abs().max() < 1e-10
+    g = load_case("orthogonalize_f64")
+    for name, fn in [("left0", lambda t: t.left_orthogonalize(0)), ("right4", lambda t: t.right_orthogonalize(4)),
+                     ("orth2", lambda t: t.orthogonalize(2)), ("orth4", lambda t: t.orthogonalize(4))]:
+        t = tn.Tensor([c.clone() for c in g["inp"]])
+        fn(t)
+        assert _max_abs(t.cores, g[name]) < 1e-12, name
+
+
+def test_known_answers_notebook():
+    full = analytic_128()
+    t = tn.Tensor(full, ranks_tt=3)
+    assert t.ranks_tt.tolist() == [1, 3, 3, 1]
+    assert abs(tn.relative_error(full, t).item() - 5.122978e-4) < 1e-9
+    t = tn.Tensor(full)
+    t.round_tt(eps=1e-5)
+    assert t.ranks_tt.tolist() == [1, 4, 6, 1]
+    assert abs(tn.relative_error(full, t).item() - 8.3358e-06) < 1e-9
+
+
+# ---- the reference's own tests, against this class --------------------------------------------
+def test_ref_orthogonalization():  # tests/test_round.py:7-18
+    np.random.seed(0)
+    for _ in range(30):
+        gt = tn.rand(np.random.randint(1, 8, np.random.randint(2, 6)), ranks_tt=np.random.randint(1, 5))
+        t = gt.clone()
+        assert tn.relative_error(gt, t) <= 1e-7
+        t.left_orthogonalize(0)
+        assert tn.relative_error(gt, t) <= 1e-7
+        t.right_orthogonalize(t.dim() - 1)
+        assert tn.relative_error(gt, t) <= 1e-7
+        t.orthogonalize(np.random.randint(t.dim()))
+        assert tn.relative_error(gt, t) <= 1e-7
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_ref_truncated_svd_batch_equals_loop(alg):  # tests/test_round.py:21-38
+    gt = torch.rand((2, 32, 32))
+    u, v = tn.truncated_svd(gt, batch=True, algorithm=alg)
+    for i in range(len(gt)):
+        u1, v1 = tn.truncated_svd(gt[i], batch=False, algorithm=alg)
+        assert torch.allclose(u1 @ v1, u[i] @ v[i])
+
+
+def test_ref_round_tt_svd_rank_recovery():  # tests/test_round.py:41-49
+    np.random.seed(1)
+    for _ in range(20):
+        gt = tn.rand(np.random.randint(1, 8, np.random.randint(8, 10)), ranks_tt=np.random.randint(1, 10))
+        gt.round_tt(1e-8, algorithm="svd")
+        t = gt + gt
+        t.round_tt(1e-8, algorithm="svd")
+        assert tn.relative_error(gt, t / 2) <= 1e-4
+        assert max(gt.ranks_tt) == max(t.ranks_tt)
+
+
+def test_ref_tt_tensor_batch_equals_loop():  # tests/test_tensor.py:28-49
+    torch.manual_seed(1)
+    for shape in [(10, 5, 5, 5, 5), (4, 2, 2, 2, 2, 2, 2, 2, 2)]:
+        a = torch.rand(*shape)
+        b = tn.Tensor(a, ranks_tt=3, batch=True)
+        for i in range(len(a)):
+            c = tn.Tensor(a[i], ranks_tt=3, batch=False)
+            for j, core in enumerate(c.cores):
+                assert torch.allclose(core, b.cores[j][i, ...])
+            assert torch.allclose(c.torch(), b.torch()[i])
+
+
+def test_ref_round_tt_keeps_tensor():  # tests/test_tensor.py:361-392
+    torch.manual_seed(2)
+    t = tn.rand([8] * 4, ranks_tt=5)
+    X = t.torch()
+    t.round_tt(eps=1e-8)
+    assert torch.norm(X - t.torch()) / torch.norm(X) < 1e-8
+    tb = tn.rand([3, 8, 8, 8], ranks_tt=5, batch=True)
+    Xb = tb.torch()
+    tb.round_tt(eps=1e-8)
+    assert torch.norm(Xb - tb.torch()) / torch.norm(Xb) < 1e-8
+
+
+def test_ref_from_ndarray():  # tests/test_init.py:7-13
+    np.random.seed(3)
+    for _ in range(30):
+        gt = np.random.rand(*np.random.randint(1, 8, np.random.randint(1, 6)))
+        t = tn.Tensor(gt)
+        assert np.linalg.norm(gt - t.numpy()) / np.linalg.norm(gt) <= 1e-7
+
+
+def test_ref_unfolding():  # tests/test_tools.py:7-10
+    X = torch.rand(3, 4, 5, 6)
+    assert torch.equal(tn.unfolding(X, 2), X.permute(2, 0, 1, 3).reshape(5, -1))
+    assert torch.equal(tn.unfolding(X, 1, batch=True), X.permute(0, 2, 1, 3).reshape(3, 5, -1))
+    c = torch.rand(2, 3, 4)
+    assert tn.left_unfolding(c).shape == (6, 4) and tn.right_unfolding(c).shape == (2, 12)
+    assert tn.left_unfolding(X, batch=True).shape == (3, 20, 6) and tn.right_unfolding(X, batch=True).shape == (3, 4, 30)
+
+
+def test_api_errors_and_quirks():
+    M = torch.rand(4, 5)
+    with pytest.raises(ValueError, match="either"):
+        tn.truncated_svd(M, delta=0.1, eps=0.1)
+    with pytest.raises(AssertionError):
+        tn.truncated_svd(M, algorithm="qr")
+    with pytest.raises(ValueError, match="ranks do not match"):
+        tn.Tensor([torch.rand(1, 3, 2), torch.rand(3, 3, 1)])
+    with pytest.raises(ValueError):
+        tn.Tensor("nope")
+    t = tn.rand([4, 4, 4], ranks_tt=2)
+    with pytest.raises(AssertionError):
+        t.round_tt(rmax=[1])
+    with pytest.raises(AssertionError):
+        t.left_orthogonalize(2)
+    with pytest.raises(NotImplementedError):
+        tn.Tensor(torch.rand(4, 4, 4), ranks_cp=2)
+    # quirks 1, 5, 13, 14
+    assert tn.Tensor(torch.ones(4, 4, 4), ranks_tt=3).ranks_tt.tolist() == [1, 1, 1, 1]
+    z = tn.Tensor([torch.zeros(1, 5, 3), torch.zeros(3, 5, 3), torch.zeros(3, 5, 1)])
+    z.round_tt()
+    assert z.ranks_tt.tolist() == [1, 1, 1, 1]
+    t = tn.rand([5, 5, 5, 5], ranks_tt=4)
+    before = [c.clone() for c in t.cores]
+    t2 = tn.round_tt(t, rmax=2)  # free function clones (round.py:17)
+    assert _max_abs(t.cores, before) == 0 and t2.ranks_tt.tolist() == [1, 2, 2, 2, 1]
+    t.ranks_tt = 3  # setter rounds in place (tensor.py:885-888)
+    assert t.ranks_tt.tolist() == [1, 3, 3, 3, 1]
+    # arithmetic used around the path
+    a, b = tn.rand([3, 4, 5], ranks_tt=2), tn.rand([3, 4, 5], ranks_tt=3)
+    assert torch.allclose((a + b).torch(), a.torch() + b.torch())
+    assert torch.allclose((a - b).torch(), a.torch() - b.torch())
+    assert torch.allclose((a * 2.5).torch(), a.torch() * 2.5) and torch.allclose((a / 2).torch(), a.torch() / 2)
+    assert torch.allclose((a + 1.5).torch(), a.torch() + 1.5)
+    assert abs(tn.dot(a, b).item() - (a.torch() * b.torch()).sum().item()) < 1e-9
+    assert abs(tn.norm(a).item() - a.torch().norm().item()) < 1e-9

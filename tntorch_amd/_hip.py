@@ -50,7 +50,7 @@ _SIGNATURES = {
         c_int,
         [c_int, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
-         c_int, c_int, c_double, c_int64, c_void_p, c_int64, c_void_p],
+         c_int, c_int, c_double, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     ),
     "ttr_norm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_scale_cols": (
@@ -196,7 +196,8 @@ def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def eigh_trunc(
-    G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int
+    G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: bool = True,
+    sweeps: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
     decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard)."""
@@ -214,7 +215,8 @@ def eigh_trunc(
     rmax = int(min(max(int(rmax), 1), 2**31 - 1))
     code = L.ttr_eigh_trunc(
         dt, n, batch, G.data_ptr(), ldg, sG, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
-        eig_mode, int(bool(use_delta)), float(delta2), rmax,
+        eig_mode, int(bool(use_delta)), float(delta2), rmax, int(bool(abs_floor)),
+        sweeps.data_ptr() if sweeps is not None else None,
         ws.data_ptr() if ws is not None else None, wsb, _stream(),
     )
     _check(code, "ttr_eigh_trunc")

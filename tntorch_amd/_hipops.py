@@ -11,10 +11,12 @@ Algorithms (reference call sites in brackets):
     - ``algorithm='eig'``: Gram -> Jacobi eigh (with the reference's 1e-8 clamp) ->
       rank rule -> projection; one pass, Gram accuracy (sigma resolved down to
       ~sqrt(eps)*sigma_max), exactly what round.py:101-135 computes.
-    - ``algorithm='svd'``: two Gram/Jacobi passes.  Pass 1 rotates ``M`` into nearly
-      orthogonal rows (columns); pass 2 re-computes the Gram matrix of the rotated
-      matrix, which is now graded/diagonally dominant, so Jacobi resolves every sigma to
-      high *relative* accuracy -- the accuracy class of LAPACK gesdd [round.py:96]
+    - ``algorithm='svd'``: two Gram/Jacobi passes.  Pass 1 rotates ``M`` into rows
+      (columns) that are orthogonal down to the accuracy of a float Gram matrix; pass 2
+      re-computes the Gram matrix of the ROTATED matrix, whose small rows are now formed
+      from small numbers (no cancellation against sigma_max^2), so every sigma comes out
+      with absolute error O(eps * sigma_max) -- the accuracy class of LAPACK gesdd
+      [round.py:96] -- instead of the O(sqrt(eps) * sigma_max) of a single Gram pass, and
       without ever forming the (I r)x(I r) right factor the reference throws away.
 * ``round_tt``      L2R QR sweep + R2L truncation sweep            [tensor.py:2008-2083]
 * ``dense_tt_svd``  right-to-left TT-SVD on the dense unfoldings; mathematically equal to

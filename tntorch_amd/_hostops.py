@@ -22,18 +22,41 @@ def _t(M):
 
 
 def qr(A3: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    return torch.linalg.qr(A3)  # tensor.py:1816 (reduced)
+    """tensor.py:1816 (reduced QR).  A single matrix goes through the 2-D LAPACK path exactly as in
+    the reference's non-batch mode, so CPU results match the reference bit for bit."""
+    if A3.shape[0] == 1:
+        Q, R = torch.linalg.qr(A3[0])
+        return Q[None], R[None]
+    return torch.linalg.qr(A3)
+
+
+def _mm(A, B):
+    if A.dim() == 3 and A.shape[0] == 1:
+        return (A[0] @ B[0])[None]
+    return A @ B
 
 
 def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
     """round.py:52-187 with the batch dim always present ([B, m, n]; B == 1 when not batch)."""
+    if not batch:  # same 2-D operator calls as the reference's non-batch mode
+        left, M2 = _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, False, squeeze=True)
+        return left, M2
+    return _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, True, squeeze=False)
+
+
+def _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch, squeeze):
+    if squeeze:
+        M3 = M3[0]
+        lead = ()
+    else:
+        lead = (M3.shape[0],)
     if delta is None and eps is not None:  # round.py:79-80
         delta = eps * torch.norm(M3).item()
     if delta is None:
         delta = 0
     if rmax is None:
         rmax = INT32_MAX
-    Bt, m, n = M3.shape
+    m, n = M3.shape[-2], M3.shape[-1]
 
     if algorithm == "svd":  # round.py:94-100
         U, sig = torch.linalg.svd(M3)[:2]
@@ -47,17 +70,17 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
         w = torch.where(w < 0, torch.zeros_like(w) + 1e-8, w)
         sig = torch.sqrt(w)
         sig, idx = torch.sort(sig, dim=-1, descending=True)
-        U = torch.gather(U, 2, idx[:, None, :].expand(-1, U.shape[1], -1))
+        U = torch.gather(U, -1, idx[..., None, :].expand(U.shape))
 
     if sig.max() < 1e-13:  # round.py:137-145 (kept on M's device/dtype)
-        return M3.new_zeros(Bt, m, 1), M3.new_zeros(Bt, 1, n)
+        return M3.new_zeros((1,) * squeeze + lead + (m, 1)), M3.new_zeros((1,) * squeeze + lead + (1, n))
 
     S = sig**2
     k = S.shape[-1]
     if batch:  # round.py:149-150
         rank = max(1, int(min(rmax, k)))
     else:  # round.py:152-158
-        tail = torch.cumsum(torch.flip(S[0], [0]), dim=0) <= delta**2
+        tail = torch.cumsum(torch.flip(S, [0]), dim=0) <= delta**2
         where = torch.where(tail)[0]
         if len(where) == 0:
             rank = max(1, int(min(rmax, k)))
@@ -81,6 +104,8 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
             newleft = M3 @ left
             M2 = _t(left)
             left = newleft
+    if squeeze:
+        return left[None], M2[None]
     return left, M2
 
 
@@ -91,7 +116,7 @@ def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     k = Q.shape[2]
     c[mu] = Q.reshape(Bt, r0, I, k)
     nxt = c[mu + 1]
-    c[mu + 1] = (R @ nxt.reshape(Bt, nxt.shape[1], -1)).reshape(Bt, k, nxt.shape[2], nxt.shape[3])
+    c[mu + 1] = _mm(R, nxt.reshape(Bt, nxt.shape[1], -1)).reshape(Bt, k, nxt.shape[2], nxt.shape[3])
     return R
 
 
@@ -103,7 +128,7 @@ def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     k = Q.shape[1]
     c[mu] = Q.reshape(Bt, k, I, r1)
     prev = c[mu - 1]
-    c[mu - 1] = (prev.reshape(Bt, prev.shape[1] * prev.shape[2], r0) @ L).reshape(Bt, prev.shape[1], prev.shape[2], k)
+    c[mu - 1] = _mm(prev.reshape(Bt, prev.shape[1] * prev.shape[2], r0), L).reshape(Bt, prev.shape[1], prev.shape[2], k)
     return L
 
 
@@ -124,7 +149,7 @@ def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch) -> Lis
         r = right.shape[1]
         c[mu] = right.reshape(Bt, r, I, rn)
         prev = c[mu - 1]
-        c[mu - 1] = (prev.reshape(Bt, prev.shape[1] * prev.shape[2], R) @ left).reshape(Bt, prev.shape[1], prev.shape[2], r)
+        c[mu - 1] = _mm(prev.reshape(Bt, prev.shape[1] * prev.shape[2], R), left).reshape(Bt, prev.shape[1], prev.shape[2], r)
     return c
 
 

@@ -133,7 +133,8 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
 int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
-                  int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream);
+                  int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
+                  int64_t ws_bytes, hipStream_t stream);
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int eigh_max_n_lds(int dtype);
 
@@ -189,13 +190,14 @@ int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return e
 
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
                    int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
-                   int use_delta, double delta2, int64_t rmax, void* workspace, int64_t workspace_bytes, void* stream) {
+                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_trunc: bad dtype %d", dtype);
   TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(G && V && sigma && info, TTR_E_INVALID, "ttr_eigh_trunc: null pointer");
   return eigh_dispatch(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                       use_delta, delta2, rmax, workspace, workspace_bytes, (hipStream_t)stream);
+                       use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ttr_norm(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out, void* stream) {

@@ -8,6 +8,11 @@
 //   phase 1  one thread per pair computes (c, s) from G_pp, G_qq, G_pq
 //   phase 2  columns p,q of G and V are rotated (lanes walk the rows)
 //   phase 3  rows p,q of G are rotated (lanes walk the columns)
+// The rotation parameters and the accumulated eigenvector matrix V are kept in DOUBLE for
+// either input type: ~500 rotations touch every entry of V, and float accumulation leaves
+// V^T V = I + O(1e-6), which shows up one-to-one as reconstruction error of the
+// truncation (measured 3.5e-6 per bond vs 3e-7 for LAPACK); with double accumulation V is
+// orthogonal to float round-off.
 // Rotations are skipped when |G_pq| <= eps * sqrt(G_pp G_qq) (the relative criterion
 // that gives Jacobi its high relative accuracy on graded Gram matrices); the sweep
 // loop ends when a whole sweep rotates nothing.
@@ -33,8 +38,11 @@ struct EighArgs {
   int use_delta;
   double delta2;
   int64_t rmax;
-  T* ws;  // global-memory variant: per matrix 2 * n * (n + 1) elements
+  T* ws;  // global-memory variant: per matrix n * (n + 1) * (sizeof(T) + 8) bytes (G in T, V in double)
   int max_sweeps;
+  int abs_floor;     // 1: also skip rotations with |G_pq| <= tol * max|G_ii| (plain Gram input: its entries are
+                     //    only accurate to eps*||G||, below that level rotations chase rounding noise forever)
+  int32_t* sweeps;   // optional [batch]: sweeps used (diagnostics / convergence tests)
 };
 
 constexpr int kMaxPairs = 512;  // n <= 1024 in the global-memory variant
@@ -50,52 +58,64 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int np = ne / 2;
 
   // carve the dynamic LDS
-  T* cs_c = reinterpret_cast<T*>(smem_raw);          // [np]
-  T* cs_s = cs_c + kMaxPairs;                        // [np]
+  double* cs_c = reinterpret_cast<double*>(smem_raw);  // [np]
+  double* cs_s = cs_c + kMaxPairs;                     // [np]
   int* pq_p = reinterpret_cast<int*>(cs_s + kMaxPairs);
   int* pq_q = pq_p + kMaxPairs;
   int* flags = pq_q + kMaxPairs;                     // [0]: rotated-this-sweep
   T* sg = reinterpret_cast<T*>(flags + 16);          // sigma / ordering scratch [2 * n]
   T* Gs;
-  T* Vs;
+  double* Vs;
   if (LDSRES) {
-    Gs = sg + 2 * ((n + 1) & ~1) + 2;
-    Vs = Gs + (size_t)n * ld;
+    Vs = reinterpret_cast<double*>(sg + 2 * ((n + 1) & ~1) + 2);  // 8-byte aligned by construction
+    Gs = reinterpret_cast<T*>(Vs + (size_t)n * ld);
   } else {
-    Gs = p.ws + bt * (int64_t)2 * n * ld;
-    Vs = Gs + (size_t)n * ld;
+    unsigned char* base = reinterpret_cast<unsigned char*>(p.ws) + bt * (int64_t)n * ld * (8 + sizeof(T));
+    Vs = reinterpret_cast<double*>(base);
+    Gs = reinterpret_cast<T*>(Vs + (size_t)n * ld);
   }
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   for (int idx = tid; idx < n * n; idx += kThreads) {
     const int i = idx / n, j = idx % n;
     Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
-    Vs[i * ld + j] = (i == j) ? T(1) : T(0);
+    Vs[i * ld + j] = (i == j) ? 1.0 : 0.0;
   }
   if (tid == 0) flags[0] = 0;
   __syncthreads();
+  T floor_abs = Num<T>::tiny();
+  if (p.abs_floor) {
+    T gmax = 0;
+    for (int i = 0; i < n; ++i) gmax = fmax(gmax, fabs(Gs[i * ld + i]));  // broadcast reads, n <= 1024
+    floor_abs = fmax(floor_abs, Num<T>::eps() * sqrt((T)n) * gmax);
+  }
 
-  const T eps = Num<T>::eps();
-  const T tiny = Num<T>::tiny();
+  // LAPACK xGESVJ-style tolerance sqrt(n)*eps: with a bare eps the rounding noise of the updates keeps
+  // regenerating off-diagonals at the eps level and the sweep loop never terminates.
+  const T eps = Num<T>::eps() * sqrt((T)n);
   const int m1 = ne - 1;
+  const int k0 = tid / n, i0 = tid % n;            // item = tid + 256*e  <->  (k, i), advanced incrementally
+  const int dk = kThreads / n, di = kThreads % n;
 
+  int sweeps_used = 0;
   for (int sweep = 0; sweep < p.max_sweeps && n > 1; ++sweep) {
+    sweeps_used = sweep + 1;
     for (int r = 0; r < m1; ++r) {
       // ---- phase 1: rotations of this round
       for (int k = tid; k < np; k += kThreads) {
         int pp, qq;
         if (k == 0) { pp = ne - 1; qq = r % m1; }
         else { pp = (r + k) % m1; qq = (r - k + m1) % m1; }
-        T c = T(1), s = T(0);
+        double c = 1.0, s = 0.0;
         if (pp < n && qq < n) {
           const T app = Gs[pp * ld + pp], aqq = Gs[qq * ld + qq], apq = Gs[pp * ld + qq];
           const T aabs = fabs(apq);
-          if (aabs > eps * sqrt(fabs(app) * fabs(aqq)) && aabs > tiny) {
-            const T theta = (aqq - app) / (T(2) * apq);
-            T t;
-            if (fabs(theta) > Num<T>::big_theta()) t = T(0.5) / theta;
-            else t = copysign(T(1), theta) / (fabs(theta) + sqrt(T(1) + theta * theta));
-            c = T(1) / sqrt(T(1) + t * t);
+          if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs) {  // no overflow of app*aqq
+            const double theta = ((double)aqq - (double)app) / (2.0 * (double)apq);
+            double t;
+            if (fabs(theta) > 1e150) t = 0.5 / theta;
+            else t = copysign(1.0, theta) / (fabs(theta) + sqrt(1.0 + theta * theta));
+            c = 1.0 / sqrt(1.0 + t * t);
             s = t * c;
             flags[0] = 1;
           }
@@ -104,32 +124,35 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       }
       __syncthreads();
       // ---- phase 2: G <- G J, V <- V J  (columns p,q; lanes walk rows)
-      for (int item = tid; item < np * n; item += kThreads) {
-        const int k = item / n, i = item % n;
-        const T s = cs_s[k];
-        if (s != T(0)) {
-          const T c = cs_c[k];
+      for (int item = tid, k = k0, i = i0; item < np * n; item += kThreads) {
+        const double sd = cs_s[k];
+        if (sd != 0.0) {
+          const double cd = cs_c[k];
+          const T s = (T)sd, c = (T)cd;
           const int pp = pq_p[k], qq = pq_q[k];
           const T gp = Gs[i * ld + pp], gq = Gs[i * ld + qq];
           Gs[i * ld + pp] = c * gp - s * gq;
           Gs[i * ld + qq] = s * gp + c * gq;
-          const T vp = Vs[i * ld + pp], vq = Vs[i * ld + qq];
-          Vs[i * ld + pp] = c * vp - s * vq;
-          Vs[i * ld + qq] = s * vp + c * vq;
+          const double vp = Vs[i * ld + pp], vq = Vs[i * ld + qq];
+          Vs[i * ld + pp] = cd * vp - sd * vq;
+          Vs[i * ld + qq] = sd * vp + cd * vq;
         }
+        i += di; k += dk;
+        if (i >= n) { i -= n; ++k; }
       }
       __syncthreads();
       // ---- phase 3: G <- J^T G  (rows p,q; lanes walk columns)
-      for (int item = tid; item < np * n; item += kThreads) {
-        const int k = item / n, i = item % n;
-        const T s = cs_s[k];
-        if (s != T(0)) {
-          const T c = cs_c[k];
+      for (int item = tid, k = k0, i = i0; item < np * n; item += kThreads) {
+        const double sd = cs_s[k];
+        if (sd != 0.0) {  // same predicate as phase 2 (a (T)sd that underflows must not skip the row update)
+          const T s = (T)sd, c = (T)cs_c[k];
           const int pp = pq_p[k], qq = pq_q[k];
           const T gp = Gs[pp * ld + i], gq = Gs[qq * ld + i];
           Gs[pp * ld + i] = c * gp - s * gq;
           Gs[qq * ld + i] = s * gp + c * gq;
         }
+        i += di; k += dk;
+        if (i >= n) { i -= n; ++k; }
       }
       __syncthreads();
     }
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     sig_sorted[pos] = si;
     // permute the eigenvector: column i -> column pos
     T* __restrict__ V = p.V + bt * p.strideV;
-    for (int row = 0; row < n; ++row) V[(int64_t)row * p.ldv + pos] = Vs[row * ld + i];
+    for (int row = 0; row < n; ++row) V[(int64_t)row * p.ldv + pos] = (T)Vs[row * ld + i];
   }
   __syncthreads();
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
@@ -187,13 +210,14 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       rank = (int)rk;
     }
     p.info[bt] = rank;
+    if (p.sweeps) p.sweeps[bt] = sweeps_used;
   }
 }
 
 static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
-  size_t bytes = 2 * kMaxPairs * elem + 2 * kMaxPairs * sizeof(int) + 16 * sizeof(int);
+  size_t bytes = 2 * kMaxPairs * sizeof(double) + 2 * kMaxPairs * sizeof(int) + 16 * sizeof(int);
   bytes += (2 * ((n + 1) & ~1) + 2) * elem;
-  if (ldsres) bytes += 2 * (size_t)n * (n + 1) * elem;
+  if (ldsres) bytes += (size_t)n * (n + 1) * (elem + sizeof(double));  // G in T, V in double
   return (bytes + 15) & ~size_t(15);
 }
 
@@ -207,13 +231,14 @@ int eigh_max_n_lds(int dtype) {
 
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   if (n <= eigh_max_n_lds(dtype)) return 0;
-  return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
+  return batch * n * (n + 1) * ((dtype == TTR_F64 ? 8 : 4) + 8);
 }
 
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
                       int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
-                      int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                      int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
+                      int64_t ws_bytes, hipStream_t stream) {
   TTR_REQUIRE(n >= 1 && n <= 2 * kMaxPairs, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %d]", (long long)n,
               2 * kMaxPairs);
   EighArgs<T> p;
@@ -225,6 +250,8 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.eig_mode = eig_mode; p.use_delta = use_delta; p.delta2 = delta2; p.rmax = rmax;
   p.ws = (T*)ws;
   p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
+  p.abs_floor = abs_floor;
+  p.sweeps = sweeps;
   const bool ldsres = n <= eigh_max_n_lds(dtype);
   if (!ldsres) {
     const int64_t need = eigh_workspace_bytes(dtype, n, batch);
@@ -248,12 +275,13 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
 
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
-                  int use_delta, double delta2, int64_t rmax, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                  int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
+                  int64_t ws_bytes, hipStream_t stream) {
   if (dtype == TTR_F32)
     return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                             use_delta, delta2, rmax, ws, ws_bytes, stream);
+                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
   return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                            use_delta, delta2, rmax, ws, ws_bytes, stream);
+                            use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
 }
 
 }  // namespace ttr
