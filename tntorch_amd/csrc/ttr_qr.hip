@@ -45,6 +45,48 @@ struct QrLevel {
   int top;     // 1: single block, writes k x n to the user's R
 };
 
+// 16-byte LDS reads of the (wave-uniform) reflector: 4 floats / 2 doubles per ds_read_b128.
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<double> {
+  static constexpr int N = 2;
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+// w = sum_r v[r] * a[r] over a thread's NC-row column segment; v is read from LDS in 16-byte pieces,
+// four independent accumulators break the FMA dependency chain.
+template <typename T, int NC>
+__device__ __forceinline__ T seg_dot(const T* __restrict__ v, const T (&a)[NC]) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int q = 0; q < NC / VN; ++q) {
+    const V x = *reinterpret_cast<const V*>(v + q * VN);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[(q * VN + e) & 3] += x[e] * a[q * VN + e];
+  }
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <typename T, int NC>
+__device__ __forceinline__ void seg_axpy(const T* __restrict__ v, T f, T (&a)[NC]) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+#pragma unroll
+  for (int q = 0; q < NC / VN; ++q) {
+    const V x = *reinterpret_cast<const V*>(v + q * VN);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) a[q * VN + e] -= f * x[e];
+  }
+}
+
 __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& row0, int& rows) {
   const int64_t q = m / nb, rem = m % nb;
   row0 = (int64_t)b * q + (b < rem ? b : rem);
@@ -55,9 +97,10 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 template <typename T, int NC>
 __global__ __launch_bounds__(kThreads) void qr_factor_kernel(QrLevel<T> p) {
   constexpr int SEGS = kThreads / NC;  // row segments; each owns NC rows (SEGS * NC == BR)
-  __shared__ T xbuf[BR];               // current column (as stored)
-  __shared__ T vbuf[BR];               // current reflector (explicit)
-  __shared__ T wpart[SEGS][NC];        // per-segment partial dots
+  __shared__ __attribute__((aligned(16))) T xbuf[BR];          // current column (as stored)
+  __shared__ __attribute__((aligned(16))) T vbuf[BR];          // current reflector (explicit)
+  __shared__ __attribute__((aligned(16))) T wpart[SEGS][NC];   // per-segment partial dots
+  __shared__ T rdiag[NC];                                      // beta_j = R[j][j]
   const int tid = threadIdx.x;
   const int c = tid % NC, seg = tid / NC;
   const int b = blockIdx.x;
@@ -77,12 +120,20 @@ __global__ __launch_bounds__(kThreads) void qr_factor_kernel(QrLevel<T> p) {
   }
   T* __restrict__ Vt = p.Vt + ((bt * p.nb + b) * (int64_t)n) * BR;
   T* __restrict__ tau = p.tau + (bt * p.nb + b) * (int64_t)n;
+  if (tid < NC) rdiag[tid] = T(0);
 
   for (int j = 0; j < kb; ++j) {
-    // (1) the owner of column j publishes it
+    // (1) the owner of column j publishes it (16-byte LDS stores, one lane per segment)
     if (c == j) {
+      using V = typename Vec16<T>::type;
+      constexpr int VN = Vec16<T>::N;
 #pragma unroll
-      for (int r = 0; r < NC; ++r) xbuf[seg * NC + r] = a[r];
+      for (int q = 0; q < NC / VN; ++q) {
+        V x;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) x[e] = a[q * VN + e];
+        *reinterpret_cast<V*>(&xbuf[seg * NC + q * VN]) = x;
+      }
     }
     __syncthreads();
     // (2) every wave reduces the whole column redundantly: no cross-wave step
@@ -107,42 +158,38 @@ __global__ __launch_bounds__(kThreads) void qr_factor_kernel(QrLevel<T> p) {
     const T vt = (tid > j) ? xt * scale : (tid == j ? T(1) : T(0));
     vbuf[tid] = vt;
     Vt[(int64_t)j * BR + tid] = vt;  // coalesced, fire and forget
-    if (tid == 0) tau[j] = tj;
+    if (tid == 0) { tau[j] = tj; rdiag[j] = beta; }
     __syncthreads();
-    // (3) owner stores v / beta in place; the columns to its right take the dot product
-    if (c == j) {
-#pragma unroll
-      for (int r = 0; r < NC; ++r) {
-        const int rg = seg * NC + r;
-        a[r] = (rg > j) ? vbuf[rg] : (rg == j ? beta : a[r]);
-      }
-    } else if (c > j && c < n) {
-      T w = 0;
-#pragma unroll
-      for (int r = 0; r < NC; ++r) w += vbuf[seg * NC + r] * a[r];
-      wpart[seg][c] = w;
-    }
+    // (3) the columns right of j take the dot product with the reflector.  The owner's registers are
+    //     left alone: rows < j of column j are final R entries, the diagonal lives in rdiag, and the
+    //     reflector itself already went to Vt.
+    const bool active = (c > j && c < n);
+    if (active) wpart[seg][c] = seg_dot<T, NC>(&vbuf[seg * NC], a);
     __syncthreads();
     // (4) rank-1 update of the trailing columns
-    if (c > j && c < n) {
+    if (active) {
       T w = 0;
 #pragma unroll
-      for (int s = 0; s < SEGS; ++s) w += wpart[s][c];
-      const T f = tj * w;
-#pragma unroll
-      for (int r = 0; r < NC; ++r) a[r] -= f * vbuf[seg * NC + r];
+      for (int s2 = 0; s2 < SEGS; ++s2) w += wpart[s2][c];
+      seg_axpy<T, NC>(&vbuf[seg * NC], tj * w, a);
     }
     // next (1) writes xbuf (last read before the 2nd barrier) -> no barrier needed here;
     // vbuf/wpart are rewritten only after the next iteration's first barrier.
   }
+  __syncthreads();
 
   // R: rows 0..kb-1 live in segment 0 (kb <= n <= NC)
   T* __restrict__ Rout = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
   const int rrows = p.top ? kb : n;
   if (seg == 0 && c < n) {
+    const T dg = rdiag[c];
 #pragma unroll
     for (int r = 0; r < NC; ++r) {
-      if (r < rrows) Rout[(int64_t)r * p.ldr + c] = (r <= c && r < kb) ? a[r] : T(0);
+      if (r < rrows) {
+        T v = T(0);
+        if (r < kb) v = (r < c) ? a[r] : (r == c ? dg : T(0));
+        Rout[(int64_t)r * p.ldr + c] = v;
+      }
     }
   }
 }
@@ -165,8 +212,8 @@ struct QrApply {
 template <typename T, int NC>
 __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
   constexpr int SEGS = kThreads / NC;
-  __shared__ T vbuf[3][BR];
-  __shared__ T wpart[2][SEGS][NC];
+  __shared__ __attribute__((aligned(16))) T vbuf[3][BR];
+  __shared__ __attribute__((aligned(16))) T wpart[2][SEGS][NC];
   __shared__ T taus[NC];
   const int tid = threadIdx.x;
   const int c = tid % NC, seg = tid / NC;
@@ -204,18 +251,13 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
     const int cur = j % 3;
     const int wb = j & 1;
     if (j > 0) vnext = Vt[(int64_t)(j - 1) * BR + tid];  // prefetch, lands under the FMAs
-    T w = 0;
-#pragma unroll
-    for (int r = 0; r < NC; ++r) w += vbuf[cur][seg * NC + r] * a[r];
-    wpart[wb][seg][c] = w;
+    wpart[wb][seg][c] = seg_dot<T, NC>(&vbuf[cur][seg * NC], a);
     if (j > 0) vbuf[(j - 1) % 3][tid] = vnext;
     __syncthreads();
     T ws = 0;
 #pragma unroll
     for (int s = 0; s < SEGS; ++s) ws += wpart[wb][s][c];
-    const T f = taus[j] * ws;
-#pragma unroll
-    for (int r = 0; r < NC; ++r) a[r] -= f * vbuf[cur][seg * NC + r];
+    seg_axpy<T, NC>(&vbuf[cur][seg * NC], taus[j] * ws, a);
   }
 
   T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
