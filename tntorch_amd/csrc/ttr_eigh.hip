@@ -46,6 +46,7 @@ struct EighArgs {
 };
 
 constexpr int kMaxPairs = 512;  // n <= 1024 in the global-memory variant
+constexpr int UNR = 8;          // rotation items batched per thread (n = 64: exactly one batch per phase)
 
 template <typename T, bool LDSRES>
 __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
@@ -120,39 +121,77 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
             flags[0] = 1;
           }
         }
-        cs_c[k] = c; cs_s[k] = s; pq_p[k] = pp; pq_q[k] = qq;
+        // phantom indices (n odd) carry s = 0 and are clamped so that the batched loads stay in bounds
+        cs_c[k] = c; cs_s[k] = s; pq_p[k] = pp < n ? pp : 0; pq_q[k] = qq < n ? qq : 0;
       }
       __syncthreads();
       // ---- phase 2: G <- G J, V <- V J  (columns p,q; lanes walk rows)
-      for (int item = tid, k = k0, i = i0; item < np * n; item += kThreads) {
-        const double sd = cs_s[k];
-        if (sd != 0.0) {
-          const double cd = cs_c[k];
-          const T s = (T)sd, c = (T)cd;
-          const int pp = pq_p[k], qq = pq_q[k];
-          const T gp = Gs[i * ld + pp], gq = Gs[i * ld + qq];
-          Gs[i * ld + pp] = c * gp - s * gq;
-          Gs[i * ld + qq] = s * gp + c * gq;
-          const double vp = Vs[i * ld + pp], vq = Vs[i * ld + qq];
-          Vs[i * ld + pp] = cd * vp - sd * vq;
-          Vs[i * ld + qq] = sd * vp + cd * vq;
+      // Different pairs touch disjoint columns, so a thread's items are independent: all LDS loads are
+      // issued first, then the FMAs, then the stores (written as a plain loop the compiler must keep
+      // the loads behind the previous item's stores -- possible aliasing -- and every item pays a full
+      // LDS round trip).
+      for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
+        double cd[UNR], sd[UNR], vp[UNR], vq[UNR];
+        T gp[UNR], gq[UNR];
+        int pp[UNR], qq[UNR], ii[UNR];
+        bool on[UNR];
+        int k = kb_, i = ib_, item = base;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          on[u] = item < np * n;
+          const int ku = on[u] ? k : 0;
+          ii[u] = on[u] ? i : 0;
+          sd[u] = cs_s[ku]; cd[u] = cs_c[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
+          on[u] = on[u] && (sd[u] != 0.0);
+          item += kThreads; i += di; k += dk;
+          if (i >= n) { i -= n; ++k; }
         }
-        i += di; k += dk;
-        if (i >= n) { i -= n; ++k; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          gp[u] = Gs[ii[u] * ld + pp[u]]; gq[u] = Gs[ii[u] * ld + qq[u]];
+          vp[u] = Vs[ii[u] * ld + pp[u]]; vq[u] = Vs[ii[u] * ld + qq[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (on[u]) {
+            const T c = (T)cd[u], sn = (T)sd[u];
+            Gs[ii[u] * ld + pp[u]] = c * gp[u] - sn * gq[u];
+            Gs[ii[u] * ld + qq[u]] = sn * gp[u] + c * gq[u];
+            Vs[ii[u] * ld + pp[u]] = cd[u] * vp[u] - sd[u] * vq[u];
+            Vs[ii[u] * ld + qq[u]] = sd[u] * vp[u] + cd[u] * vq[u];
+          }
+        }
+        base = item; kb_ = k; ib_ = i;
       }
       __syncthreads();
-      // ---- phase 3: G <- J^T G  (rows p,q; lanes walk columns)
-      for (int item = tid, k = k0, i = i0; item < np * n; item += kThreads) {
-        const double sd = cs_s[k];
-        if (sd != 0.0) {  // same predicate as phase 2 (a (T)sd that underflows must not skip the row update)
-          const T s = (T)sd, c = (T)cs_c[k];
-          const int pp = pq_p[k], qq = pq_q[k];
-          const T gp = Gs[pp * ld + i], gq = Gs[qq * ld + i];
-          Gs[pp * ld + i] = c * gp - s * gq;
-          Gs[qq * ld + i] = s * gp + c * gq;
+      // ---- phase 3: G <- J^T G  (rows p,q; lanes walk columns); same load / compute / store batching
+      for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
+        double sd[UNR];
+        T c[UNR], gp[UNR], gq[UNR];
+        int pp[UNR], qq[UNR], ii[UNR];
+        bool on[UNR];
+        int k = kb_, i = ib_, item = base;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          on[u] = item < np * n;
+          const int ku = on[u] ? k : 0;
+          ii[u] = on[u] ? i : 0;
+          sd[u] = cs_s[ku]; c[u] = (T)cs_c[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
+          on[u] = on[u] && (sd[u] != 0.0);  // same predicate as phase 2
+          item += kThreads; i += di; k += dk;
+          if (i >= n) { i -= n; ++k; }
         }
-        i += di; k += dk;
-        if (i >= n) { i -= n; ++k; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { gp[u] = Gs[pp[u] * ld + ii[u]]; gq[u] = Gs[qq[u] * ld + ii[u]]; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (on[u]) {
+            const T sn = (T)sd[u];
+            Gs[pp[u] * ld + ii[u]] = c[u] * gp[u] - sn * gq[u];
+            Gs[qq[u] * ld + ii[u]] = sn * gp[u] + c[u] * gq[u];
+          }
+        }
+        base = item; kb_ = k; ib_ = i;
       }
       __syncthreads();
     }
