@@ -80,8 +80,9 @@ int ttr_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
  * k = min(m, n), LAPACK sign convention (geqrf: beta = -sign(alpha)*norm), R upper triangular/trapezoidal.
  * Replaces: torch.linalg.qr at tensor.py:1816 (left_orthogonalize) and tensor.py:1853/1859
  * (right_orthogonalize, on the transposed unfolding).
- * Communication-avoiding TSQR: 256-row blocks factored in registers, R factors reduced over a tree,
- * Q formed by walking the tree back.  n <= ttr_qr_max_cols(dtype).
+ * Communication-avoiding TSQR: 256-row blocks held as MFMA accumulator tiles and factored with the blocked
+ * compact-WY algorithm (16-column panels, trailing updates on the matrix cores), R factors reduced over a
+ * 4-ary tree, Q formed by walking the tree back (pure MFMA).  n <= ttr_qr_max_cols(dtype).
  */
 int64_t ttr_qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
 int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch,
@@ -89,6 +90,22 @@ int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch,
            void* Q, int64_t ldq, int64_t strideQ,
            void* R, int64_t ldr, int64_t strideR,
            void* workspace, int64_t workspace_bytes, void* stream);
+/*
+ * The two halves of ttr_qr, for callers that fuse work into the formation of Q:
+ *   ttr_qr_factor  factors A (TSQR tree of blocked compact-WY Householder blocks on MFMA), writes R (k x n) and
+ *                  leaves the reflectors / T factors in `workspace` (which must stay alive and untouched);
+ *   ttr_qr_apply   forms Out[b] (m x kcols) = Q[b] * C[b], C (k x kcols, kcols <= k) -- C == NULL means the
+ *                  identity, i.e. the first kcols columns of Q.  round_tt uses it to produce core * (U sigma)
+ *                  directly (the "push left" einsum of tensor.py:2081-2083) without ever materialising Q.
+ */
+int ttr_qr_factor(int dtype, int64_t m, int64_t n, int64_t batch,
+                  const void* A, int64_t lda, int64_t strideA,
+                  void* R, int64_t ldr, int64_t strideR,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int ttr_qr_apply(int dtype, int64_t m, int64_t n, int64_t batch,
+                 void* workspace, int64_t workspace_bytes,
+                 const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
+                 void* Out, int64_t ldo, int64_t strideO, void* stream);
 
 /*
  * Symmetric eigen-decomposition + the rank rule of truncated_svd, batched, on device.

@@ -45,6 +45,17 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_void_p],
     ),
+    "ttr_qr_factor": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_qr_apply": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64,
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+    ),
     "ttr_eigh_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
     "ttr_eigh_trunc": (
         c_int,
@@ -193,6 +204,56 @@ def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
                     ws.data_ptr(), wsb, _stream())
     _check(code, "ttr_qr")
     return Q, R
+
+
+class QrFactors:
+    """Handle on a factored batch (reflectors + T factors live in ``ws``) for later ``qr_apply`` calls."""
+
+    __slots__ = ("ws", "wsb", "m", "n", "batch", "dtype", "R")
+
+    def __init__(self, ws, wsb, m, n, batch, dtype, R):
+        self.ws, self.wsb, self.m, self.n, self.batch, self.dtype, self.R = ws, wsb, m, n, batch, dtype, R
+
+    @property
+    def k(self):
+        return min(self.m, self.n)
+
+
+def qr_factor(A: torch.Tensor) -> QrFactors:
+    """Factor [batch, m, n]; returns a handle holding R [batch, k, n] and the implicit Q."""
+    L = lib()
+    dt = dtype_code(A.dtype)
+    A, lda, sA = _mat(A)
+    batch, m, n = A.shape
+    k = min(m, n)
+    R = torch.empty((batch, k, n), dtype=A.dtype, device=A.device)
+    wsb = L.ttr_qr_workspace_bytes(dt, m, n, max(batch, 1))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=A.device)
+    if batch > 0:
+        code = L.ttr_qr_factor(dt, m, n, batch, A.data_ptr(), lda, sA, R.data_ptr(), n, k * n, ws.data_ptr(), wsb, _stream())
+        _check(code, "ttr_qr_factor")
+    return QrFactors(ws, wsb, m, n, batch, A.dtype, R)
+
+
+def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None) -> torch.Tensor:
+    """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q)."""
+    L = lib()
+    dt = dtype_code(f.dtype)
+    if C is not None:
+        C, ldc, sC = _mat(C)
+        assert C.shape[0] == f.batch and C.shape[1] == f.k
+        kcols = C.shape[2]
+        cptr = C.data_ptr()
+    else:
+        kcols = f.k if kcols is None else kcols
+        ldc, sC, cptr = 0, 0, None
+    Out = torch.empty((f.batch, f.m, kcols), dtype=f.dtype, device=f.ws.device)
+    if f.batch == 0:
+        return Out
+    code = L.ttr_qr_apply(dt, f.m, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
+                          Out.data_ptr(), kcols, f.m * kcols, _stream())
+    _check(code, "ttr_qr_apply")
+    return Out
 
 
 def eigh_trunc(

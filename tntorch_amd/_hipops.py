@@ -184,27 +184,43 @@ def round_tt(
     algorithm: str,
     batch: bool,
 ) -> List[torch.Tensor]:
-    """tensor.py:2008-2083 on [B, r0, I, r1] cores.  Returns new cores (inputs untouched)."""
+    """tensor.py:2008-2083 on [B, r0, I, r1] cores.  Returns new cores (inputs untouched).
+
+    Same two sweeps as the reference, with one fusion: the left-orthogonal cores Q_mu of the L2R sweep
+    are never materialised.  Each QR leaves its reflectors in a workspace; in the R2L sweep the core
+    that the reference obtains as ``einsum(Q_mu, U sigma)`` (tensor.py:2081-2083) is produced directly
+    by applying the reflectors to ``[U sigma; 0]`` (``ttr_qr_apply``): half the columns, no Q round
+    trip through HBM, no separate push-left GEMM.
+    """
     c = list(cores4)
     N = len(c)
-    for mu in range(N - 1):  # tensor.py:1905-1906
-        left_orthogonalize(c, mu)
+    facs = []
+    for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit)
+        Bt, r0, I, r1 = c[mu].shape
+        f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1))
+        facs.append((f, r0, I))
+        nxt = c[mu + 1]
+        pushed = _hip.gemm(f.R, nxt.reshape(Bt, nxt.shape[1], nxt.shape[2] * nxt.shape[3]))
+        c[mu + 1] = pushed.reshape(Bt, f.k, nxt.shape[2], nxt.shape[3])
+        c[mu] = None
     if batch:  # tensor.py:2036-2037
         delta = None
     else:  # tensor.py:2039-2051
         nrm = float(_hip.norm(c[-1].reshape(1, -1))[0].item())
         delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
-    for mu in range(N - 1, 0, -1):  # tensor.py:2053-2083
-        Bt, R, I, rn = c[mu].shape
-        t = truncate(c[mu].reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch)
-        c[mu] = t.right.reshape(Bt, t.rank, I, rn)
-        prev = c[mu - 1]
-        p2 = prev.reshape(Bt, prev.shape[1] * prev.shape[2], R)
-        if t.colscale is not None:  # fused (core @ U) * sigma
-            pushed = _hip.gemm(p2, t.left, colscale=t.colscale, colscale_mode=_hip.SCALE_MUL)
+    left = None  # (U sigma) of the bond to the right, to be absorbed by the current core
+    for mu in range(N - 1, 0, -1):  # R2L: tensor.py:2053-2083
+        if mu == N - 1:
+            M4 = c[mu]
         else:
-            pushed = _hip.gemm(p2, t.left)
-        c[mu - 1] = pushed.reshape(Bt, prev.shape[1], prev.shape[2], t.rank)
+            f, r0, I = facs[mu]
+            M4 = _hip.qr_apply(f, left).reshape(f.batch, r0, I, left.shape[2])
+        Bt, R, I, rn = M4.shape
+        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch)
+        c[mu] = t.right.reshape(Bt, t.rank, I, rn)
+        left = t.left_scaled()
+    f, r0, I = facs[0]
+    c[0] = _hip.qr_apply(f, left).reshape(f.batch, r0, I, left.shape[2])
     return c
 
 

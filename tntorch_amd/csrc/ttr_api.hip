@@ -126,9 +126,11 @@ int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64
                   const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
                   int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream);
 int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch);
-int qr_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
-                int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes,
-                hipStream_t stream);
+int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
+int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
+                      int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
+                      hipStream_t stream);
 int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
 int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
@@ -175,15 +177,37 @@ int64_t ttr_qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   return qr_workspace_bytes(dtype, m, n, batch);
 }
 
+int ttr_qr_factor(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
+                  int64_t ldr, int64_t strideR, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_factor: bad dtype %d", dtype);
+  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_qr_factor: bad shape %lld x %lld", (long long)m,
+              (long long)n);
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(A && R && workspace, TTR_E_INVALID, "ttr_qr_factor: null pointer");
+  return qr_factor_dispatch(dtype, m, n, batch, A, lda, strideA, R, ldr, strideR, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+int ttr_qr_apply(int dtype, int64_t m, int64_t n, int64_t batch, void* workspace, int64_t workspace_bytes,
+                 const void* C, int64_t ldc, int64_t strideC, int64_t kcols, void* Out, int64_t ldo, int64_t strideO,
+                 void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_apply: bad dtype %d", dtype);
+  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0 && kcols >= 1, TTR_E_INVALID, "ttr_qr_apply: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Out && workspace, TTR_E_INVALID, "ttr_qr_apply: null pointer");
+  TTR_REQUIRE(kcols <= (m < n ? m : n), TTR_E_INVALID, "ttr_qr_apply: kcols %lld > min(m, n)", (long long)kcols);
+  return qr_apply_dispatch(dtype, m, n, batch, workspace, workspace_bytes, C, ldc, strideC, kcols, Out, ldo, strideO,
+                           (hipStream_t)stream);
+}
+
 int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
            int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* workspace,
            int64_t workspace_bytes, void* stream) {
-  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr: bad dtype %d", dtype);
-  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_qr: bad shape %lld x %lld", (long long)m, (long long)n);
-  if (batch == 0) return TTR_OK;
-  TTR_REQUIRE(A && Q && R && workspace, TTR_E_INVALID, "ttr_qr: null pointer");
-  return qr_dispatch(dtype, m, n, batch, A, lda, strideA, Q, ldq, strideQ, R, ldr, strideR, workspace, workspace_bytes,
-                     (hipStream_t)stream);
+  TTR_REQUIRE(Q != nullptr || batch == 0, TTR_E_INVALID, "ttr_qr: null pointer");
+  int rc = ttr_qr_factor(dtype, m, n, batch, A, lda, strideA, R, ldr, strideR, workspace, workspace_bytes, stream);
+  if (rc != TTR_OK || batch == 0) return rc;
+  return ttr_qr_apply(dtype, m, n, batch, workspace, workspace_bytes, nullptr, 0, 0, m < n ? m : n, Q, ldq, strideQ,
+                      stream);
 }
 
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return eigh_workspace_bytes(dtype, n, batch); }

@@ -2,89 +2,66 @@
 //
 //   A[b] (m x n) = Q[b] (m x k) R[b] (k x n),  k = min(m, n),  n <= 64
 //
-// The left unfolding of a TT core is (R*I) x R -- thousands of rows, a few dozen
-// columns -- and, in the main use of rounding (a+b, a*b), exactly rank deficient.
-// Gram-based orthogonalisation (CholeskyQR) breaks down on such inputs, so this is a
-// true Householder QR (LAPACK geqrf/orgqr conventions), organised as a
-// communication-avoiding TSQR:
+// The left unfolding of a TT core is (R*I) x R -- thousands of rows, a few dozen columns -- and, in
+// the main use of rounding (a+b, a*b), exactly rank deficient.  Gram-based orthogonalisation
+// (CholeskyQR) breaks down on such inputs, so this is a true Householder QR (LAPACK geqrf/orgqr
+// conventions), organised as a communication-avoiding TSQR whose blocks are factored with the
+// blocked compact-WY algorithm on the matrix cores:
 //
-//   factor:  the rows are cut into blocks of <= 256 rows; one workgroup factors one
-//            block.  The block lives in REGISTERS: thread (seg, c) owns NC rows of
-//            column c, so the reflector dot products v^T a_c and the rank-1 updates
-//            are thread-local FMA chains, the column norm is one wave reduction, and
-//            LDS only carries the current reflector (256 values) and the per-segment
-//            partial dots.  The reflector is streamed to HBM transposed (Vt[j][row],
-//            one coalesced 1 KiB store per step); the block's R (n x n) goes to the
-//            stacked matrix of the next tree level.
-//   tree:    the stacked R factors (n rows per block) are factored again by the same
-//            kernel until one block is left; its R is the result.
-//   apply:   Q is formed top-down: the top block applies its reflectors to [I; 0],
-//            every lower block to [T_b; 0] where T_b is its n x k slice of the level
-//            above.  Again thread (seg, c) owns a column segment in registers.
+//   block    256 rows x (16*NT) columns, one workgroup (4 wave64).  The block lives in REGISTERS as
+//            MFMA accumulator tiles: wave w owns rows 64w..64w+63 = 4 row tiles x NT column tiles of
+//            16x16 (v_mfma_*_16x16x4 C/D layout), 64 VGPRs for fp32.
+//   panel    16 columns at a time.  Inside a panel the 16 Householder steps are sequential but
+//            light: thread (segment, c) holds 16 rows of column c, so v^T a_c and the rank-1 update
+//            are 16 FMAs; the column norm is one redundant wave reduction; LDS carries the current
+//            column / reflector (256 values) and 16x16 partial dots.
+//   block    after a panel: S = V^T V (MFMA), the 16x16 triangular factor T (larft recurrence), then
+//   update   the trailing tiles get  A2 <- (I - V T^T V^T) A2  as three MFMA GEMMs
+//            W = V^T A2 (the accumulator registers ARE the B operand: K-step s of a row tile is
+//            register s of every lane group), W2 = -T^T W, A2 += V W2 -- no LDS traffic for A2.
+//   tree     the R factors (n rows per block) are stacked and factored again by the same kernel
+//            until one block is left; its R is the result.
+//   apply    Q (or Q [C;0], the fused "push-left" of round_tt) is formed top-down, one block per
+//            workgroup, entirely on MFMA: per panel (last to first) W = V^T C, W2 = -T W,
+//            C += V W2.  No sequential Householder steps at all.
 //
-// HBM traffic per level-0 block: read 256*n, write 256*n (Vt), read Vt + write Q in
-// apply: 4 * 256 * n * s bytes; the tree levels add a geometric 1/3 on top.
+// Reflectors are stored explicitly (unit diagonal, zeros above) and transposed, Vt[j][row], so a
+// Householder step emits one coalesced 1 KiB store; T factors (16x16 per panel) sit next to them.
 #include "ttr_common.h"
 
 namespace ttr {
 
-constexpr int BR = 256;  // rows per block (= threads: thread t also acts as "row t")
+constexpr int BR = 256;   // rows per block (= threads: thread t also acts as "row t")
+constexpr int PW = 16;    // panel width = MFMA tile edge
+constexpr int VLD = 17;   // leading dimension of 16-column LDS panels (conflict-free column walks)
 
 template <typename T>
 struct QrLevel {
-  // input matrix of this level
-  const T* X;
+  const T* X;          // input matrix of this level
   int64_t ldx, strideX;
-  int64_t m;   // rows
-  int n;       // cols
-  int nb;      // row blocks (evenly split)
-  T* Vt;       // [batch][nb][n][BR] reflectors, transposed, explicit (1 on the diagonal, 0 above)
-  T* tau;      // [batch][nb][n]
-  T* Rout;     // where the block's R goes: next level's X (row block b*n) or the user's R
+  int64_t m;           // rows
+  int n;               // cols (<= 16*NT)
+  int nb;              // row blocks (evenly split)
+  T* Vt;               // [batch][nb][16*NT][BR] explicit reflectors, transposed
+  T* tau;              // [batch][nb][16*NT]
+  T* Tg;               // [batch][nb][NT][16][16] compact-WY triangular factors
+  T* Rout;             // the block's R: next level's X (row block b*n) or the user's R
   int64_t ldr, strideR;
-  int top;     // 1: single block, writes k x n to the user's R
+  int top;             // 1: single block, writes k x n to the user's R
 };
 
-// 16-byte LDS reads of the (wave-uniform) reflector: 4 floats / 2 doubles per ds_read_b128.
-template <typename T>
-struct Vec16;
-template <>
-struct Vec16<float> {
-  static constexpr int N = 4;
-  typedef float type __attribute__((ext_vector_type(4)));
-};
-template <>
-struct Vec16<double> {
-  static constexpr int N = 2;
-  typedef double type __attribute__((ext_vector_type(2)));
-};
-
-// w = sum_r v[r] * a[r] over a thread's NC-row column segment; v is read from LDS in 16-byte pieces,
-// four independent accumulators break the FMA dependency chain.
-template <typename T, int NC>
-__device__ __forceinline__ T seg_dot(const T* __restrict__ v, const T (&a)[NC]) {
-  using V = typename Vec16<T>::type;
-  constexpr int VN = Vec16<T>::N;
-  T acc[4] = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-  for (int q = 0; q < NC / VN; ++q) {
-    const V x = *reinterpret_cast<const V*>(v + q * VN);
-#pragma unroll
-    for (int e = 0; e < VN; ++e) acc[(q * VN + e) & 3] += x[e] * a[q * VN + e];
-  }
-  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+// beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
+// fp32 uses the 1-ulp hardware sqrt / reciprocal: a Householder step sits on a serial latency chain and the
+// IEEE division / sqrt expansions are ~40 dependent instructions; H = I - tau v v^T stays orthogonal to O(eps).
+__device__ __forceinline__ void larfg_scalars(float alpha, float ss, float& beta, float& tj, float& scale) {
+  beta = -copysignf(__builtin_amdgcn_sqrtf(alpha * alpha + ss), alpha);
+  tj = (beta - alpha) * __builtin_amdgcn_rcpf(beta);
+  scale = __builtin_amdgcn_rcpf(alpha - beta);
 }
-
-template <typename T, int NC>
-__device__ __forceinline__ void seg_axpy(const T* __restrict__ v, T f, T (&a)[NC]) {
-  using V = typename Vec16<T>::type;
-  constexpr int VN = Vec16<T>::N;
-#pragma unroll
-  for (int q = 0; q < NC / VN; ++q) {
-    const V x = *reinterpret_cast<const V*>(v + q * VN);
-#pragma unroll
-    for (int e = 0; e < VN; ++e) a[q * VN + e] -= f * x[e];
-  }
+__device__ __forceinline__ void larfg_scalars(double alpha, double ss, double& beta, double& tj, double& scale) {
+  beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+  tj = (beta - alpha) / beta;
+  scale = 1.0 / (alpha - beta);
 }
 
 __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& row0, int& rows) {
@@ -94,15 +71,23 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 }
 
 // ---------------------------------------------------------------- factor
-template <typename T, int NC>
-__global__ __launch_bounds__(kThreads) void qr_factor_kernel(QrLevel<T> p) {
-  constexpr int SEGS = kThreads / NC;  // row segments; each owns NC rows (SEGS * NC == BR)
-  __shared__ __attribute__((aligned(16))) T xbuf[BR];          // current column (as stored)
-  __shared__ __attribute__((aligned(16))) T vbuf[BR];          // current reflector (explicit)
-  __shared__ __attribute__((aligned(16))) T wpart[SEGS][NC];   // per-segment partial dots
-  __shared__ T rdiag[NC];                                      // beta_j = R[j][j]
+template <typename T, int NT>
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_kernel(QrLevel<T> p) {
+  using M = Mfma<T>;
+  using Acc = typename M::Acc;
+  constexpr int NP = PW * NT;  // padded column count
+  __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];       // current panel's reflectors [row][j]
+  __shared__ __attribute__((aligned(16))) T xbuf[2][BR];        // current / next column (double buffered)
+  __shared__ T wpart[2][4][PW];                                 // per-wave partials: x_tail^T a_c and a_c[jj]
+  __shared__ T rdiag[NP], taus[NP];
+  __shared__ T Ts[PW * VLD], Ss[PW * VLD];
+  __shared__ T Wp[4][PW][NP];                                   // per-wave partial W (also S partials)
+  __shared__ T W2s[PW][NP + 1];
+
   const int tid = threadIdx.x;
-  const int c = tid % NC, seg = tid / NC;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cl = lane & 15, g = lane >> 4;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;  // provably wave-uniform
   const int b = blockIdx.x;
   const int64_t bt = blockIdx.y;
   int64_t row0;
@@ -110,113 +95,268 @@ __global__ __launch_bounds__(kThreads) void qr_factor_kernel(QrLevel<T> p) {
   block_rows(p.m, p.nb, b, row0, rows);
   const int n = p.n;
   const int kb = rows < n ? rows : n;
+  auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
   const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
-  T a[NC];
+  Acc acc[4][NT];
 #pragma unroll
-  for (int r = 0; r < NC; ++r) {
-    const int rg = seg * NC + r;
-    a[r] = (rg < rows && c < n) ? X[(int64_t)rg * p.ldx + c] : T(0);
-  }
-  T* __restrict__ Vt = p.Vt + ((bt * p.nb + b) * (int64_t)n) * BR;
-  T* __restrict__ tau = p.tau + (bt * p.nb + b) * (int64_t)n;
-  if (tid < NC) rdiag[tid] = T(0);
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowl(tm, r), col = tn * PW + cl;
+        acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
+      }
+  const int64_t blk = bt * p.nb + b;
+  T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
+  T* __restrict__ tau = p.tau + blk * (int64_t)NP;
+  T* __restrict__ Tg = p.Tg + blk * (int64_t)NT * PW * PW;
+  if (tid < NP) { rdiag[tid] = T(0); taus[tid] = T(0); }
 
-  for (int j = 0; j < kb; ++j) {
-    // (1) the owner of column j publishes it (16-byte LDS stores, one lane per segment)
-    if (c == j) {
-      using V = typename Vec16<T>::type;
-      constexpr int VN = Vec16<T>::N;
 #pragma unroll
-      for (int q = 0; q < NC / VN; ++q) {
-        V x;
+  for (int pnl = 0; pnl < NT; ++pnl) {
+    const int j0 = pnl * PW;
+    int nsteps = kb - j0;
+    nsteps = nsteps < 0 ? 0 : (nsteps > PW ? PW : nsteps);
+    if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
+      __syncthreads();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
-        for (int e = 0; e < VN; ++e) x[e] = a[q * VN + e];
-        *reinterpret_cast<V*>(&xbuf[seg * NC + q * VN]) = x;
+      for (int j = 0; j < PW; ++j) Vs[tid * VLD + j] = T(0);
+    }
+    // Panel steps.  With x the current column (rows >= jj), beta = -sign(x_jj)||x||, scale = 1/(x_jj - beta)
+    // the reflector is v = [1; x_tail*scale], so  v^T a_c = a_c[jj] + scale * (x_tail^T a_c,tail):  the
+    // column norm and every reflector dot product are the SAME partial-dot pass against the raw column.
+    // Two barriers per step, no wave reduction; the next column is published by its owner while it is
+    // being updated (double-buffered xbuf).
+    // Row classes (jj < 64, so only wave 0 ever holds rows <= jj): for wave 0, row tiles tm < pnl lie
+    // entirely above the diagonal (no contribution), tile tm == pnl straddles it (masked), tiles
+    // tm > pnl and all tiles of waves 1..3 are pure tail (no masks, one FMA per element).
+    int cur = 0;
+    if (nsteps > 0 && cl == 0) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xbuf[0][rowl(tm, r)] = acc[tm][pnl][r];
+    }
+    for (int j = 0; j < nsteps; ++j) {
+      const int jj = j0 + j;
+      __syncthreads();  // B1: column jj is in xbuf[cur]
+      const bool incol = (cl >= j) && (j0 + cl < n);
+      T xv[16];
+      T pd = 0, pa = 0;
+      if (incol) {
+        if (wave0) {
+#pragma unroll
+          for (int tm = pnl; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = rowl(tm, r);
+              const T x = xbuf[cur][row];
+              const T a = acc[tm][pnl][r];
+              if (tm == pnl) {
+                xv[tm * 4 + r] = (row > jj) ? x : T(0);
+                pa += (row == jj) ? a : T(0);
+              } else {
+                xv[tm * 4 + r] = x;
+              }
+              pd += xv[tm * 4 + r] * a;
+            }
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              xv[tm * 4 + r] = xbuf[cur][rowl(tm, r)];
+              pd += xv[tm * 4 + r] * acc[tm][pnl][r];
+            }
+        }
+      }
+      // pre-reduce over the wave's 4 lane groups (same column, rows 4g.. of every tile)
+      pd += __shfl_xor(pd, 16, 64); pd += __shfl_xor(pd, 32, 64);
+      pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
+      if (g == 0) { wpart[0][wave][cl] = pd; wpart[1][wave][cl] = pa; }
+      __syncthreads();  // B2: partial dots visible
+      const T ss = (wpart[0][0][j] + wpart[0][1][j]) + (wpart[0][2][j] + wpart[0][3][j]);  // ||x_tail||^2
+      const T alpha = xbuf[cur][jj];
+      T beta, tj, scale;
+      if (ss == T(0)) {  // LAPACK larfg: H = I
+        beta = alpha; tj = T(0); scale = T(0);
+      } else {
+        larfg_scalars(alpha, ss, beta, tj, scale);
+      }
+      {
+        const T xt = xbuf[cur][tid];
+        const T vt = (tid > jj) ? xt * scale : (tid == jj ? T(1) : T(0));
+        Vs[tid * VLD + j] = vt;
+        Vt[(int64_t)jj * BR + tid] = vt;  // coalesced, fire and forget
+        if (tid == 0) { tau[jj] = tj; taus[jj] = tj; rdiag[jj] = beta; }
+      }
+      if (incol && cl > j) {
+        const T dot = (wpart[0][0][cl] + wpart[0][1][cl]) + (wpart[0][2][cl] + wpart[0][3][cl]);
+        const T ajj = (wpart[1][0][cl] + wpart[1][1][cl]) + (wpart[1][2][cl] + wpart[1][3][cl]);
+        const T f = tj * (ajj + scale * dot);
+        const T fs = f * scale;
+        const bool publish = (cl == j + 1) && (j + 1 < nsteps);
+        if (wave0) {
+#pragma unroll
+          for (int tm = pnl; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (tm == pnl) {
+                const int row = rowl(tm, r);
+                acc[tm][pnl][r] -= (row == jj) ? f : fs * xv[tm * 4 + r];  // xv is 0 for rows <= jj
+              } else {
+                acc[tm][pnl][r] -= fs * xv[tm * 4 + r];
+              }
+            }
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][pnl][r] -= fs * xv[tm * 4 + r];
+        }
+        if (publish) {
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xbuf[cur ^ 1][rowl(tm, r)] = acc[tm][pnl][r];
+        }
+      }
+      cur ^= 1;
+    }
+    for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
+      Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
+      if (tid == 0) tau[j0 + j] = T(0);
+    }
+    __syncthreads();
+    // (5) S = V^T V over the block (MFMA, K = 256 split over the 4 waves), then the triangular factor T
+    {
+      Acc s = M::zero();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const T a = Vs[(wave * 64 + ks * 4 + g) * VLD + cl];
+        s = M::mma(a, a, s);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][cl] = s[r];
+    }
+    __syncthreads();
+    {
+      const int i = tid >> 4, k = tid & 15;
+      Ss[i * VLD + k] = (Wp[0][i][k] + Wp[1][i][k]) + (Wp[2][i][k] + Wp[3][i][k]);
+    }
+    __syncthreads();
+    if (tid < PW) {  // larft (forward, columnwise): T[0:j,j] = -tau_j T[0:j,0:j] S[0:j,j], T[j][j] = tau_j
+      const int i = tid;
+      T trow[PW];
+#pragma unroll
+      for (int jc = 0; jc < PW; ++jc) {
+        T a2 = 0;
+#pragma unroll
+        for (int k = 0; k < jc; ++k) a2 += (k >= i ? trow[k] : T(0)) * Ss[k * VLD + jc];
+        const T tj = taus[j0 + jc];
+        trow[jc] = (i < jc) ? -tj * a2 : (i == jc ? tj : T(0));
+        Ts[i * VLD + jc] = trow[jc];
+        Tg[pnl * PW * PW + i * PW + jc] = trow[jc];
       }
     }
     __syncthreads();
-    // (2) every wave reduces the whole column redundantly: no cross-wave step
-    T ss = 0;
+    if (pnl < NT - 1 && (pnl + 1) * PW < n) {
+      // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand
 #pragma unroll
-    for (int q = 0; q < BR / kWave; ++q) {
-      const int rg = (tid & 63) + q * kWave;
-      const T x = xbuf[rg];
-      ss += (rg > j) ? x * x : T(0);
-    }
-    ss = wave_sum(ss);
-    const T alpha = xbuf[j];
-    const T xt = xbuf[tid];
-    T beta, tj, scale;
-    if (ss == T(0)) {  // LAPACK larfg: H = I
-      beta = alpha; tj = T(0); scale = T(0);
-    } else {
-      beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-      tj = (beta - alpha) / beta;
-      scale = T(1) / (alpha - beta);
-    }
-    const T vt = (tid > j) ? xt * scale : (tid == j ? T(1) : T(0));
-    vbuf[tid] = vt;
-    Vt[(int64_t)j * BR + tid] = vt;  // coalesced, fire and forget
-    if (tid == 0) { tau[j] = tj; rdiag[j] = beta; }
-    __syncthreads();
-    // (3) the columns right of j take the dot product with the reflector.  The owner's registers are
-    //     left alone: rows < j of column j are final R entries, the diagonal lives in rdiag, and the
-    //     reflector itself already went to Vt.
-    const bool active = (c > j && c < n);
-    if (active) wpart[seg][c] = seg_dot<T, NC>(&vbuf[seg * NC], a);
-    __syncthreads();
-    // (4) rank-1 update of the trailing columns
-    if (active) {
-      T w = 0;
+      for (int tn = pnl + 1; tn < NT; ++tn) {
+        Acc wa = M::zero();
 #pragma unroll
-      for (int s2 = 0; s2 < SEGS; ++s2) w += wpart[s2][c];
-      seg_axpy<T, NC>(&vbuf[seg * NC], tj * w, a);
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], acc[tm][tn][s], wa);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tn * PW + cl] = wa[r];
+      }
+      __syncthreads();
+      // W2 = -T^T (sum of the partials)
+      {
+        const int jc = tid & 63, i4 = tid >> 6;
+        if (jc < NP && jc >= (pnl + 1) * PW) {
+          T ws[PW];
+#pragma unroll
+          for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const int i = i4 * 4 + ii;
+            T a2 = 0;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) a2 += Ts[k * VLD + i] * ws[k];
+            W2s[i][jc] = -a2;
+          }
+        }
+      }
+      __syncthreads();
+      // (7) A2 += V W2
+#pragma unroll
+      for (int tn = pnl + 1; tn < NT; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            acc[tm][tn] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * VLD + ks * 4 + g], W2s[ks * 4 + g][tn * PW + cl],
+                                 acc[tm][tn]);
     }
-    // next (1) writes xbuf (last read before the 2nd barrier) -> no barrier needed here;
-    // vbuf/wpart are rewritten only after the next iteration's first barrier.
+    // the next panel's first barrier orders (7)'s LDS reads before Vs / W2s are rewritten
   }
   __syncthreads();
 
-  // R: rows 0..kb-1 live in segment 0 (kb <= n <= NC)
+  // R: rows 0..63 live in wave 0
   T* __restrict__ Rout = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
   const int rrows = p.top ? kb : n;
-  if (seg == 0 && c < n) {
-    const T dg = rdiag[c];
+  if (wave == 0) {
 #pragma unroll
-    for (int r = 0; r < NC; ++r) {
-      if (r < rrows) {
-        T v = T(0);
-        if (r < kb) v = (r < c) ? a[r] : (r == c ? dg : T(0));
-        Rout[(int64_t)r * p.ldr + c] = v;
-      }
-    }
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = tm * 16 + M::row(lane, r), c = tn * PW + cl;
+          if (i < rrows && c < n) {
+            T v = T(0);
+            if (i < kb) v = (i < c) ? acc[tm][tn][r] : (i == c ? rdiag[c] : T(0));
+            Rout[(int64_t)i * p.ldr + c] = v;
+          }
+        }
   }
 }
 
-// ---------------------------------------------------------------- apply (form Q top-down)
+// ---------------------------------------------------------------- apply (form Q [C;0] top-down)
 template <typename T>
 struct QrApply {
   const T* Vt;
   const T* tau;
-  int64_t m;   // rows of this level's matrix
-  int n;       // reflector count upper bound / cols of the factored matrix
+  const T* Tg;
+  int64_t m;     // rows of this level's matrix
+  int n;         // cols of the factored matrix
   int nb;
-  int kcols;   // columns of Q being formed (k)
-  const T* Top;  // level above: (nb * n) x kcols, row block b*n ; nullptr => identity
+  int kcols;     // columns of the product being formed
+  const T* Top;  // level above: row block b*n, n x kcols ; nullptr => identity
   int64_t ldtop, strideTop;
   T* Out;
   int64_t ldout, strideOut;
 };
 
-template <typename T, int NC>
+template <typename T, int NT, int NTC>
 __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
-  constexpr int SEGS = kThreads / NC;
-  __shared__ __attribute__((aligned(16))) T vbuf[3][BR];
-  __shared__ __attribute__((aligned(16))) T wpart[2][SEGS][NC];
-  __shared__ T taus[NC];
+  using M = Mfma<T>;
+  using Acc = typename M::Acc;
+  constexpr int NP = PW * NT;
+  constexpr int NC = PW * NTC;
+  __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];
+  __shared__ T Ts[PW * VLD];
+  __shared__ T Wp[4][PW][NC];
+  __shared__ T W2s[PW][NC + 1];
+
   const int tid = threadIdx.x;
-  const int c = tid % NC, seg = tid / NC;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cl = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   const int64_t bt = blockIdx.y;
   int64_t row0;
@@ -225,63 +365,120 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
   const int n = p.n;
   const int kb = rows < n ? rows : n;
   const int kc = p.kcols;
+  auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
-  const T* __restrict__ Vt = p.Vt + ((bt * p.nb + b) * (int64_t)n) * BR;
-  const T* __restrict__ tau = p.tau + (bt * p.nb + b) * (int64_t)n;
-  if (tid < n) taus[tid] = tid < kb ? tau[tid] : T(0);
+  const int64_t blk = bt * p.nb + b;
+  const T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
+  const T* __restrict__ Tg = p.Tg + blk * (int64_t)NT * PW * PW;
 
-  T a[NC];
-  if (p.Top) {
-    const T* __restrict__ Top = p.Top + bt * p.strideTop + (int64_t)b * n * p.ldtop;
+  Acc C[4][NTC];
 #pragma unroll
-    for (int r = 0; r < NC; ++r) {
-      const int rg = seg * NC + r;
-      a[r] = (rg < n && rg < rows && c < kc) ? Top[(int64_t)rg * p.ldtop + c] : T(0);
-    }
-  } else {
+  for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-    for (int r = 0; r < NC; ++r) a[r] = (seg * NC + r == c && c < kc) ? T(1) : T(0);
+    for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowl(tm, r), col = tc * PW + cl;
+        T v = T(0);
+        if (col < kc) {
+          if (p.Top) {
+            if (row < n && row < rows) v = p.Top[bt * p.strideTop + ((int64_t)b * n + row) * p.ldtop + col];
+          } else {
+            v = (row == col) ? T(1) : T(0);
+          }
+        }
+        C[tm][tc][r] = v;
+      }
+
+  const int npanels = (kb + PW - 1) / PW;
+  T vreg[PW], treg;
+  if (npanels > 0) {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
+    treg = Tg[(npanels - 1) * PW * PW + tid];
   }
-
-  // reflectors are applied last-to-first: Q [T;0] = H_0 H_1 ... H_{kb-1} [T;0]
-  T vnext = kb > 0 ? Vt[(int64_t)(kb - 1) * BR + tid] : T(0);
-  if (kb > 0) vbuf[(kb - 1) % 3][tid] = vnext;
-  __syncthreads();
-  for (int j = kb - 1; j >= 0; --j) {
-    const int cur = j % 3;
-    const int wb = j & 1;
-    if (j > 0) vnext = Vt[(int64_t)(j - 1) * BR + tid];  // prefetch, lands under the FMAs
-    wpart[wb][seg][c] = seg_dot<T, NC>(&vbuf[cur][seg * NC], a);
-    if (j > 0) vbuf[(j - 1) % 3][tid] = vnext;
-    __syncthreads();
-    T ws = 0;
+  for (int pnl = npanels - 1; pnl >= 0; --pnl) {
+    // stage the panel's reflectors ([row][j]) and its T factor; the next panel's loads fly under the MFMAs
 #pragma unroll
-    for (int s = 0; s < SEGS; ++s) ws += wpart[wb][s][c];
-    seg_axpy<T, NC>(&vbuf[cur][seg * NC], taus[j] * ws, a);
+    for (int j = 0; j < PW; ++j) Vs[tid * VLD + j] = vreg[j];
+    Ts[(tid >> 4) * VLD + (tid & 15)] = treg;
+    if (pnl > 0) {
+#pragma unroll
+      for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((pnl - 1) * PW + j) * BR + tid];
+      treg = Tg[(pnl - 1) * PW * PW + tid];
+    }
+    __syncthreads();
+    // W = V^T C (per-wave partial over its 64 rows)
+#pragma unroll
+    for (int tc = 0; tc < NTC; ++tc) {
+      Acc wa = M::zero();
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], C[tm][tc][s], wa);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tc * PW + cl] = wa[r];
+    }
+    __syncthreads();
+    // W2 = -T W
+    {
+      const int jc = tid & 63, i4 = tid >> 6;
+      if (jc < NC) {
+        T ws[PW];
+#pragma unroll
+        for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = i4 * 4 + ii;
+          T a2 = 0;
+#pragma unroll
+          for (int k = 0; k < PW; ++k) a2 += Ts[i * VLD + k] * ws[k];
+          W2s[i][jc] = -a2;
+        }
+      }
+    }
+    __syncthreads();
+    // C += V W2
+#pragma unroll
+    for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * VLD + ks * 4 + g], W2s[ks * 4 + g][tc * PW + cl],
+                             C[tm][tc]);
+    __syncthreads();  // Vs / Ts / W2s are rewritten by the next panel
   }
 
   T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
-  if (c < kc) {
 #pragma unroll
-    for (int r = 0; r < NC; ++r) {
-      const int rg = seg * NC + r;
-      if (rg < rows) Out[(int64_t)rg * p.ldout + c] = a[r];
-    }
-  }
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowl(tm, r), col = tc * PW + cl;
+        if (row < rows && col < kc) Out[(int64_t)row * p.ldout + col] = C[tm][tc][r];
+      }
 }
 
 // ---------------------------------------------------------------- host-side tree
 struct QrPlan {
   int levels;
+  int npad;  // 16 * NT
   int64_t m[16];
   int nb[16];
   // workspace offsets in elements
-  int64_t off_vt[16], off_tau[16], off_x[16], off_out[16];
+  int64_t off_vt[16], off_tau[16], off_tg[16], off_x[16], off_out[16];
   int64_t total;  // elements
 };
 
+static int nt_for(int64_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : 4); }
+
 static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   QrPlan pl{};
+  const int NT = nt_for(n);
+  pl.npad = NT * PW;
   int64_t cur = m;
   int L = 0;
   for (;;) {
@@ -294,11 +491,12 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   pl.levels = L;
   int64_t off = 0;
   for (int l = 0; l < L; ++l) {
-    pl.off_vt[l] = off; off += batch * pl.nb[l] * n * BR;
-    pl.off_tau[l] = off; off += align_up(batch * pl.nb[l] * n, 64);
+    pl.off_vt[l] = off; off += batch * pl.nb[l] * pl.npad * BR;
+    pl.off_tau[l] = off; off += align_up(batch * pl.nb[l] * pl.npad, 64);
+    pl.off_tg[l] = off; off += batch * pl.nb[l] * NT * PW * PW;
     if (l > 0) {
       pl.off_x[l] = off; off += batch * pl.m[l] * n;    // stacked R factors (input of level l)
-      pl.off_out[l] = off; off += batch * pl.m[l] * n;  // Q of level l (m_l x k)
+      pl.off_out[l] = off; off += batch * pl.m[l] * n;  // Q slab of level l (m_l x kcols, kcols <= n)
     }
   }
   pl.total = off;
@@ -310,12 +508,10 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   return make_plan(m, n, batch).total * (dtype == TTR_F64 ? 8 : 4);
 }
 
-template <typename T, int NC>
-static int qr_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* Q, int64_t ldq,
-                  int64_t strideQ, T* R, int64_t ldr, int64_t strideR, T* ws, const QrPlan& pl, hipStream_t stream) {
+template <typename T, int NT>
+static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* R, int64_t ldr,
+                      int64_t strideR, T* ws, const QrPlan& pl, hipStream_t stream) {
   const int L = pl.levels;
-  const int k = (int)(m < n ? m : n);
-  // ---- factor, bottom-up
   for (int l = 0; l < L; ++l) {
     QrLevel<T> p;
     p.X = l == 0 ? A : ws + pl.off_x[l];
@@ -324,56 +520,94 @@ static int qr_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int6
     p.m = pl.m[l]; p.n = n; p.nb = pl.nb[l];
     p.Vt = ws + pl.off_vt[l];
     p.tau = ws + pl.off_tau[l];
+    p.Tg = ws + pl.off_tg[l];
     p.top = (l == L - 1);
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-    hipLaunchKernelGGL((qr_factor_kernel<T, NC>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
+    hipLaunchKernelGGL((qr_factor_kernel<T, NT>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
   }
-  // ---- form Q, top-down
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+template <typename T, int NT, int NTC>
+static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const QrPlan& pl, const T* C, int64_t ldc,
+                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
+  const int L = pl.levels;
   for (int l = L - 1; l >= 0; --l) {
     QrApply<T> p;
     p.Vt = ws + pl.off_vt[l];
     p.tau = ws + pl.off_tau[l];
-    p.m = pl.m[l]; p.n = n; p.nb = pl.nb[l]; p.kcols = k;
-    if (l == L - 1) { p.Top = nullptr; p.ldtop = 0; p.strideTop = 0; }
-    else { p.Top = ws + pl.off_out[l + 1]; p.ldtop = k; p.strideTop = pl.m[l + 1] * n; }
-    if (l == 0) { p.Out = Q; p.ldout = ldq; p.strideOut = strideQ; }
-    else { p.Out = ws + pl.off_out[l]; p.ldout = k; p.strideOut = pl.m[l] * n; }
+    p.Tg = ws + pl.off_tg[l];
+    p.m = pl.m[l]; p.n = n; p.nb = pl.nb[l]; p.kcols = kc;
+    if (l == L - 1) { p.Top = C; p.ldtop = ldc; p.strideTop = strideC; }  // C == nullptr: identity
+    else { p.Top = ws + pl.off_out[l + 1]; p.ldtop = kc; p.strideTop = pl.m[l + 1] * n; }
+    if (l == 0) { p.Out = Out; p.ldout = ldo; p.strideOut = strideO; }
+    else { p.Out = wsw + pl.off_out[l]; p.ldout = kc; p.strideOut = pl.m[l] * n; }
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
-    hipLaunchKernelGGL((qr_apply_kernel<T, NC>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
+    hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0,
+                       stream, p);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
 
 template <typename T>
-static int qr_typed(int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
-                    int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes,
-                    hipStream_t stream) {
+static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
+                        int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const QrPlan pl = make_plan(m, n, batch);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
   TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_qr: batch %lld > 65535", (long long)batch);
-#define TTR_QR_CASE(NCV)                                                                                          \
-  return qr_run<T, NCV>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)Q, ldq, strideQ, (T*)R, ldr, strideR, \
-                        (T*)ws, pl, stream)
-  if (n <= 16) TTR_QR_CASE(16);
-  if (n <= 32) TTR_QR_CASE(32);
-  TTR_QR_CASE(64);
-#undef TTR_QR_CASE
+  switch (nt_for(n)) {
+    case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
+    case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
+    default: return factor_run<T, 4>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
+  }
+}
+
+template <typename T, int NT>
+static int apply_nt(int64_t m, int n, int64_t batch, T* ws, const QrPlan& pl, const T* C, int64_t ldc, int64_t strideC,
+                    int kc, T* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
+  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+}
+
+template <typename T>
+static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
+                       int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
+  const QrPlan pl = make_plan(m, n, batch);
+  TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr_apply: workspace %lld < %lld bytes",
+              (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
+  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_qr_apply: batch %lld > 65535", (long long)batch);
+  TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
+              (long long)kc);
+  switch (nt_for(n)) {
+    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
+    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
+    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
+  }
 }
 
 int qr_max_cols(int) { return 64; }
 
-int qr_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* Q,
-                int64_t ldq, int64_t strideQ, void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes,
-                hipStream_t stream) {
+int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  if (dtype == TTR_F32)
-    return qr_typed<float>(m, n, batch, A, lda, strideA, Q, ldq, strideQ, R, ldr, strideR, ws, ws_bytes, stream);
-  return qr_typed<double>(m, n, batch, A, lda, strideA, Q, ldq, strideQ, R, ldr, strideR, ws, ws_bytes, stream);
+  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, stream);
+  return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, stream);
+}
+
+int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
+                      int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
+                      hipStream_t stream) {
+  TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr_apply: n = %lld exceeds the %d-column panel kernel",
+              (long long)n, qr_max_cols(dtype));
+  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, stream);
 }
 
 }  // namespace ttr

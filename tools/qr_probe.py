@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tntorch_amd import _hip
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+torch.manual_seed(0)
+A = torch.randn(B, 4096, 64, device="cuda")
+for _ in range(2):
+    f = _hip.qr_factor(A)
+    Q = _hip.qr_apply(f)
+    Q2 = _hip.qr_apply(f, torch.randn(B, 64, 32, device="cuda"))
+torch.cuda.synchronize()
