@@ -73,36 +73,56 @@ def algorithmic_bytes_per_tensor():
             "total": l2r_read + l2r_write + r2l + last}
 
 
-def cpu_baseline(sample_eig=8, sample_svd=2):
-    """Time the CPU oracle (restatement of the reference, same LAPACK calls) on a bounded sample."""
+def cpu_baseline(budget_s=25.0):
+    """Time the CPU oracle (restatement of the reference, same LAPACK calls) on a bounded sample.
+
+    The reference's small-matrix LAPACK calls do not scale with threads (128 MKL threads are ~40x SLOWER
+    than 8 on this workload), so a few thread counts are tried and the FASTEST is reported: the baseline
+    is the best the CPU path can do on this box, not a strawman.
+    """
     import oracle
 
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
     g = oracle.tt_randn([MODE] * N_CORES, R_OUT, dtype=torch.float32)
     inp = oracle.tt_add(g, g)
-    out = {}
-    for alg, reps in (("eig", sample_eig), ("svd", sample_svd)):
-        oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)  # warm-up (MKL init)
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)
-            ts.append(time.perf_counter() - t0)
-        ts.sort()
-        out[alg] = ts[len(ts) // 2]
+    ncpu = os.cpu_count() or 8
+    cands = sorted({t for t in (4, 8, 16, 32, ncpu) if t <= ncpu})
+    saved = torch.get_num_threads()
+    t_start = time.perf_counter()
+    best = {}
+    trials = {}
+    for alg in ("eig", "svd"):
+        for nt in cands:
+            if time.perf_counter() - t_start > budget_s:
+                break
+            torch.set_num_threads(nt)
+            oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)  # warm-up (MKL init / thread pool)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                oracle.round_tt(inp, rmax=R_OUT, algorithm=alg)
+                ts.append(time.perf_counter() - t0)
+                if ts[-1] > 1.5:
+                    break
+            med = sorted(ts)[len(ts) // 2]
+            trials[f"{alg}@{nt}"] = med
+            if alg not in best or med < best[alg][0]:
+                best[alg] = (med, nt)
+    torch.set_num_threads(saved)
+    fast_alg = min(best, key=lambda a: best[a][0])
+    sec, nt = best[fast_alg]
     return {
-        "value": N_CORES / out["eig"],
+        "value": N_CORES / sec,
         "unit": "cores/s",
-        "cores": threads,
+        "cores": nt,
         "kind": "port",
-        "sample": f"oracle.round_tt(rmax=32) of ONE 64^8 rank-64 float32 TT, median of {sample_eig} runs, "
-                  f"algorithm='eig' (the faster reference algorithm); the reference default 'svd' "
-                  f"(median of {sample_svd}) is reported next to it",
-        "sec_per_tensor_eig": out["eig"],
-        "sec_per_tensor_svd": out["svd"],
-        "value_svd": N_CORES / out["svd"],
-        "gflops_eig": FLOP_PER_TENSOR / out["eig"] / 1e9,
+        "sample": f"oracle.round_tt(rmax=32) of ONE 64^8 rank-64 float32 TT (the metric's unit), median of <=3 runs per "
+                  f"(algorithm, thread count) over threads {cands}; reported: fastest = algorithm='{fast_alg}' at {nt} threads",
+        "algorithm": fast_alg,
+        "sec_per_tensor": {a: best[a][0] for a in best},
+        "threads": {a: best[a][1] for a in best},
+        "trials_sec": trials,
+        "gflops": FLOP_PER_TENSOR / sec / 1e9,
     }
 
 
@@ -111,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="tensors per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="tensors per GPU per step")
     ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -235,7 +255,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             res["cpu_baseline"] = cb
-            res["speedup_vs_cpu_eig"] = cores_per_s / cb["value"]
+            res["speedup_vs_cpu_best"] = cores_per_s / cb["value"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

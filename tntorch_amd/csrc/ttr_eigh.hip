@@ -6,8 +6,9 @@
 // bank-conflict free) when they fit, otherwise in a caller workspace that stays
 // L2-resident.  A round rotates n/2 disjoint (p,q) pairs (round-robin tournament):
 //   phase 1  one thread per pair computes (c, s) from G_pp, G_qq, G_pq
-//   phase 2  columns p,q of G and V are rotated (lanes walk the rows)
-//   phase 3  rows p,q of G are rotated (lanes walk the columns)
+//   phase 2  G <- J^T G J block-wise: one thread owns the 2x2 block (row pair, column pair) and applies
+//            both rotations in place; V <- V J column-wise in the same barrier interval
+// (two barriers per round)
 // The rotation parameters and the accumulated eigenvector matrix V are kept in DOUBLE for
 // either input type: ~500 rotations touch every entry of V, and float accumulation leaves
 // V^T V = I + O(1e-6), which shows up one-to-one as reconstruction error of the
@@ -46,6 +47,34 @@ struct EighArgs {
 };
 
 constexpr int kMaxPairs = 512;  // n <= 1024 in the global-memory variant
+
+template <typename T>
+__host__ __device__ constexpr size_t rot_table_bytes(int npad) {
+  return (size_t)npad * (2 * sizeof(double) + 4 * sizeof(int) + 2 * sizeof(T));
+}
+
+// Jacobi rotation that annihilates G_pq.  Computed in the matrix precision with the fast hardware
+// reciprocal / rsqrt (the angle only has to be accurate enough for convergence), then (c, s) is pulled back
+// onto the unit circle in double with one Newton step so that the accumulated V stays orthogonal.
+__device__ __forceinline__ void jacobi_cs(float app, float aqq, float apq, double& c, double& s) {
+  const float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.0f * apq);
+  float t;
+  if (fabsf(theta) > 1e18f) t = 0.5f * __builtin_amdgcn_rcpf(theta);
+  else t = copysignf(1.0f, theta) * __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(1.0f + theta * theta));
+  const float cf = __builtin_amdgcn_rsqf(1.0f + t * t);
+  const double cd = (double)cf, sd = (double)(t * cf);
+  const double corr = 1.5 - 0.5 * (cd * cd + sd * sd);
+  c = cd * corr;
+  s = sd * corr;
+}
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+  const double theta = (aqq - app) / (2.0 * apq);
+  double t;
+  if (fabs(theta) > 1e150) t = 0.5 / theta;
+  else t = copysign(1.0, theta) / (fabs(theta) + sqrt(1.0 + theta * theta));
+  c = 1.0 / sqrt(1.0 + t * t);
+  s = t * c;
+}
 constexpr int UNR = 8;          // rotation items batched per thread (n = 64: exactly one batch per phase)
 
 template <typename T, bool LDSRES>
@@ -58,13 +87,20 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int ne = n + (n & 1);  // even number of players (phantom index n if n is odd)
   const int np = ne / 2;
 
-  // carve the dynamic LDS
-  double* cs_c = reinterpret_cast<double*>(smem_raw);  // [np]
-  double* cs_s = cs_c + kMaxPairs;                     // [np]
-  int* pq_p = reinterpret_cast<int*>(cs_s + kMaxPairs);
-  int* pq_q = pq_p + kMaxPairs;
-  int* flags = pq_q + kMaxPairs;                     // [0]: rotated-this-sweep
-  T* sg = reinterpret_cast<T*>(flags + 16);          // sigma / ordering scratch [2 * n]
+  // carve the dynamic LDS: rotation table, sigma scratch, then G / V.
+  const int npad = (np + 7) & ~7;
+  unsigned char* tab = smem_raw;  // one table shared by the workgroup
+  double* cs_c = reinterpret_cast<double*>(tab);           // [npad]
+  double* cs_s = cs_c + npad;
+  int* pq_p = reinterpret_cast<int*>(cs_s + npad);
+  int* pq_q = pq_p + npad;
+  int* prow = pq_q + npad;                                 // p * ld, q * ld (row offsets of the pair)
+  int* qrow = prow + npad;
+  T* ct = reinterpret_cast<T*>(qrow + npad);               // (c, s) once more in the matrix type
+  T* st = ct + npad;
+  unsigned char* after = smem_raw + rot_table_bytes<T>(npad);
+  int* flags = reinterpret_cast<int*>(after);              // [0]: rotated-this-sweep
+  T* sg = reinterpret_cast<T*>(flags + 16);                // sigma / ordering scratch [2 * n]
   T* Gs;
   double* Vs;
   if (LDSRES) {
@@ -97,12 +133,17 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int m1 = ne - 1;
   const int k0 = tid / n, i0 = tid % n;            // item = tid + 256*e  <->  (k, i), advanced incrementally
   const int dk = kThreads / n, di = kThreads % n;
+  // 2x2-block phase mapping: sub-groups of cw lanes <-> column pairs, (wave, sub-group) <-> row pairs
+  const int cw = np <= 32 ? 32 : 64;
+  const int kc_l = (tid & 63) & (cw - 1);
+  const int krs = 4 * (64 / cw);                       // row-pair stride between a thread's blocks
+  const int kr0 = (tid >> 6) * (64 / cw) + (tid & 63) / cw;
 
   int sweeps_used = 0;
   for (int sweep = 0; sweep < p.max_sweeps && n > 1; ++sweep) {
     sweeps_used = sweep + 1;
     for (int r = 0; r < m1; ++r) {
-      // ---- phase 1: rotations of this round
+      // ---- phase 1: rotations of this round (one thread per pair)
       for (int k = tid; k < np; k += kThreads) {
         int pp, qq;
         if (k == 0) { pp = ne - 1; qq = r % m1; }
@@ -112,27 +153,61 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           const T app = Gs[pp * ld + pp], aqq = Gs[qq * ld + qq], apq = Gs[pp * ld + qq];
           const T aabs = fabs(apq);
           if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs) {  // no overflow of app*aqq
-            const double theta = ((double)aqq - (double)app) / (2.0 * (double)apq);
-            double t;
-            if (fabs(theta) > 1e150) t = 0.5 / theta;
-            else t = copysign(1.0, theta) / (fabs(theta) + sqrt(1.0 + theta * theta));
-            c = 1.0 / sqrt(1.0 + t * t);
-            s = t * c;
+            jacobi_cs(app, aqq, apq, c, s);
             flags[0] = 1;
           }
         }
-        // phantom indices (n odd) carry s = 0 and are clamped so that the batched loads stay in bounds
-        cs_c[k] = c; cs_s[k] = s; pq_p[k] = pp < n ? pp : 0; pq_q[k] = qq < n ? qq : 0;
+        // n odd: the player paired with the phantom index sits this round out.  Its pair is stored as
+        // (real, real) with the identity rotation: the 2x2-block update then still applies the COLUMN
+        // rotations to that row (both block rows alias the same row and receive the same value).
+        if (pp >= n) pp = qq;
+        if (qq >= n) qq = pp;
+        cs_c[k] = c; cs_s[k] = s; ct[k] = (T)c; st[k] = (T)s; pq_p[k] = pp; pq_q[k] = qq;
+        prow[k] = pp * ld; qrow[k] = qq * ld;
       }
       __syncthreads();
-      // ---- phase 2: G <- G J, V <- V J  (columns p,q; lanes walk rows)
-      // Different pairs touch disjoint columns, so a thread's items are independent: all LDS loads are
-      // issued first, then the FMAs, then the stores (written as a plain loop the compiler must keep
-      // the loads behind the previous item's stores -- possible aliasing -- and every item pays a full
-      // LDS round trip).
+      // ---- phase 2: G <- J^T G J on 2x2 blocks.  Thread item = (row pair kr, column pair kc): the block
+      // G[{p,q}][{p',q'}] is read, rotated from both sides and written back by ONE thread, so the two-sided
+      // update is a single in-place pass (4 LDS reads, 16 flops, 4 writes) instead of a column pass, a
+      // barrier and a row pass.  Lanes walk the column pairs.
+      // Lane sub-groups of `cw` lanes walk the column pairs (their rotation is loaded once per round),
+      // the sub-groups / waves / iterations walk the row pairs, four blocks in flight per thread.
+      for (int kc = kc_l; kc < np; kc += cw) {
+        const T cc = ct[kc], sc = st[kc];
+        const bool onc = cs_s[kc] != 0.0;
+        const int pc = pq_p[kc], qc = pq_q[kc];
+        for (int krb = kr0; krb < np; krb += 4 * krs) {
+          T cr[4], sr[4], a[4], bq[4], c2[4], d[4];
+          int pr[4], qr[4];
+          bool on[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kr = krb + u * krs;
+            const bool in = kr < np;
+            const int kk = in ? kr : 0;
+            cr[u] = ct[kk]; sr[u] = st[kk]; pr[u] = prow[kk]; qr[u] = qrow[kk];
+            on[u] = in && (onc || cs_s[kk] != 0.0);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            a[u] = Gs[pr[u] + pc]; bq[u] = Gs[pr[u] + qc]; c2[u] = Gs[qr[u] + pc]; d[u] = Gs[qr[u] + qc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (on[u]) {
+              const T t1 = cc * a[u] - sc * bq[u], t2 = sc * a[u] + cc * bq[u];
+              const T u1 = cc * c2[u] - sc * d[u], u2 = sc * c2[u] + cc * d[u];
+              Gs[pr[u] + pc] = cr[u] * t1 - sr[u] * u1;
+              Gs[pr[u] + qc] = cr[u] * t2 - sr[u] * u2;
+              Gs[qr[u] + pc] = sr[u] * t1 + cr[u] * u1;
+              Gs[qr[u] + qc] = sr[u] * t2 + cr[u] * u2;
+            }
+          }
+        }
+      }
+      // ---- V <- V J  (columns p,q; lanes walk rows).  Independent of the G blocks: same barrier interval.
       for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
         double cd[UNR], sd[UNR], vp[UNR], vq[UNR];
-        T gp[UNR], gq[UNR];
         int pp[UNR], qq[UNR], ii[UNR];
         bool on[UNR];
         int k = kb_, i = ib_, item = base;
@@ -147,48 +222,12 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           if (i >= n) { i -= n; ++k; }
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          gp[u] = Gs[ii[u] * ld + pp[u]]; gq[u] = Gs[ii[u] * ld + qq[u]];
-          vp[u] = Vs[ii[u] * ld + pp[u]]; vq[u] = Vs[ii[u] * ld + qq[u]];
-        }
+        for (int u = 0; u < UNR; ++u) { vp[u] = Vs[ii[u] * ld + pp[u]]; vq[u] = Vs[ii[u] * ld + qq[u]]; }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           if (on[u]) {
-            const T c = (T)cd[u], sn = (T)sd[u];
-            Gs[ii[u] * ld + pp[u]] = c * gp[u] - sn * gq[u];
-            Gs[ii[u] * ld + qq[u]] = sn * gp[u] + c * gq[u];
             Vs[ii[u] * ld + pp[u]] = cd[u] * vp[u] - sd[u] * vq[u];
             Vs[ii[u] * ld + qq[u]] = sd[u] * vp[u] + cd[u] * vq[u];
-          }
-        }
-        base = item; kb_ = k; ib_ = i;
-      }
-      __syncthreads();
-      // ---- phase 3: G <- J^T G  (rows p,q; lanes walk columns); same load / compute / store batching
-      for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
-        double sd[UNR];
-        T c[UNR], gp[UNR], gq[UNR];
-        int pp[UNR], qq[UNR], ii[UNR];
-        bool on[UNR];
-        int k = kb_, i = ib_, item = base;
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          on[u] = item < np * n;
-          const int ku = on[u] ? k : 0;
-          ii[u] = on[u] ? i : 0;
-          sd[u] = cs_s[ku]; c[u] = (T)cs_c[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
-          on[u] = on[u] && (sd[u] != 0.0);  // same predicate as phase 2
-          item += kThreads; i += di; k += dk;
-          if (i >= n) { i -= n; ++k; }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) { gp[u] = Gs[pp[u] * ld + ii[u]]; gq[u] = Gs[qq[u] * ld + ii[u]]; }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          if (on[u]) {
-            const T sn = (T)sd[u];
-            Gs[pp[u] * ld + ii[u]] = c[u] * gp[u] - sn * gq[u];
-            Gs[qq[u] * ld + ii[u]] = sn * gp[u] + c[u] * gq[u];
           }
         }
         base = item; kb_ = k; ib_ = i;
@@ -254,7 +293,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 }
 
 static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
-  size_t bytes = 2 * kMaxPairs * sizeof(double) + 2 * kMaxPairs * sizeof(int) + 16 * sizeof(int);
+  const int np = (int)((n + 1) / 2), npad = (np + 7) & ~7;
+  const size_t tab = (size_t)npad * (2 * sizeof(double) + 4 * sizeof(int) + 2 * elem);
+  size_t bytes = tab + 16 * sizeof(int);
   bytes += (2 * ((n + 1) & ~1) + 2) * elem;
   if (ldsres) bytes += (size_t)n * (n + 1) * (elem + sizeof(double));  // G in T, V in double
   return (bytes + 15) & ~size_t(15);
