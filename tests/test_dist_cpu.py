@@ -33,10 +33,21 @@ def _worker(rank, world, port, total, q):
     full = tn.randn([total, 6, 6, 6, 6], ranks_tt=5, batch=True, dtype=torch.float64)
     lo, hi = shard_range(total, world, rank)
     out = round_tt_sharded([c[lo:hi] for c in full.cores], rmax=3, algorithm="svd")
+    # the pipelined form used by bench.py: async gather with sizes known up front, no merge copy
+    from tntorch_amd.dist_batch import gather_batch, shard_range as sr
+
+    t = tn.Tensor([c[lo:hi].clone() for c in full.cores], batch=True)
+    t.round_tt(rmax=3, algorithm="svd")
+    sizes = [sr(total, world, r)[1] - sr(total, world, r)[0] for r in range(world)]
+    h = gather_batch(t, dst=0, sizes=sizes, async_op=True)
+    parts = h.wait()
     if rank == 0:
+        assert len(parts) == world and [p.cores[0].shape[0] for p in parts] == sizes
+        merged = [torch.cat([p.cores[k] for p in parts]) for k in range(len(out.cores))]
+        assert all(torch.equal(a, b) for a, b in zip(merged, out.cores))
         q.put([c.numpy() for c in out.cores])
     else:
-        assert out is None
+        assert out is None and parts is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -75,6 +75,37 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Sum over the 64 lanes, result in every lane.  Row (16-lane) sums with four DPP steps -- VALU only, no
+// LDS crossbar -- then the four row sums are combined through SGPRs (readlane).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ float lane_get(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double lane_get(double v, int l) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+
 template <typename T>
 struct Num;
 template <>

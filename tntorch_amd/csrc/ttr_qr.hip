@@ -27,6 +27,8 @@
 //
 // Reflectors are stored explicitly (unit diagonal, zeros above) and transposed, Vt[j][row], so a
 // Householder step emits one coalesced 1 KiB store; T factors (16x16 per panel) sit next to them.
+#include <type_traits>
+
 #include "ttr_common.h"
 
 namespace ttr {
@@ -34,6 +36,8 @@ namespace ttr {
 constexpr int BR = 256;   // rows per block (= threads: thread t also acts as "row t")
 constexpr int PW = 16;    // panel width = MFMA tile edge
 constexpr int VLD = 17;   // leading dimension of 16-column LDS panels (conflict-free column walks)
+template <int I>
+using IC = std::integral_constant<int, I>;
 
 template <typename T>
 struct QrLevel {
@@ -77,9 +81,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
   using Acc = typename M::Acc;
   constexpr int NP = PW * NT;  // padded column count
   __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];       // current panel's reflectors [row][j]
-  __shared__ __attribute__((aligned(16))) T xbuf[2][BR];        // current / next column (double buffered)
-  __shared__ T wpart[2][4][PW];                                 // per-wave partials: x_tail^T a_c and a_c[jj]
-  __shared__ T rdiag[NP], taus[NP];
+  __shared__ T taus[NP];
   __shared__ T Ts[PW * VLD], Ss[PW * VLD];
   __shared__ T Wp[4][PW][NP];                                   // per-wave partial W (also S partials)
   __shared__ T W2s[PW][NP + 1];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = lane & 15, g = lane >> 4;
-  const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;  // provably wave-uniform
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   const int b = blockIdx.x;
   const int64_t bt = blockIdx.y;
   int64_t row0;
@@ -112,118 +114,98 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
   T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
   T* __restrict__ tau = p.tau + blk * (int64_t)NP;
   T* __restrict__ Tg = p.Tg + blk * (int64_t)NT * PW * PW;
-  if (tid < NP) { rdiag[tid] = T(0); taus[tid] = T(0); }
+  if (tid < NP) taus[tid] = T(0);
 
-#pragma unroll
-  for (int pnl = 0; pnl < NT; ++pnl) {
+  // Panels are expanded at compile time as well (acc[tm][pnl] must be a static register index).
+  auto panel = [&](auto PN) {
+    constexpr int pnl = decltype(PN)::value;
     const int j0 = pnl * PW;
     int nsteps = kb - j0;
     nsteps = nsteps < 0 ? 0 : (nsteps > PW ? PW : nsteps);
+    // Panel factorisation in a COLUMN-OWNING layout: the 256 x 16 panel is transposed through LDS (the
+    // Vs buffer, whose column j is only ever touched by the owner of column j) so that wave w holds panel
+    // columns 4w..4w+3 completely -- lane l has rows l, l+64, l+128, l+192.  The column norm and every
+    // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
+    // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
+    T pc[4][4];  // [column 4w+cc][row lane + 64 q]
+    if (pnl > 0) __syncthreads();  // the previous panel's MFMA update may still be reading Vs
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Vs[rowl(tm, r) * VLD + cl] = acc[tm][pnl][r];
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * 4 + cc];
+    __syncthreads();  // all columns are in registers before reflectors start overwriting Vs
     if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
-      __syncthreads();  // the previous panel's MFMA update may still be reading Vs
-#pragma unroll
-      for (int j = 0; j < PW; ++j) Vs[tid * VLD + j] = T(0);
+      for (int j = nsteps; j < PW; ++j) Vs[tid * VLD + j] = T(0);
     }
-    // Panel steps.  With x the current column (rows >= jj), beta = -sign(x_jj)||x||, scale = 1/(x_jj - beta)
-    // the reflector is v = [1; x_tail*scale], so  v^T a_c = a_c[jj] + scale * (x_tail^T a_c,tail):  the
-    // column norm and every reflector dot product are the SAME partial-dot pass against the raw column.
-    // Two barriers per step, no wave reduction; the next column is published by its owner while it is
-    // being updated (double-buffered xbuf).
-    // Row classes (jj < 64, so only wave 0 ever holds rows <= jj): for wave 0, row tiles tm < pnl lie
-    // entirely above the diagonal (no contribution), tile tm == pnl straddles it (masked), tiles
-    // tm > pnl and all tiles of waves 1..3 are pure tail (no masks, one FMA per element).
-    int cur = 0;
-    if (nsteps > 0 && cl == 0) {
+    // The 16 steps are expanded at compile time (J is a constant: the owner's column pc[oc] must be a
+    // static register index, and LLVM does not unroll a loop whose body contains the barrier).
+    auto step = [&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if (j < nsteps) {  // block-uniform
+        const int jj = j0 + j;
+        const int ow = j >> 2, oc = j & 3;
+        T v[4];
+        if (wave_id == ow) {  // wave-uniform: the owner of column jj builds the reflector
+          T ss = (lane > jj) ? pc[oc][0] * pc[oc][0] : T(0);
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+          for (int q = 1; q < 4; ++q) ss += pc[oc][q] * pc[oc][q];
+          ss = wave_sum_dpp(ss);
+          const T alpha = lane_get(pc[oc][0], jj);
+          T beta, tj, scale;
+          if (ss == T(0)) {  // LAPACK larfg: H = I
+            beta = alpha; tj = T(0); scale = T(0);
+          } else {
+            larfg_scalars(alpha, ss, beta, tj, scale);
+          }
+          v[0] = (lane > jj) ? pc[oc][0] * scale : (lane == jj ? T(1) : T(0));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xbuf[0][rowl(tm, r)] = acc[tm][pnl][r];
-    }
-    for (int j = 0; j < nsteps; ++j) {
-      const int jj = j0 + j;
-      __syncthreads();  // B1: column jj is in xbuf[cur]
-      const bool incol = (cl >= j) && (j0 + cl < n);
-      T xv[16];
-      T pd = 0, pa = 0;
-      if (incol) {
-        if (wave0) {
+          for (int q = 1; q < 4; ++q) v[q] = pc[oc][q] * scale;
 #pragma unroll
-          for (int tm = pnl; tm < 4; ++tm)
+          for (int q = 0; q < 4; ++q) {
+            Vs[(lane + 64 * q) * VLD + j] = v[q];
+            Vt[(int64_t)jj * BR + lane + 64 * q] = v[q];  // coalesced, fire and forget
+          }
+          if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
+          if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
+        }
+        __syncthreads();  // reflector jj (column j of Vs) and its tau are visible
+        if (wave_id >= ow && j0 + wave_id * 4 < n) {  // waves that still own columns right of jj
+          if (wave_id != ow) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = rowl(tm, r);
-              const T x = xbuf[cur][row];
-              const T a = acc[tm][pnl][r];
-              if (tm == pnl) {
-                xv[tm * 4 + r] = (row > jj) ? x : T(0);
-                pa += (row == jj) ? a : T(0);
-              } else {
-                xv[tm * 4 + r] = x;
-              }
-              pd += xv[tm * 4 + r] * a;
+            for (int q = 0; q < 4; ++q) v[q] = Vs[(lane + 64 * q) * VLD + j];
+          }
+          const T tj = taus[jj];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int col = wave_id * 4 + cc;  // panel-local column
+            if (col > j && j0 + col < n) {     // wave-uniform
+              T d = v[0] * pc[cc][0];
+#pragma unroll
+              for (int q = 1; q < 4; ++q) d += v[q] * pc[cc][q];
+              const T f = tj * wave_sum_dpp(d);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
             }
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              xv[tm * 4 + r] = xbuf[cur][rowl(tm, r)];
-              pd += xv[tm * 4 + r] * acc[tm][pnl][r];
-            }
+          }
         }
       }
-      // pre-reduce over the wave's 4 lane groups (same column, rows 4g.. of every tile)
-      pd += __shfl_xor(pd, 16, 64); pd += __shfl_xor(pd, 32, 64);
-      pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
-      if (g == 0) { wpart[0][wave][cl] = pd; wpart[1][wave][cl] = pa; }
-      __syncthreads();  // B2: partial dots visible
-      const T ss = (wpart[0][0][j] + wpart[0][1][j]) + (wpart[0][2][j] + wpart[0][3][j]);  // ||x_tail||^2
-      const T alpha = xbuf[cur][jj];
-      T beta, tj, scale;
-      if (ss == T(0)) {  // LAPACK larfg: H = I
-        beta = alpha; tj = T(0); scale = T(0);
-      } else {
-        larfg_scalars(alpha, ss, beta, tj, scale);
+    };
+    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
+    step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{}); step(IC<12>{}); step(IC<13>{}); step(IC<14>{}); step(IC<15>{});
+    {
+      // R rows of this panel: row i (< 64) of column 4w+cc sits in lane i, q = 0
+      T* __restrict__ Ro = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
+      const int rr = p.top ? kb : n;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = j0 + wave_id * 4 + cc;
+        if (c < n && lane < rr) Ro[(int64_t)lane * p.ldr + c] = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
       }
-      {
-        const T xt = xbuf[cur][tid];
-        const T vt = (tid > jj) ? xt * scale : (tid == jj ? T(1) : T(0));
-        Vs[tid * VLD + j] = vt;
-        Vt[(int64_t)jj * BR + tid] = vt;  // coalesced, fire and forget
-        if (tid == 0) { tau[jj] = tj; taus[jj] = tj; rdiag[jj] = beta; }
-      }
-      if (incol && cl > j) {
-        const T dot = (wpart[0][0][cl] + wpart[0][1][cl]) + (wpart[0][2][cl] + wpart[0][3][cl]);
-        const T ajj = (wpart[1][0][cl] + wpart[1][1][cl]) + (wpart[1][2][cl] + wpart[1][3][cl]);
-        const T f = tj * (ajj + scale * dot);
-        const T fs = f * scale;
-        const bool publish = (cl == j + 1) && (j + 1 < nsteps);
-        if (wave0) {
-#pragma unroll
-          for (int tm = pnl; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (tm == pnl) {
-                const int row = rowl(tm, r);
-                acc[tm][pnl][r] -= (row == jj) ? f : fs * xv[tm * 4 + r];  // xv is 0 for rows <= jj
-              } else {
-                acc[tm][pnl][r] -= fs * xv[tm * 4 + r];
-              }
-            }
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tm][pnl][r] -= fs * xv[tm * 4 + r];
-        }
-        if (publish) {
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xbuf[cur ^ 1][rowl(tm, r)] = acc[tm][pnl][r];
-        }
-      }
-      cur ^= 1;
     }
     for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
       Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
@@ -304,27 +286,13 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
                                  acc[tm][tn]);
     }
     // the next panel's first barrier orders (7)'s LDS reads before Vs / W2s are rewritten
-  }
+  };
+  panel(IC<0>{});
+  if constexpr (NT > 1) panel(IC<1>{});
+  if constexpr (NT > 2) panel(IC<2>{});
+  if constexpr (NT > 3) panel(IC<3>{});
   __syncthreads();
 
-  // R: rows 0..63 live in wave 0
-  T* __restrict__ Rout = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
-  const int rrows = p.top ? kb : n;
-  if (wave == 0) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = tm * 16 + M::row(lane, r), c = tn * PW + cl;
-          if (i < rrows && c < n) {
-            T v = T(0);
-            if (i < kb) v = (i < c) ? acc[tm][tn][r] : (i == c ? rdiag[c] : T(0));
-            Rout[(int64_t)i * p.ldr + c] = v;
-          }
-        }
-  }
 }
 
 // ---------------------------------------------------------------- apply (form Q [C;0] top-down)

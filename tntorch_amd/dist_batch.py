@@ -7,6 +7,12 @@ core k), so a single tensor does not shard; a BATCH of independent tensors (the 
 rank g owns the contiguous block ``[lo, hi)`` of the batch, runs the sweeps with no
 communication, and the rounded cores are collected with ONE gather of a packed buffer
 (rmax mode => identical core shapes on every rank, so the buffer layout is static).
+
+xGMI is point-to-point: every peer reaches the root over its own link, so the gather is
+bound by one link per peer (0.8 GB per rank for 512 rounded 64^8 trains).  ``gather_batch``
+can therefore run asynchronously (``async_op=True``): RCCL executes it on its own stream
+while the next batch is already being rounded, and the root receives views into the
+per-rank receive buffers -- no concatenation copy.
 """
 
 from typing import List, Optional, Sequence, Tuple
@@ -16,7 +22,7 @@ import torch.distributed as dist
 
 from .tensor import Tensor
 
-__all__ = ["shard_range", "pack_cores", "unpack_cores", "gather_batch", "round_tt_sharded"]
+__all__ = ["shard_range", "pack_cores", "unpack_cores", "gather_batch", "round_tt_sharded", "GatherHandle"]
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -32,6 +38,7 @@ def pack_cores(cores: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 def unpack_cores(flat: torch.Tensor, shapes: Sequence[Sequence[int]]) -> List[torch.Tensor]:
+    """Views of ``flat`` with the given shapes (inverse of ``pack_cores``, zero-copy)."""
     out, off = [], 0
     for shp in shapes:
         n = 1
@@ -42,45 +49,90 @@ def unpack_cores(flat: torch.Tensor, shapes: Sequence[Sequence[int]]) -> List[to
     return out
 
 
-def gather_batch(t: Tensor, dst: int = 0, group=None) -> Optional[Tensor]:
+class GatherHandle:
+    """Result of ``gather_batch``: ``wait()`` returns, on the destination rank, one ``Tensor`` per source
+    rank (cores are views into the receive buffers) -- ``None`` on the other ranks."""
+
+    def __init__(self, work, bufs, shapes, sizes, keep):
+        self._work, self._bufs, self._shapes, self._sizes, self._keep = work, bufs, shapes, sizes, keep
+        self._done = work is None
+
+    def wait(self) -> Optional[List[Tensor]]:
+        if not self._done:
+            self._work.wait()  # stream-level wait for NCCL, blocking for gloo
+            self._done = True
+        if self._bufs is None:
+            return None
+        out = []
+        for g, buf in enumerate(self._bufs):
+            cores = unpack_cores(buf, self._shapes)
+            out.append(Tensor([c[: self._sizes[g]] for c in cores], batch=True))
+        return out
+
+    def merged(self) -> Optional[Tensor]:
+        """Concatenate the per-rank pieces into one full-batch ``Tensor`` (copies)."""
+        parts = self.wait()
+        if parts is None:
+            return None
+        if len(parts) == 1:
+            return parts[0]
+        n = parts[0].dim()
+        return Tensor([torch.cat([p.cores[k] for p in parts]) for k in range(n)], batch=True)
+
+
+def gather_batch(
+    t: Tensor,
+    dst: int = 0,
+    group=None,
+    sizes: Optional[Sequence[int]] = None,
+    async_op: bool = False,
+) -> GatherHandle:
     """Collect the batch-sharded tensor ``t`` (``batch=True``) on rank ``dst`` with a single gather.
 
-    Every rank must hold cores of identical trailing shape (rmax-mode rounding); local batch
-    sizes may differ by one (block partition) -- shorter shards are padded in the packed buffer.
-    Returns the full-batch ``Tensor`` on ``dst`` and ``None`` elsewhere.
+    Every rank must hold cores of identical trailing shape (rmax-mode rounding).  ``sizes``: local batch
+    size of every rank when known up front (skips the 8-byte size exchange and its host sync); shorter
+    shards are padded in the packed buffer.  ``async_op=True`` returns immediately; call ``wait()``.
     """
     assert t.batch, "gather_batch needs a batch=True tensor"
+    Bl = t.cores[0].shape[0]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return t
+        flat = pack_cores(t.cores)
+        return GatherHandle(None, [flat], [list(c.shape) for c in t.cores], [Bl], None)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    Bl = t.cores[0].shape[0]
     dev = t.cores[0].device
-    sizes = torch.tensor([Bl], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)  # 8 bytes per rank; part of the same exchange step
-    all_B = [int(s.item()) for s in all_sizes]
-    Bmax = max(all_B)
+    if sizes is None:
+        mine = torch.tensor([Bl], dtype=torch.int64, device=dev)
+        allsz = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsz, mine, group=group)
+        sizes = [int(s.item()) for s in allsz]
+    sizes = [int(s) for s in sizes]
+    assert sizes[rank] == Bl, "sizes[rank] does not match the local batch"
+    Bmax = max(sizes)
     cores = t.cores
     if Bl < Bmax:
         cores = [torch.cat([c, c.new_zeros((Bmax - Bl,) + tuple(c.shape[1:]))]) for c in cores]
     flat = pack_cores(cores)
+    shapes = [[Bmax] + list(c.shape[1:]) for c in cores]
     if rank == dst:
         bufs = [torch.empty_like(flat) for _ in range(world)]
-        dist.gather(flat, gather_list=bufs, dst=dst, group=group)
-        shapes = [[Bmax] + list(c.shape[1:]) for c in cores]
-        per_rank = [unpack_cores(b, shapes) for b in bufs]
-        merged = [torch.cat([per_rank[g][k][: all_B[g]] for g in range(world)]) for k in range(len(cores))]
-        return Tensor(merged, batch=True)
-    dist.gather(flat, gather_list=None, dst=dst, group=group)
-    return None
+        work = dist.gather(flat, gather_list=bufs, dst=dst, group=group, async_op=True)
+        h = GatherHandle(work, bufs, shapes, sizes, flat)
+    else:
+        work = dist.gather(flat, gather_list=None, dst=dst, group=group, async_op=True)
+        h = GatherHandle(work, None, shapes, sizes, flat)
+    if not async_op:
+        h.wait()
+    return h
 
 
-def round_tt_sharded(cores: Sequence[torch.Tensor], rmax, algorithm: str = "svd", dst: int = 0, group=None):
+def round_tt_sharded(cores: Sequence[torch.Tensor], rmax, algorithm: str = "svd", dst: int = 0, group=None,
+                     sizes: Optional[Sequence[int]] = None):
     """Round the local shard of a batch and gather the result on ``dst``.
 
-    ``cores``: this rank's block of the batch (``[B_local, r0, I, r1]`` per core).
+    ``cores``: this rank's block of the batch (``[B_local, r0, I, r1]`` per core).  Returns the full-batch
+    ``Tensor`` on ``dst`` and ``None`` elsewhere.
     """
     t = Tensor(list(cores), batch=True)
     t.round_tt(rmax=rmax, algorithm=algorithm)
-    return gather_batch(t, dst=dst, group=group)
+    return gather_batch(t, dst=dst, group=group, sizes=sizes).merged()
