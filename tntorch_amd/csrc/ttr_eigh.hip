@@ -9,11 +9,12 @@
 //   phase 2  G <- J^T G J block-wise: one thread owns the 2x2 block (row pair, column pair) and applies
 //            both rotations in place; V <- V J column-wise in the same barrier interval
 // (two barriers per round)
-// The rotation parameters and the accumulated eigenvector matrix V are kept in DOUBLE for
-// either input type: ~500 rotations touch every entry of V, and float accumulation leaves
-// V^T V = I + O(1e-6), which shows up one-to-one as reconstruction error of the
-// truncation (measured 3.5e-6 per bond vs 3e-7 for LAPACK); with double accumulation V is
-// orthogonal to float round-off.
+// ~500 rotations touch every entry of the accumulated eigenvector matrix V, and float accumulation
+// leaves V^T V = I + O(3e-6), which shows up one-to-one as reconstruction error of the truncation
+// (measured 3.5e-6 per bond vs 3e-7 for LAPACK).  V is nevertheless kept in the matrix precision in
+// LDS (half the footprint: FOUR fp32 64x64 problems per CU instead of three, and the kernel is
+// occupancy/latency bound) and orthogonality is restored once at the end by one Newton-Schulz step
+// V <- V (I - E/2), E = V^T V - I, with E accumulated in double: V^T V = I + O(E^2) + O(eps).
 // Rotations are skipped when |G_pq| <= eps * sqrt(G_pp G_qq) (the relative criterion
 // that gives Jacobi its high relative accuracy on graded Gram matrices); the sweep
 // loop ends when a whole sweep rotates nothing.
@@ -39,7 +40,7 @@ struct EighArgs {
   int use_delta;
   double delta2;
   int64_t rmax;
-  T* ws;  // global-memory variant: per matrix n * (n + 1) * (sizeof(T) + 8) bytes (G in T, V in double)
+  T* ws;  // global-memory variant: per matrix 2 * n * (n + 1) elements (V, then G)
   int max_sweeps;
   int abs_floor;     // 1: also skip rotations with |G_pq| <= tol * max|G_ii| (plain Gram input: its entries are
                      //    only accurate to eps*||G||, below that level rotations chase rounding noise forever)
@@ -102,21 +103,20 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   int* flags = reinterpret_cast<int*>(after);              // [0]: rotated-this-sweep
   T* sg = reinterpret_cast<T*>(flags + 16);                // sigma / ordering scratch [2 * n]
   T* Gs;
-  double* Vs;
+  T* Vs;
   if (LDSRES) {
-    Vs = reinterpret_cast<double*>(sg + 2 * ((n + 1) & ~1) + 2);  // 8-byte aligned by construction
-    Gs = reinterpret_cast<T*>(Vs + (size_t)n * ld);
+    Vs = sg + 2 * ((n + 1) & ~1) + 2;
+    Gs = Vs + (size_t)n * ld;
   } else {
-    unsigned char* base = reinterpret_cast<unsigned char*>(p.ws) + bt * (int64_t)n * ld * (8 + sizeof(T));
-    Vs = reinterpret_cast<double*>(base);
-    Gs = reinterpret_cast<T*>(Vs + (size_t)n * ld);
+    Vs = p.ws + bt * (int64_t)2 * n * ld;
+    Gs = Vs + (size_t)n * ld;
   }
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   for (int idx = tid; idx < n * n; idx += kThreads) {
     const int i = idx / n, j = idx % n;
     Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
-    Vs[i * ld + j] = (i == j) ? 1.0 : 0.0;
+    Vs[i * ld + j] = (i == j) ? T(1) : T(0);
   }
   if (tid == 0) flags[0] = 0;
   __syncthreads();
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       }
       // ---- V <- V J  (columns p,q; lanes walk rows).  Independent of the G blocks: same barrier interval.
       for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
-        double cd[UNR], sd[UNR], vp[UNR], vq[UNR];
+        T cv[UNR], sv[UNR], vp[UNR], vq[UNR];
         int pp[UNR], qq[UNR], ii[UNR];
         bool on[UNR];
         int k = kb_, i = ib_, item = base;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           on[u] = item < np * n;
           const int ku = on[u] ? k : 0;
           ii[u] = on[u] ? i : 0;
-          sd[u] = cs_s[ku]; cd[u] = cs_c[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
-          on[u] = on[u] && (sd[u] != 0.0);
+          sv[u] = st[ku]; cv[u] = ct[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
+          on[u] = on[u] && (cs_s[ku] != 0.0);
           item += kThreads; i += di; k += dk;
           if (i >= n) { i -= n; ++k; }
         }
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           if (on[u]) {
-            Vs[ii[u] * ld + pp[u]] = cd[u] * vp[u] - sd[u] * vq[u];
-            Vs[ii[u] * ld + qq[u]] = sd[u] * vp[u] + cd[u] * vq[u];
+            Vs[ii[u] * ld + pp[u]] = cv[u] * vp[u] - sv[u] * vq[u];
+            Vs[ii[u] * ld + qq[u]] = sv[u] * vp[u] + cv[u] * vq[u];
           }
         }
         base = item; kb_ = k; ib_ = i;
@@ -241,9 +241,11 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     if (!rotated) break;
   }
 
-  // ---- epilogue: clamp / sqrt / sort / permute / rank rule
+  // ---- epilogue: clamp / sqrt / sort, Newton-Schulz re-orthogonalisation, permuted write, rank rule
   T* sig = sg;            // [n] unsorted sigma
   T* sig_sorted = sg + n; // [n]
+  int* posv = reinterpret_cast<int*>(smem_raw);  // [n] destination column of eigenvector i (the rotation table is
+                                                 // free now; its first array alone holds npad doubles >= n ints)
   for (int i = tid; i < n; i += kThreads) {
     T w = Gs[i * ld + i];
     if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
@@ -259,11 +261,32 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       pos += (sj > si) || (sj == si && j < i);
     }
     sig_sorted[pos] = si;
-    // permute the eigenvector: column i -> column pos
-    T* __restrict__ V = p.V + bt * p.strideV;
-    for (int row = 0; row < n; ++row) V[(int64_t)row * p.ldv + pos] = (T)Vs[row * ld + i];
+    posv[i] = pos;
   }
   __syncthreads();
+  T* __restrict__ V = p.V + bt * p.strideV;
+  if constexpr (sizeof(T) == 4) {
+    // E = V^T V - I (double accumulation) overwrites G, which is no longer needed
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int i = idx / n, j = idx - i * n;
+      double a = 0.0;
+      for (int k = 0; k < n; ++k) a += (double)Vs[k * ld + i] * (double)Vs[k * ld + j];
+      Gs[i * ld + j] = (T)(a - (i == j ? 1.0 : 0.0));
+    }
+    __syncthreads();
+    // V' = V - 0.5 V E, written straight to the output with the columns permuted into sorted order
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int row = idx / n, j = idx - row * n;
+      T a = 0;
+      for (int k = 0; k < n; ++k) a += Vs[row * ld + k] * Gs[k * ld + j];
+      V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j] - T(0.5) * a;
+    }
+  } else {  // double accumulation is already orthogonal to ~1e-14
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int row = idx / n, j = idx - row * n;
+      V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j];
+    }
+  }
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
   for (int i = tid; i < n; i += kThreads) sout[i] = sig_sorted[i];
   if (tid == 0) {
@@ -297,7 +320,7 @@ static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
   const size_t tab = (size_t)npad * (2 * sizeof(double) + 4 * sizeof(int) + 2 * elem);
   size_t bytes = tab + 16 * sizeof(int);
   bytes += (2 * ((n + 1) & ~1) + 2) * elem;
-  if (ldsres) bytes += (size_t)n * (n + 1) * (elem + sizeof(double));  // G in T, V in double
+  if (ldsres) bytes += 2 * (size_t)n * (n + 1) * elem;  // G and V
   return (bytes + 15) & ~size_t(15);
 }
 
@@ -311,7 +334,7 @@ int eigh_max_n_lds(int dtype) {
 
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   if (n <= eigh_max_n_lds(dtype)) return 0;
-  return batch * n * (n + 1) * ((dtype == TTR_F64 ? 8 : 4) + 8);
+  return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
 }
 
 template <typename T>
