@@ -174,63 +174,78 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       // the sub-groups / waves / iterations walk the row pairs, four blocks in flight per thread.
       for (int kc = kc_l; kc < np; kc += cw) {
         const T cc = ct[kc], sc = st[kc];
-        const bool onc = cs_s[kc] != 0.0;
         const int pc = pq_p[kc], qc = pq_q[kc];
         for (int krb = kr0; krb < np; krb += 4 * krs) {
-          T cr[4], sr[4], a[4], bq[4], c2[4], d[4];
-          int pr[4], qr[4];
-          bool on[4];
+          if (krb + 3 * krs < np) {
+            // fast path, branch-free: an identity rotation (c = 1, s = 0) reproduces its inputs exactly, so
+            // nothing is skipped and the 16 LDS loads of the four blocks are in flight together
+            T cr[4], sr[4], a[4], bq[4], c2[4], d[4];
+            int pr[4], qr[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int kr = krb + u * krs;
-            const bool in = kr < np;
-            const int kk = in ? kr : 0;
-            cr[u] = ct[kk]; sr[u] = st[kk]; pr[u] = prow[kk]; qr[u] = qrow[kk];
-            on[u] = in && (onc || cs_s[kk] != 0.0);
-          }
+            for (int u = 0; u < 4; ++u) {
+              const int kk = krb + u * krs;
+              cr[u] = ct[kk]; sr[u] = st[kk]; pr[u] = prow[kk]; qr[u] = qrow[kk];
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            a[u] = Gs[pr[u] + pc]; bq[u] = Gs[pr[u] + qc]; c2[u] = Gs[qr[u] + pc]; d[u] = Gs[qr[u] + qc];
-          }
+            for (int u = 0; u < 4; ++u) {
+              a[u] = Gs[pr[u] + pc]; bq[u] = Gs[pr[u] + qc]; c2[u] = Gs[qr[u] + pc]; d[u] = Gs[qr[u] + qc];
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (on[u]) {
+            for (int u = 0; u < 4; ++u) {
               const T t1 = cc * a[u] - sc * bq[u], t2 = sc * a[u] + cc * bq[u];
               const T u1 = cc * c2[u] - sc * d[u], u2 = sc * c2[u] + cc * d[u];
-              Gs[pr[u] + pc] = cr[u] * t1 - sr[u] * u1;
-              Gs[pr[u] + qc] = cr[u] * t2 - sr[u] * u2;
-              Gs[qr[u] + pc] = sr[u] * t1 + cr[u] * u1;
-              Gs[qr[u] + qc] = sr[u] * t2 + cr[u] * u2;
+              a[u] = cr[u] * t1 - sr[u] * u1; bq[u] = cr[u] * t2 - sr[u] * u2;
+              c2[u] = sr[u] * t1 + cr[u] * u1; d[u] = sr[u] * t2 + cr[u] * u2;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              Gs[pr[u] + pc] = a[u]; Gs[pr[u] + qc] = bq[u]; Gs[qr[u] + pc] = c2[u]; Gs[qr[u] + qc] = d[u];
+            }
+          } else {
+            for (int kk = krb; kk < np; kk += krs) {
+              const T cr = ct[kk], sr = st[kk];
+              const int pr = prow[kk], qr = qrow[kk];
+              const T a = Gs[pr + pc], bq = Gs[pr + qc], c2 = Gs[qr + pc], d = Gs[qr + qc];
+              const T t1 = cc * a - sc * bq, t2 = sc * a + cc * bq;
+              const T u1 = cc * c2 - sc * d, u2 = sc * c2 + cc * d;
+              Gs[pr + pc] = cr * t1 - sr * u1; Gs[pr + qc] = cr * t2 - sr * u2;
+              Gs[qr + pc] = sr * t1 + cr * u1; Gs[qr + qc] = sr * t2 + cr * u2;
             }
           }
         }
       }
       // ---- V <- V J  (columns p,q; lanes walk rows).  Independent of the G blocks: same barrier interval.
       for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
-        T cv[UNR], sv[UNR], vp[UNR], vq[UNR];
-        int pp[UNR], qq[UNR], ii[UNR];
-        bool on[UNR];
-        int k = kb_, i = ib_, item = base;
+        if (base + (UNR - 1) * kThreads < np * n) {  // fast path, branch-free (same argument as above)
+          T cv[UNR], sv[UNR], vp[UNR], vq[UNR];
+          int ap[UNR], aq[UNR];
+          int k = kb_, i = ib_;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          on[u] = item < np * n;
-          const int ku = on[u] ? k : 0;
-          ii[u] = on[u] ? i : 0;
-          sv[u] = st[ku]; cv[u] = ct[ku]; pp[u] = pq_p[ku]; qq[u] = pq_q[ku];
-          on[u] = on[u] && (cs_s[ku] != 0.0);
-          item += kThreads; i += di; k += dk;
-          if (i >= n) { i -= n; ++k; }
-        }
+          for (int u = 0; u < UNR; ++u) {
+            sv[u] = st[k]; cv[u] = ct[k]; ap[u] = i * ld + pq_p[k]; aq[u] = i * ld + pq_q[k];
+            i += di; k += dk;
+            if (i >= n) { i -= n; ++k; }
+          }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) { vp[u] = Vs[ii[u] * ld + pp[u]]; vq[u] = Vs[ii[u] * ld + qq[u]]; }
+          for (int u = 0; u < UNR; ++u) { vp[u] = Vs[ap[u]]; vq[u] = Vs[aq[u]]; }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          if (on[u]) {
-            Vs[ii[u] * ld + pp[u]] = cv[u] * vp[u] - sv[u] * vq[u];
-            Vs[ii[u] * ld + qq[u]] = sv[u] * vp[u] + cv[u] * vq[u];
+          for (int u = 0; u < UNR; ++u) {
+            Vs[ap[u]] = cv[u] * vp[u] - sv[u] * vq[u];
+            Vs[aq[u]] = sv[u] * vp[u] + cv[u] * vq[u];
+          }
+          base += UNR * kThreads; kb_ = k; ib_ = i;
+        } else {
+          int k = kb_, i = ib_;
+          for (; base < np * n; base += kThreads) {
+            const T sv = st[k], cv = ct[k];
+            const int ap = i * ld + pq_p[k], aq = i * ld + pq_q[k];
+            const T vp = Vs[ap], vq = Vs[aq];
+            Vs[ap] = cv * vp - sv * vq;
+            Vs[aq] = sv * vp + cv * vq;
+            i += di; k += dk;
+            if (i >= n) { i -= n; ++k; }
           }
         }
-        base = item; kb_ = k; ib_ = i;
       }
       __syncthreads();
     }
