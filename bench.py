@@ -50,27 +50,25 @@ def make_input(B, device, seed):
 
 
 def algorithmic_bytes_per_tensor():
-    """Per-stage split of SURVEY 8d's byte model for the M workload (float32).
-
-    L2R: every core is read once by the QR (-> `qr_factor`) and written once as Q (-> `qr_apply`);
-    R2L: per bond, M (m x n) read once, V^T (r x n) written, previous core read (R I m) and written (R I r)
-    (-> `gemm` + `eigh`, the Gram/projection/push GEMMs).  Sum = 2.69e7 B.
-    """
+    """Bytes each kernel kind must move per tensor GIVEN ITS INTERFACE (float32, M workload): operands read
+    once, results written once.  (SURVEY 8d's 2.69e7 B/tensor is the fully fused lower bound for the whole
+    sweep and is reported separately as `whole_sweep_hbm_frac`.)"""
     s = 4
-    numel = [1 * MODE * R_IN] + [R_IN * MODE * R_IN] * (N_CORES - 2) + [R_IN * MODE * 1]
-    l2r_read = s * sum(numel[:-1])   # cores 0..N-2 enter a QR
-    l2r_write = s * sum(numel[:-1])
-    r2l = 0
-    rn = 1
-    for k in range(N_CORES - 1, 0, -1):
-        m, n = R_IN, MODE * rn
-        rk = min(R_OUT, m, n)
-        Rprev = 1 if k - 1 == 0 else R_IN
-        r2l += s * (m * n + rk * n + Rprev * MODE * (m + rk))
-        rn = rk
-    last = s * numel[-1] * 2  # last core: written by the last push, read by the first truncation
-    return {"qr_factor": l2r_read, "qr_apply": l2r_write, "gemm+eigh": r2l + last,
-            "total": l2r_read + l2r_write + r2l + last}
+    mid = R_IN * MODE * R_IN
+    first = 1 * MODE * R_IN
+    last = R_IN * MODE * 1
+    qr_factor = s * (first + (N_CORES - 2) * mid)                     # every core but the last enters one QR
+    qr_apply = s * (1 * MODE * R_OUT + (N_CORES - 2) * R_IN * MODE * R_OUT)  # Q [U sigma; 0]: (R I) x 32 per core
+    push = s * (2 * (N_CORES - 2) * mid + 2 * last + (N_CORES - 1) * R_IN * R_IN)    # R @ next core: read + write
+    n_big = MODE * R_OUT                                              # right unfolding of a middle core: 64 x 2048
+    per_bond = s * (R_IN * n_big                                      # Gram(M)
+                    + 2 * R_IN * n_big                                # V1^T M: read + write
+                    + R_IN * n_big                                    # Gram(M1)
+                    + R_IN * n_big + R_OUT * n_big)                   # projection: read M1, write V^T
+    last_bond = s * (4 * R_IN * MODE + R_IN * MODE + R_OUT * MODE)
+    gemm = push + (N_CORES - 2) * per_bond + last_bond
+    eigh = 2 * (N_CORES - 1) * s * 2 * R_IN * R_IN                    # two Jacobi passes per bond: G in, V out
+    return {"qr_factor": qr_factor, "qr_apply": qr_apply, "gemm": gemm, "eigh": eigh}
 
 
 def cpu_baseline(budget_s=25.0):
@@ -222,21 +220,28 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         cores_per_s = tensors * N_CORES / elapsed
         abytes = algorithmic_bytes_per_tensor()
-        kinds = {k: v for k, v in prof.items() if v["launches"] > 0}
+        kinds = {k: v for k, v in prof.items() if v["launches"] > 0 and k in abytes}
         dom = max(kinds, key=lambda k: kinds[k]["ms"])
-        stage_key = dom if dom in abytes else "gemm+eigh"
-        stage_ms = kinds[dom]["ms"] if dom in abytes else kinds.get("gemm", {"ms": 0})["ms"] + kinds.get("eigh", {"ms": 0})["ms"]
         launches = kinds[dom]["launches"]
         avg_launch_ms = kinds[dom]["ms"] / launches
-        bytes_per_launch = abytes[stage_key] * B * args.steps / launches
-        achieved = abytes[stage_key] * B * args.steps / (stage_ms * 1e-3) / 1e9
+        bytes_per_launch = abytes[dom] * B * args.steps / launches
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is not None and pmc.get("_batch"):
+                    traffic = traffic * B / pmc["_batch"]
             except Exception:
                 traffic = None
+        per_kind = {
+            k: {"ms_per_step": v["ms"] / args.steps,
+                "achieved_GBs": abytes[k] * B * args.steps / (v["ms"] * 1e-3) / 1e9,
+                "frac_of_hbm_peak": abytes[k] * B * args.steps / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            for k, v in kinds.items()
+        }
         res = {
             "metric": "TT rounding 64^8 rank-64 -> rank-32 (round_tt rmax=32), cores/s",
             "value": cores_per_s,
@@ -261,7 +266,6 @@ def main():
             "whole_sweep_hbm_frac": BYTES_PER_TENSOR * tensors / elapsed / 1e9 / HBM_PEAK_GBS,
             "roofline": {
                 "kernel": dom,
-                "stage": stage_key,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -272,7 +276,8 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "launches": launches,
             },
-            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in kinds.items()},
+            "roofline_per_kernel": per_kind,
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()

@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libttround_hip.so")
 F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF = 0, 1
+SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG = 0, 1, 2  # `abs_floor` argument of ttr_eigh_trunc
 PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc")
 
 _lib = None
@@ -257,7 +258,7 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
 
 
 def eigh_trunc(
-    G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: bool = True,
+    G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: int = 1,
     sweeps: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
@@ -276,7 +277,7 @@ def eigh_trunc(
     rmax = int(min(max(int(rmax), 1), 2**31 - 1))
     code = L.ttr_eigh_trunc(
         dt, n, batch, G.data_ptr(), ldg, sG, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
-        eig_mode, int(bool(use_delta)), float(delta2), rmax, int(bool(abs_floor)),
+        eig_mode, int(bool(use_delta)), float(delta2), rmax, int(abs_floor),
         sweeps.data_ptr() if sweeps is not None else None,
         ws.data_ptr() if ws is not None else None, wsb, _stream(),
     )

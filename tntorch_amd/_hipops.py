@@ -92,12 +92,12 @@ def truncate(
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         if left_side:
             G = _hip.gemm(M, M, transB=True)
-            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k)
+            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
             G = _hip.gemm(Mw, Mw, transB=True)
         else:
             G = _hip.gemm(M, M, transA=True)
-            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k)
+            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             Mw = _hip.gemm(M, V1)                        # M V1
             G = _hip.gemm(Mw, Mw, transA=True)
     else:
@@ -105,7 +105,10 @@ def truncate(
         Mw = M
         G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
 
-    V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap)
+    # 'eig' (and pass 1 above): absolute accuracy is all a plain Gram matrix carries -> tridiagonal QL solver;
+    # pass 2 of 'svd': graded, accurately formed Gram matrix -> Jacobi (relative accuracy of the small sigmas)
+    V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
+                                   abs_floor=_hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_ABS)
     r = _select_rank(info, batch, rmax, k)
     if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
         z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)

@@ -330,6 +330,223 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   }
 }
 
+// ====================================================================================================
+// Tridiagonal QL eigensolver: ONE WAVE per matrix (n <= 64), no workgroup barriers.
+//
+// Householder reduction to tridiagonal form, in-place accumulation of Q, implicit-shift QL with the
+// rotations applied to Q's columns: ~10x fewer flops than cyclic Jacobi (n^3-class constant 4/3+4/3+~3
+// instead of ~50) and no cross-wave synchronisation, so many problems run per CU.  Absolute accuracy
+// O(eps * ||G||) (LAPACK steqr class): this is the pass-1 / 'eig' solver.  Pass 2 of the 'svd' algorithm
+// needs the relative accuracy of Jacobi on a graded matrix and keeps the Jacobi kernel.
+//   lane = row      for the reduction (symmetric mat-vec, rank-2 update) and for applying QL rotations
+//   lane = column   for forming Q (each lane reduces its own column: no cross-lane reductions)
+// The matrix is scaled by 1/max|G_ii| on load (fp32 Gram matrices of the metric workload reach 1e24, whose
+// squares overflow) and the eigenvalues are scaled back at the end.
+template <typename T>
+__global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int64_t bt = blockIdx.x;
+  const int n = p.n;
+  const int ld = n + 1;
+  T* A = reinterpret_cast<T*>(smem_raw);     // [n][ld]  G -> reflectors -> Q -> eigenvectors
+  T* vs = A + n * ld + 3;                    // [64] current reflector
+  T* wsv = vs + 64;                          // [64]
+  T* dv = wsv + 64;                          // [65] diagonal / eigenvalues
+  T* ev = dv + 66;                           // [65] sub-diagonal (ev[i] couples i, i+1)
+  T* tauv = ev + 66;                         // [64]
+  T* cv = tauv + 64;                         // [64] rotations of the current QL sweep
+  T* sv = cv + 64;                           // [64]
+  int* posv = reinterpret_cast<int*>(sv + 64);  // [64]
+
+  const T* __restrict__ G = p.G + bt * p.strideG;
+  // ---- load + scale
+  T gd = (lane < n) ? fabs(G[(int64_t)lane * p.ldg + lane]) : T(0);
+  T gmax = gd;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
+  const T ginv = gmax > T(0) ? T(1) / gmax : T(0);
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int i = idx / n, j = idx - i * n;
+    A[i * ld + j] = G[(int64_t)i * p.ldg + j] * ginv;
+  }
+  __syncthreads();
+
+  // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k]
+  for (int k = 0; k + 1 < n; ++k) {
+    const bool below = lane >= k + 2 && lane < n;
+    const T x = below ? A[lane * ld + k] : T(0);
+    const T alpha = A[(k + 1) * ld + k];
+    const T xn2 = wave_sum_dpp(x * x);
+    T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
+    if (xn2 != T(0)) {
+      beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+      t = (beta - alpha) / beta;
+      const T scale = T(1) / (alpha - beta);
+      if (below) v = x * scale;
+    }
+    if (lane == 0) { ev[k] = beta; tauv[k] = t; }
+    vs[lane] = v;
+    __syncthreads();
+    if (t != T(0)) {
+      const bool act = lane >= k + 1 && lane < n;
+      T pr = 0;
+      if (act) {
+        for (int j = k + 1; j < n; ++j) pr += A[lane * ld + j] * vs[j];
+        pr *= t;
+      }
+      const T dot = wave_sum_dpp(pr * v);
+      const T w = pr - T(0.5) * t * dot * v;
+      wsv[lane] = w;
+      __syncthreads();
+      if (act) {
+        for (int j = k + 1; j < n; ++j) A[lane * ld + j] -= v * wsv[j] + w * vs[j];
+      }
+    }
+    if (below) A[lane * ld + k] = v;  // keep the reflector below the sub-diagonal
+    __syncthreads();
+    if (lane == 0) dv[k] = A[k * ld + k];
+  }
+  if (lane == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = T(0); if (n == 1) tauv[0] = T(0); }
+  __syncthreads();
+
+  // ---- 2. Q = H_0 ... H_{n-2} in place: column c of the trailing (n-1)x(n-1) block of Q lands in column c+1,
+  //         reflector k sits in A[k+2:, k]; processed k = n-2 .. 0 with lane = column
+  for (int k = n - 2; k >= 0; --k) {
+    const T v = (lane == k + 1) ? T(1) : ((lane >= k + 2 && lane < n) ? A[lane * ld + k] : T(0));
+    const T t = tauv[k];
+    vs[lane] = v;
+    __syncthreads();
+    if (lane >= k + 2 && lane < n && t != T(0)) {  // lane = column c
+      T sdot = 0;
+      for (int i = k + 1; i < n; ++i) sdot += vs[i] * A[i * ld + lane];
+      const T f = t * sdot;
+      for (int i = k + 1; i < n; ++i) A[i * ld + lane] -= f * vs[i];
+    }
+    __syncthreads();
+    if (lane < n) A[lane * ld + k + 1] = (lane == k + 1) ? T(1) - t : ((lane >= k + 2) ? -t * v : T(0));  // lane = row
+    __syncthreads();
+  }
+  if (lane < n) { A[lane * ld + 0] = (lane == 0) ? T(1) : T(0); A[0 * ld + lane] = (lane == 0) ? T(1) : T(0); }
+  __syncthreads();
+
+  // ---- 3. implicit-shift QL on (dv, ev); rotations applied to the columns of Q (lane = row)
+  const T eps = Num<T>::eps();
+  T an = (lane < n) ? fmax(fabs(dv[lane]), fabs(ev[lane])) : T(0);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) an = fmax(an, __shfl_xor(an, off, 64));
+  const T floor_abs = eps * an;
+  int total_iter = 0;
+  for (int l = 0; l < n; ++l) {
+    for (int iter = 0; iter < 64; ++iter) {
+      // m = first index >= l with a negligible sub-diagonal (n-1 if none)
+      bool small = true;
+      if (lane >= l && lane < n - 1) {
+        const T el = fabs(ev[lane]);
+        small = (el <= eps * (fabs(dv[lane]) + fabs(dv[lane + 1]))) || (el <= floor_abs);
+      }
+      unsigned long long mask = __ballot(small && lane >= l);
+      const int m = __ffsll((long long)mask) - 1;  // lanes >= n-1 always report "small"
+      if (m <= l) break;
+      ++total_iter;
+      T g = (dv[l + 1] - dv[l]) / (T(2) * ev[l]);
+      T r = sqrt(g * g + T(1));
+      g = dv[m] - dv[l] + ev[l] / (g + copysign(r, g));
+      T sn = T(1), cs = T(1), pp = T(0);
+      bool underflow = false;
+      int ilast = l;
+      for (int i = m - 1; i >= l; --i) {
+        const T f = sn * ev[i], b = cs * ev[i];
+        r = sqrt(f * f + g * g);
+        if (lane == 0) ev[i + 1] = r;
+        if (r == T(0)) {
+          if (lane == 0) { dv[i + 1] -= pp; ev[m] = T(0); }
+          underflow = true;
+          ilast = i + 1;
+          break;
+        }
+        const T rinv = T(1) / r;
+        sn = f * rinv; cs = g * rinv;
+        g = dv[i + 1] - pp;
+        r = (dv[i] - g) * sn + T(2) * cs * b;
+        pp = sn * r;
+        if (lane == 0) { dv[i + 1] = g + pp; cv[i] = cs; sv[i] = sn; }
+        g = cs * r - b;
+      }
+      __syncthreads();
+      // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element
+      if (lane < n) {
+        T hi = A[lane * ld + m];
+        for (int i = m - 1; i >= ilast; --i) {
+          const T lo = A[lane * ld + i];
+          const T c2 = cv[i], s2 = sv[i];
+          A[lane * ld + i + 1] = s2 * lo + c2 * hi;
+          hi = c2 * lo - s2 * hi;
+        }
+        A[lane * ld + ilast] = hi;
+      }
+      if (!underflow && lane == 0) { dv[l] -= pp; ev[l] = g; ev[m] = T(0); }
+      __syncthreads();
+    }
+  }
+
+  // ---- 4. epilogue: un-scale, clamp / sqrt / sort, permuted write, rank rule (round.py:118-158)
+  T* sig = vs;          // reuse
+  T* sig_sorted = wsv;
+  if (lane < n) {
+    T w = dv[lane] * gmax;
+    if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
+    else { if (!(w > T(0))) w = T(0); }
+    sig[lane] = sqrt(w);
+  }
+  __syncthreads();
+  if (lane < n) {
+    const T si = sig[lane];
+    int pos = 0;
+    for (int j = 0; j < n; ++j) {
+      const T sj = sig[j];
+      pos += (sj > si) || (sj == si && j < lane);
+    }
+    sig_sorted[pos] = si;
+    posv[lane] = pos;
+  }
+  __syncthreads();
+  T* __restrict__ V = p.V + bt * p.strideV;
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int row = idx / n, j = idx - row * n;
+    V[(int64_t)row * p.ldv + posv[j]] = A[row * ld + j];
+  }
+  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
+  if (lane < n) sout[lane] = sig_sorted[lane];
+  if (lane == 0) {
+    int rank;
+    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
+    if (sig_sorted[0] < T(1e-13)) {
+      rank = 0;  // zero guard, round.py:137-145
+    } else if (!p.use_delta) {
+      rank = (int)(cap < 1 ? 1 : cap);
+    } else {
+      const T d2 = (T)p.delta2;
+      double acc = 0.0;
+      int tail = 0;
+      for (int k = n - 1; k >= 0; --k) {
+        acc += (double)(sig_sorted[k] * sig_sorted[k]);
+        if ((T)acc <= d2) tail = n - k; else break;
+      }
+      int64_t rk = n - tail;
+      if (rk > cap) rk = cap;
+      if (rk < 1) rk = 1;
+      rank = (int)rk;
+    }
+    p.info[bt] = rank;
+    if (p.sweeps) p.sweeps[bt] = total_iter;
+  }
+}
+
+static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {
+  return (((size_t)n * (n + 1) + 3 + 64 * 5 + 66 * 2) * elem + 64 * sizeof(int) + 15) & ~size_t(15);
+}
+
 static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
   const int np = (int)((n + 1) / 2), npad = (np + 7) & ~7;
   const size_t tab = (size_t)npad * (2 * sizeof(double) + 4 * sizeof(int) + 2 * elem);
@@ -370,6 +587,14 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
   p.abs_floor = abs_floor;
   p.sweeps = sweeps;
+  if (abs_floor == 2 && n <= 64) {  // tridiagonal QL, one wave per matrix
+    const size_t lds = eigh_tridiag_lds_bytes(sizeof(T), n);
+    ProfScope prof(TTR_PROF_EIGH, stream);
+    hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(kWave), lds, stream, p);
+    TTR_HIP_CHECK(hipGetLastError());
+    return TTR_OK;
+  }
+  if (abs_floor == 2) p.abs_floor = 1;  // larger problems: Jacobi with the absolute floor
   const bool ldsres = n <= eigh_max_n_lds(dtype);
   if (!ldsres) {
     const int64_t need = eigh_workspace_bytes(dtype, n, batch);
