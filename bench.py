@@ -129,8 +129,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="tensors per GPU per step (1024 = four 64x64 Jacobi problems per CU, the occupancy sweet spot)")
+    ap.add_argument("--batch", type=int, default=2048,
+                    help="tensors per GPU per step (2048 = eight single-wave 64x64 eigenproblems per CU; 13 GB of cores)")
     ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

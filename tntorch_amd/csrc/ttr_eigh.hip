@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
     Vs[i * ld + j] = (i == j) ? T(1) : T(0);
   }
-  if (tid == 0) flags[0] = 0;
+  if (tid == 0) { flags[0] = 0; flags[1] = 0; }
   __syncthreads();
   T floor_abs = Num<T>::tiny();
   if (p.abs_floor) {
@@ -139,8 +139,20 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int krs = 4 * (64 / cw);                       // row-pair stride between a thread's blocks
   const int kr0 = (tid >> 6) * (64 / cw) + (tid & 63) / cw;
 
+  // Pre-check (pass 2 of the 'svd' algorithm hands over an already diagonal-to-working-accuracy matrix):
+  // if no off-diagonal entry passes the rotation test, no sweep runs, V stays the identity and the
+  // re-orthogonalisation below is skipped.
+  for (int idx = tid; idx < n * n; idx += kThreads) {
+    const int i = idx / n, j = idx - i * n;
+    if (i < j) {
+      const T aabs = fabs(Gs[i * ld + j]);
+      if (aabs > eps * (sqrt(fabs(Gs[i * ld + i])) * sqrt(fabs(Gs[j * ld + j]))) && aabs > floor_abs) flags[1] = 1;
+    }
+  }
+  __syncthreads();
+  const bool any_work = flags[1] != 0;
   int sweeps_used = 0;
-  for (int sweep = 0; sweep < p.max_sweeps && n > 1; ++sweep) {
+  for (int sweep = 0; sweep < p.max_sweeps && n > 1 && any_work; ++sweep) {
     sweeps_used = sweep + 1;
     for (int r = 0; r < m1; ++r) {
       // ---- phase 1: rotations of this round (one thread per pair)
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   }
   __syncthreads();
   T* __restrict__ V = p.V + bt * p.strideV;
-  if constexpr (sizeof(T) == 4) {
+  if (sizeof(T) == 4 && any_work) {
     // E = V^T V - I (double accumulation) overwrites G, which is no longer needed
     for (int idx = tid; idx < n * n; idx += kThreads) {
       const int i = idx / n, j = idx - i * n;
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       for (int k = 0; k < n; ++k) a += Vs[row * ld + k] * Gs[k * ld + j];
       V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j] - T(0.5) * a;
     }
-  } else {  // double accumulation is already orthogonal to ~1e-14
+  } else {  // double accumulation is already orthogonal to ~1e-14 (or V is still exactly the identity)
     for (int idx = tid; idx < n * n; idx += kThreads) {
       const int row = idx / n, j = idx - row * n;
       V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j];
