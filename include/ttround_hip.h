@@ -108,6 +108,25 @@ int ttr_qr_apply(int dtype, int64_t m, int64_t n, int64_t batch,
                  void* Out, int64_t ldo, int64_t strideO, void* stream);
 
 /*
+ * Fused "push right + QR" of the left-to-right sweep (tensor.py:1823-1832 followed by tensor.py:1816 of the next
+ * core): factors the (k*I) x n left unfolding of  P[kk, i, c] = sum_r0 Rm[kk, r0] * core[r0, i, c]  without ever
+ * writing P.  Rm is the R factor of the previous core (k x Rin, k, Rin <= 64), `core` the next core, contiguous
+ * [Rin, I, n].  The TSQR row blocks are chosen as {(kk, i): i = 4b .. 4b+3}, so every wave forms its own 64 x n
+ * slice Rm * core[:, i, :] on the matrix cores straight into the accumulator tiles it then factors.
+ * ttr_qr_apply_pushed is the matching ttr_qr_apply (Out rows in the natural order kk*I + i).  Needs k*I >= n.
+ */
+int64_t ttr_qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch);
+int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch,
+                         const void* Rm, int64_t ldrm, int64_t strideRm,
+                         const void* core, int64_t stride_core,
+                         void* R, int64_t ldr, int64_t strideR,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch,
+                        void* workspace, int64_t workspace_bytes,
+                        const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
+                        void* Out, int64_t ldo, int64_t strideO, void* stream);
+
+/*
  * Symmetric eigen-decomposition + the rank rule of truncated_svd, batched, on device.
  * Input  G[b]  (n x n symmetric, e.g. a Gram matrix).
  * Output V[b]  (n x n): eigenvectors as COLUMNS, sorted by DEcreasing sigma,

@@ -90,6 +90,30 @@ def test_qr(dt, m, n):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("k,Rin,I,n", [(64, 64, 64, 64), (10, 7, 9, 12), (64, 64, 5, 33), (33, 64, 130, 64), (1, 1, 40, 8)])
+def test_qr_pushed(dt, k, Rin, I, n):
+    """Fused push + QR: factor the left unfolding of Rm @ core without forming it; apply gives Q [C; 0]."""
+    h = _hip()
+    g = torch.Generator().manual_seed(k * 1000 + Rin * 100 + I * 10 + n)
+    B = 2
+    Rm = torch.randn(B, k, Rin, generator=g, dtype=torch.float64).to(dt)
+    core = torch.randn(B, Rin, I, n, generator=g, dtype=torch.float64).to(dt)
+    P = (Rm.double() @ core.double().reshape(B, Rin, I * n)).reshape(B, k * I, n)
+    f = h.qr_factor_pushed(Rm.cuda(), core.cuda())
+    Q = h.qr_apply(f).cpu().double()
+    R = f.R.cpu().double()
+    kq = min(k * I, n)
+    assert Q.shape == (B, k * I, kq) and R.shape == (B, kq, n)
+    assert (Q.transpose(1, 2) @ Q - torch.eye(kq, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
+    assert (Q @ R - P).abs().max() / P.abs().max() < tol(dt, 2e-5, 1e-12)
+    Rref = torch.linalg.qr(P)[1]
+    assert (R.abs() - Rref.abs()).abs().max() / Rref.abs().max() < tol(dt, 3e-4, 1e-10)
+    C = torch.randn(B, kq, min(kq, 5), generator=g, dtype=torch.float64).to(dt)
+    out = h.qr_apply(f, C.cuda()).cpu().double()
+    assert (out - Q @ C.double()).abs().max() < tol(dt, 3e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_qr_rank_deficient(dt):
     """Left unfolding of g+g: exactly rank-deficient; Q must still be orthonormal."""
     h = _hip()

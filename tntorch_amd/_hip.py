@@ -57,6 +57,18 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64,
          c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_qr_pushed_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "ttr_qr_factor_pushed": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_qr_apply_pushed": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+    ),
     "ttr_eigh_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
     "ttr_eigh_trunc": (
         c_int,
@@ -210,10 +222,11 @@ def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 class QrFactors:
     """Handle on a factored batch (reflectors + T factors live in ``ws``) for later ``qr_apply`` calls."""
 
-    __slots__ = ("ws", "wsb", "m", "n", "batch", "dtype", "R")
+    __slots__ = ("ws", "wsb", "m", "n", "batch", "dtype", "R", "pushed")
 
-    def __init__(self, ws, wsb, m, n, batch, dtype, R):
+    def __init__(self, ws, wsb, m, n, batch, dtype, R, pushed=None):
         self.ws, self.wsb, self.m, self.n, self.batch, self.dtype, self.R = ws, wsb, m, n, batch, dtype, R
+        self.pushed = pushed  # (k, I) when the factorisation came from qr_factor_pushed
 
     @property
     def k(self):
@@ -236,6 +249,30 @@ def qr_factor(A: torch.Tensor) -> QrFactors:
     return QrFactors(ws, wsb, m, n, batch, A.dtype, R)
 
 
+def pushed_supported(k: int, Rin: int, I: int, n: int, dt: torch.dtype) -> bool:
+    return k <= 64 and Rin <= 64 and n <= max_qr_cols(dt) and k * I >= n
+
+
+def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
+    """Factor the left unfolding of ``Rm @ core`` (Rm [batch, k, Rin], core [batch, Rin, I, n]) without forming it."""
+    L = lib()
+    dt = dtype_code(core4.dtype)
+    Rm, ldrm, sRm = _mat(Rm)
+    core4 = core4.contiguous()
+    batch, Rin, I, n = core4.shape
+    k = Rm.shape[1]
+    assert Rm.shape[2] == Rin and Rm.shape[0] == batch
+    kq = min(k * I, n)
+    R = torch.empty((batch, kq, n), dtype=core4.dtype, device=core4.device)
+    wsb = L.ttr_qr_pushed_workspace_bytes(dt, I, n, max(batch, 1))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=core4.device)
+    if batch > 0:
+        code = L.ttr_qr_factor_pushed(dt, k, Rin, I, n, batch, Rm.data_ptr(), ldrm, sRm, core4.data_ptr(), Rin * I * n,
+                                      R.data_ptr(), n, kq * n, ws.data_ptr(), wsb, _stream())
+        _check(code, "ttr_qr_factor_pushed")
+    return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I))
+
+
 def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None) -> torch.Tensor:
     """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q)."""
     L = lib()
@@ -250,6 +287,12 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
         ldc, sC, cptr = 0, 0, None
     Out = torch.empty((f.batch, f.m, kcols), dtype=f.dtype, device=f.ws.device)
     if f.batch == 0:
+        return Out
+    if f.pushed is not None:
+        k, I = f.pushed
+        code = L.ttr_qr_apply_pushed(dt, k, I, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
+                                     Out.data_ptr(), kcols, f.m * kcols, _stream())
+        _check(code, "ttr_qr_apply_pushed")
         return Out
     code = L.ttr_qr_apply(dt, f.m, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
                           Out.data_ptr(), kcols, f.m * kcols, _stream())

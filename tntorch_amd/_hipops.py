@@ -198,14 +198,25 @@ def round_tt(
     c = list(cores4)
     N = len(c)
     facs = []
-    for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit)
+    Rprev = None  # R factor still to be pushed into the current core
+    for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
         Bt, r0, I, r1 = c[mu].shape
-        f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1))
-        facs.append((f, r0, I))
-        nxt = c[mu + 1]
-        pushed = _hip.gemm(f.R, nxt.reshape(Bt, nxt.shape[1], nxt.shape[2] * nxt.shape[3]))
-        c[mu + 1] = pushed.reshape(Bt, f.k, nxt.shape[2], nxt.shape[3])
+        if Rprev is None:
+            f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1))
+            rows_k = r0
+        elif _hip.pushed_supported(Rprev.shape[1], r0, I, r1, c[mu].dtype):
+            f = _hip.qr_factor_pushed(Rprev, c[mu])  # QR of (Rprev @ core) without materialising it
+            rows_k = Rprev.shape[1]
+        else:
+            pushed = _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1)).reshape(Bt, Rprev.shape[1], I, r1)
+            f = _hip.qr_factor(pushed.reshape(Bt, Rprev.shape[1] * I, r1))
+            rows_k = Rprev.shape[1]
+        facs.append((f, rows_k, I))
+        Rprev = f.R
         c[mu] = None
+    last = c[N - 1]
+    c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
+        last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
     if batch:  # tensor.py:2036-2037
         delta = None
     else:  # tensor.py:2039-2051

@@ -132,6 +132,13 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
                       int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
                       hipStream_t stream);
 int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
+int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch);
+int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
+                              int64_t ldrm, int64_t strideRm, const void* Cn, int64_t strideCn, void* R, int64_t ldr,
+                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
+int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
+                             const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
+                             int64_t strideO, hipStream_t stream);
 int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
@@ -208,6 +215,32 @@ int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_
   if (rc != TTR_OK || batch == 0) return rc;
   return ttr_qr_apply(dtype, m, n, batch, workspace, workspace_bytes, nullptr, 0, 0, m < n ? m : n, Q, ldq, strideQ,
                       stream);
+}
+
+int64_t ttr_qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {
+  return qr_pushed_workspace_bytes(dtype, I, n, batch);
+}
+
+int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
+                         int64_t ldrm, int64_t strideRm, const void* core, int64_t stride_core, void* R, int64_t ldr,
+                         int64_t strideR, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_factor_pushed: bad dtype %d", dtype);
+  TTR_REQUIRE(batch >= 0, TTR_E_INVALID, "ttr_qr_factor_pushed: negative batch");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Rm && core && R && workspace, TTR_E_INVALID, "ttr_qr_factor_pushed: null pointer");
+  return qr_factor_pushed_dispatch(dtype, k, Rin, I, n, batch, Rm, ldrm, strideRm, core, stride_core, R, ldr, strideR,
+                                   workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* workspace,
+                        int64_t workspace_bytes, const void* C, int64_t ldc, int64_t strideC, int64_t kcols, void* Out,
+                        int64_t ldo, int64_t strideO, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_apply_pushed: bad dtype %d", dtype);
+  TTR_REQUIRE(batch >= 0 && kcols >= 1 && kcols <= n, TTR_E_INVALID, "ttr_qr_apply_pushed: bad arguments");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Out && workspace, TTR_E_INVALID, "ttr_qr_apply_pushed: null pointer");
+  return qr_apply_pushed_dispatch(dtype, k, I, n, batch, workspace, workspace_bytes, C, ldc, strideC, kcols, Out, ldo,
+                                  strideO, (hipStream_t)stream);
 }
 
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return eigh_workspace_bytes(dtype, n, batch); }

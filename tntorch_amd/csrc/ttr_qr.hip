@@ -52,6 +52,13 @@ struct QrLevel {
   T* Rout;             // the block's R: next level's X (row block b*n) or the user's R
   int64_t ldr, strideR;
   int top;             // 1: single block, writes k x n to the user's R
+  // PUSHED level 0: the factored matrix is the left unfolding of  P[kk,i,c] = sum_r0 Rm[kk,r0] C[r0,i,c]
+  // (tensor.py:1826-1832 fused into the next QR): block b owns rows {(kk, i): i = 4b + wave}
+  const T* Rm;         // [pk x pRin], leading dimension ldrm
+  int64_t ldrm, strideRm;
+  const T* Cn;         // next core [pRin][pI][n] contiguous
+  int64_t strideCn;
+  int pk, pRin, pI;
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -75,7 +82,7 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 }
 
 // ---------------------------------------------------------------- factor
-template <typename T, int NT>
+template <typename T, int NT, bool PUSHED>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
@@ -99,17 +106,55 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
   const int kb = rows < n ? rows : n;
   auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
-  const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
   Acc acc[4][NT];
+  if constexpr (PUSHED) {
+    // acc <- Rm (pk x pRin) * C[:, i, :] (pRin x n) for this wave's mode index i = 4b + wave: the wave's 64
+    // rows are exactly (kk = 0..63, i).  Rm^T is staged once in LDS (aliasing Vs, conflict-free A-operand
+    // reads), the core slice is read from global directly in MFMA B-operand layout.
+    T* Rs = Vs;  // [r0][kk], 64 x 64 (Vs holds 256 x 17)
+    const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int kk = idx >> 6, r0 = idx & 63;
+      Rs[r0 * 64 + kk] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
+    }
+    __syncthreads();
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < NT; ++tn)
+      for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
+    const int imode = b * 4 + wave;
+    const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
+    const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
+    const bool ivalid = imode < p.pI;
+    const int ksteps = (p.pRin + 3) >> 2;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int r0 = ks * 4 + g;
+      T bv[NT], av[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rowl(tm, r), col = tn * PW + cl;
-        acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
+      for (int tn = 0; tn < NT; ++tn) {
+        const int col = tn * PW + cl;
+        bv[tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
       }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[r0 * 64 + tm * 16 + cl];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[tn], acc[tm][tn]);
+    }
+    __syncthreads();  // Rs aliases Vs
+  } else {
+    const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rowl(tm, r), col = tn * PW + cl;
+          acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
+        }
+  }
   const int64_t blk = bt * p.nb + b;
   T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
   T* __restrict__ tau = p.tau + blk * (int64_t)NP;
@@ -309,6 +354,7 @@ struct QrApply {
   int64_t ldtop, strideTop;
   T* Out;
   int64_t ldout, strideOut;
+  int pk, pI;    // > 0: level 0 of a PUSHED factorisation, local row (wave, kk) <-> global row kk * pI + 4b + wave
 };
 
 template <typename T, int NT, int NTC>
@@ -418,16 +464,30 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
     __syncthreads();  // Vs / Ts / W2s are rewritten by the next panel
   }
 
-  T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
+  if (p.pI > 0) {
+    T* __restrict__ Out = p.Out + bt * p.strideOut;
+    const int imode = b * 4 + wave;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-    for (int tc = 0; tc < NTC; ++tc)
+      for (int tc = 0; tc < NTC; ++tc)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rowl(tm, r), col = tc * PW + cl;
-        if (row < rows && col < kc) Out[(int64_t)row * p.ldout + col] = C[tm][tc][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int kk = tm * 16 + M::row(lane, r), col = tc * PW + cl;
+          if (kk < p.pk && imode < p.pI && col < kc) Out[((int64_t)kk * p.pI + imode) * p.ldout + col] = C[tm][tc][r];
+        }
+  } else {
+    T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rowl(tm, r), col = tc * PW + cl;
+          if (row < rows && col < kc) Out[(int64_t)row * p.ldout + col] = C[tm][tc][r];
+        }
+  }
 }
 
 // ---------------------------------------------------------------- host-side tree
@@ -476,12 +536,22 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   return make_plan(m, n, batch).total * (dtype == TTR_F64 ? 8 : 4);
 }
 
+struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
+  const void* Rm = nullptr;
+  int64_t ldrm = 0, strideRm = 0;
+  const void* Cn = nullptr;
+  int64_t strideCn = 0;
+  int k = 0, Rin = 0, I = 0;
+};
+
 template <typename T, int NT>
 static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* R, int64_t ldr,
-                      int64_t strideR, T* ws, const QrPlan& pl, hipStream_t stream) {
+                      int64_t strideR, T* ws, const QrPlan& pl, const Pushed& pu, hipStream_t stream) {
   const int L = pl.levels;
   for (int l = 0; l < L; ++l) {
     QrLevel<T> p;
+    p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
+    p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
     p.X = l == 0 ? A : ws + pl.off_x[l];
     p.ldx = l == 0 ? lda : n;
     p.strideX = l == 0 ? strideA : pl.m[l] * n;
@@ -493,7 +563,10 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-    hipLaunchKernelGGL((qr_factor_kernel<T, NT>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
+    if (l == 0 && pu.Rm)
+      hipLaunchKernelGGL((qr_factor_kernel<T, NT, true>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
+    else
+      hipLaunchKernelGGL((qr_factor_kernel<T, NT, false>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
@@ -501,7 +574,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
 
 template <typename T, int NT, int NTC>
 static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const QrPlan& pl, const T* C, int64_t ldc,
-                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
+                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, hipStream_t stream) {
   const int L = pl.levels;
   for (int l = L - 1; l >= 0; --l) {
     QrApply<T> p;
@@ -513,6 +586,7 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     else { p.Top = ws + pl.off_out[l + 1]; p.ldtop = kc; p.strideTop = pl.m[l + 1] * n; }
     if (l == 0) { p.Out = Out; p.ldout = ldo; p.strideOut = strideO; }
     else { p.Out = wsw + pl.off_out[l]; p.ldout = kc; p.strideOut = pl.m[l] * n; }
+    p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
     hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0,
                        stream, p);
@@ -523,29 +597,30 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
 
 template <typename T>
 static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
-                        int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                        int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, const Pushed& pu, hipStream_t stream) {
   const QrPlan pl = make_plan(m, n, batch);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
   TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_qr: batch %lld > 65535", (long long)batch);
   switch (nt_for(n)) {
-    case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
-    case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
-    default: return factor_run<T, 4>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, stream);
+    case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
+    case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
+    default: return factor_run<T, 4>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
   }
 }
 
 template <typename T, int NT>
 static int apply_nt(int64_t m, int n, int64_t batch, T* ws, const QrPlan& pl, const T* C, int64_t ldc, int64_t strideC,
-                    int kc, T* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
-  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
-  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
-  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, hipStream_t stream) {
+  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
+  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
+  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
 }
 
 template <typename T>
 static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
-                       int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, hipStream_t stream) {
+                       int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI,
+                       hipStream_t stream) {
   const QrPlan pl = make_plan(m, n, batch);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr_apply: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
@@ -553,9 +628,9 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
               (long long)kc);
   switch (nt_for(n)) {
-    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
-    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
-    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, stream);
+    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
+    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
+    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
   }
 }
 
@@ -565,8 +640,9 @@ int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const voi
                        void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, stream);
-  return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, stream);
+  const Pushed none;
+  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream);
+  return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream);
 }
 
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
@@ -574,8 +650,47 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
                       hipStream_t stream) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr_apply: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, stream);
-  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, stream);
+  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, stream);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, stream);
+}
+
+// Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/4)
+// zero-padded blocks of 256 rows (one mode index per wave), so the plan is that of a (256*ceil(I/4)) x n matrix.
+static int64_t pushed_rows(int64_t I) { return 256 * ceil_div(I, 4); }
+
+int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {
+  return qr_workspace_bytes(dtype, pushed_rows(I), n, batch);
+}
+
+static int pushed_ok(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n) {
+  TTR_REQUIRE(k >= 1 && k <= 64 && Rin >= 1 && Rin <= 64 && I >= 1 && n >= 1 && n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED,
+              "ttr_qr_*_pushed: k, Rin, n must be <= 64 (got %lld, %lld, %lld)", (long long)k, (long long)Rin, (long long)n);
+  TTR_REQUIRE(k * I >= n, TTR_E_UNSUPPORTED, "ttr_qr_*_pushed: needs k*I >= n (tall unfolding)");
+  return TTR_OK;
+}
+
+int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
+                              int64_t ldrm, int64_t strideRm, const void* Cn, int64_t strideCn, void* R, int64_t ldr,
+                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int rc = pushed_ok(dtype, k, Rin, I, n);
+  if (rc != TTR_OK) return rc;
+  Pushed pu;
+  pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Cn; pu.strideCn = strideCn;
+  pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
+  const int64_t m = pushed_rows(I);
+  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
+  return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
+}
+
+int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
+                             const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
+                             int64_t strideO, hipStream_t stream) {
+  const int rc = pushed_ok(dtype, k, 1, I, n);
+  if (rc != TTR_OK) return rc;
+  const int64_t m = pushed_rows(I);
+  if (dtype == TTR_F32)
+    return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, stream);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, stream);
 }
 
 }  // namespace ttr
