@@ -177,6 +177,9 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
 #define TTR_PROF_EIGH 3
 #define TTR_PROF_MISC 4
 #define TTR_PROF_NKINDS 5
+/* Diagnostics: when set to a device buffer of >= 64 int64, block (0,0) of every level-0 QR factor launch writes
+ * its s_memtime stamps at phase boundaries there.  NULL disables. */
+int ttr_debug_set_qr_stamps(void* device_buffer);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */
 int ttr_prof_collect(double* ms, int64_t* launches);

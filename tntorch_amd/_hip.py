@@ -82,6 +82,7 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
          c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_debug_set_qr_stamps": (c_int, [c_void_p]),
     "ttr_prof_enable": (c_int, [c_int]),
     "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
 }

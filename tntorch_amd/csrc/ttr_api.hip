@@ -147,6 +147,8 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int eigh_max_n_lds(int dtype);
 
+extern long long* g_qr_dbg;
+
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
 }  // namespace ttr
@@ -294,6 +296,11 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
                        cols, (const double*)in, ldi, stride_in, (const double*)sc, stride_s, mode, (double*)out, ldo,
                        stride_out);
   TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int ttr_debug_set_qr_stamps(void* device_buffer) {
+  g_qr_dbg = (long long*)device_buffer;
   return TTR_OK;
 }
 

@@ -67,6 +67,18 @@ struct Mfma<double> {
   static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 
+// ------------------------------------------------------------------ LDS-only workgroup barrier
+// __syncthreads() also drains vmcnt: every in-flight GLOBAL store / prefetch load has to land before any
+// wave may pass.  In the sequential Householder steps that exposes the full HBM write latency of the
+// fire-and-forget reflector stores once per step (measured: 55 % of wave cycles in SQ_WAIT_ANY, ~2800 cycles
+// per step for ~100 VALU instructions), and in the apply kernel it kills the panel prefetch.  When only LDS
+// traffic has to be ordered, waiting for lgkmcnt alone is sufficient.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------ wave reductions
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -104,6 +116,21 @@ __device__ __forceinline__ T wave_sum_dpp(T v) {
   v += dpp_mov<0x141>(v);  // row_half_mirror
   v += dpp_mov<0x140>(v);  // row_mirror
   return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+
+// Four independent wave sums at once: the DPP / readlane chains of the four values interleave.
+template <typename T>
+__device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0xB1>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x4E>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x141>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x140>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = (lane_get(v[c], 0) + lane_get(v[c], 16)) + (lane_get(v[c], 32) + lane_get(v[c], 48));
 }
 
 template <typename T>

@@ -59,6 +59,7 @@ struct QrLevel {
   const T* Cn;         // next core [pRin][pI][n] contiguous
   int64_t strideCn;
   int pk, pRin, pI;
+  long long* dbg;      // optional: cycle stamps of block (0,0) at phase boundaries (diagnostics)
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -83,14 +84,15 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 
 // ---------------------------------------------------------------- factor
 template <typename T, int NT, bool PUSHED>
-__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_kernel(QrLevel<T> p) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
   constexpr int NP = PW * NT;  // padded column count
   __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];       // current panel's reflectors [row][j]
   __shared__ T taus[NP];
   __shared__ T Ts[PW * VLD], Ss[PW * VLD];
-  __shared__ T Wp[4][PW][NP];                                   // per-wave partial W (also S partials)
+  constexpr int WPC = NP > 2 * PW ? NP - PW : PW;               // W only exists for the trailing column tiles (tn >= 1)
+  __shared__ T Wp[4][PW][WPC];                                  // per-wave partial W (also S partials): 4 WGs per CU
   __shared__ T W2s[PW][NP + 1];
 
   const int tid = threadIdx.x;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
       const int kk = idx >> 6, r0 = idx & 63;
       Rs[r0 * 64 + kk] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[tn], acc[tm][tn]);
     }
-    __syncthreads();  // Rs aliases Vs
+    lds_barrier();  // Rs aliases Vs
   } else {
     const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
 #pragma unroll
@@ -155,6 +157,9 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
           acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
         }
   }
+  int dbgi = 0;
+  auto stamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  stamp();
   const int64_t blk = bt * p.nb + b;
   T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
   T* __restrict__ tau = p.tau + blk * (int64_t)NP;
@@ -173,75 +178,105 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
     // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
     // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
     T pc[4][4];  // [column 4w+cc][row lane + 64 q]
-    if (pnl > 0) __syncthreads();  // the previous panel's MFMA update may still be reading Vs
+    if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Vs[rowl(tm, r) * VLD + cl] = acc[tm][pnl][r];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
       for (int q = 0; q < 4; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * 4 + cc];
-    __syncthreads();  // all columns are in registers before reflectors start overwriting Vs
+    lds_barrier();  // all columns are in registers before reflectors start overwriting Vs
+    stamp();
     if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
       for (int j = nsteps; j < PW; ++j) Vs[tid * VLD + j] = T(0);
     }
-    // The 16 steps are expanded at compile time (J is a constant: the owner's column pc[oc] must be a
-    // static register index, and LLVM does not unroll a loop whose body contains the barrier).
-    auto step = [&](auto J) {
-      constexpr int j = decltype(J)::value;
-      if (j < nsteps) {  // block-uniform
-        const int jj = j0 + j;
-        const int ow = j >> 2, oc = j & 3;
-        T v[4];
-        if (wave_id == ow) {  // wave-uniform: the owner of column jj builds the reflector
-          T ss = (lane > jj) ? pc[oc][0] * pc[oc][0] : T(0);
+    // Steps: a RUNTIME loop over the owner wave (4); the owner factors its FOUR columns locally (build a
+    // reflector, apply it to its remaining columns, ... -- all wave-local, no barrier), publishes the four
+    // reflectors, and after ONE barrier the waves to its right apply them to their own columns.  A panel costs
+    // 4 barrier phases instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
+    for (int owv = 0; owv < 4; ++owv) {
+      if (owv * 4 < nsteps) {  // block-uniform
+        if (wave_id == owv) {  // wave-uniform: local Householder QR of columns 4*owv .. 4*owv+3
+          auto local = [&](auto OC) {
+            constexpr int oc = decltype(OC)::value;
+            const int j = owv * 4 + oc;
+            if (j < nsteps) {
+              const int jj = j0 + j;
+              T ss = (lane > jj) ? pc[oc][0] * pc[oc][0] : T(0);
 #pragma unroll
-          for (int q = 1; q < 4; ++q) ss += pc[oc][q] * pc[oc][q];
-          ss = wave_sum_dpp(ss);
-          const T alpha = lane_get(pc[oc][0], jj);
-          T beta, tj, scale;
-          if (ss == T(0)) {  // LAPACK larfg: H = I
-            beta = alpha; tj = T(0); scale = T(0);
-          } else {
-            larfg_scalars(alpha, ss, beta, tj, scale);
-          }
-          v[0] = (lane > jj) ? pc[oc][0] * scale : (lane == jj ? T(1) : T(0));
+              for (int q = 1; q < 4; ++q) ss += pc[oc][q] * pc[oc][q];
+              ss = wave_sum_dpp(ss);
+              const T alpha = lane_get(pc[oc][0], jj);
+              T beta, tj, scale;
+              if (ss == T(0)) {  // LAPACK larfg: H = I
+                beta = alpha; tj = T(0); scale = T(0);
+              } else {
+                larfg_scalars(alpha, ss, beta, tj, scale);
+              }
+              T v[4];
+              v[0] = (lane > jj) ? pc[oc][0] * scale : (lane == jj ? T(1) : T(0));
 #pragma unroll
-          for (int q = 1; q < 4; ++q) v[q] = pc[oc][q] * scale;
+              for (int q = 1; q < 4; ++q) v[q] = pc[oc][q] * scale;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            Vs[(lane + 64 * q) * VLD + j] = v[q];
-            Vt[(int64_t)jj * BR + lane + 64 * q] = v[q];  // coalesced, fire and forget
-          }
-          if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
-          if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
+              for (int q = 0; q < 4; ++q) {
+                Vs[(lane + 64 * q) * VLD + j] = v[q];
+                Vt[(int64_t)jj * BR + lane + 64 * q] = v[q];  // coalesced, fire and forget
+              }
+              if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
+              if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
+              if constexpr (oc < 3) {  // apply to the owner's remaining columns
+                T d4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int cc = oc + 1; cc < 4; ++cc) {
+                  d4[cc] = v[0] * pc[cc][0];
+#pragma unroll
+                  for (int q = 1; q < 4; ++q) d4[cc] += v[q] * pc[cc][q];
+                }
+                wave_sum_dpp4(d4);
+#pragma unroll
+                for (int cc = oc + 1; cc < 4; ++cc) {
+                  const T f = tj * d4[cc];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
+                }
+              }
+            }
+          };
+          local(IC<0>{}); local(IC<1>{}); local(IC<2>{}); local(IC<3>{});
         }
-        __syncthreads();  // reflector jj (column j of Vs) and its tau are visible
-        if (wave_id >= ow && j0 + wave_id * 4 < n) {  // waves that still own columns right of jj
-          if (wave_id != ow) {
+        lds_barrier();  // reflectors 4*owv .. 4*owv+3 (columns of Vs) and their taus are visible
+        if (wave_id > owv && j0 + wave_id * 4 < n) {  // waves right of the owner apply the four reflectors
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = Vs[(lane + 64 * q) * VLD + j];
-          }
-          const T tj = taus[jj];
+          for (int rf = 0; rf < 4; ++rf) {
+            const int j = owv * 4 + rf;
+            if (j < nsteps) {
+              T v[4];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int col = wave_id * 4 + cc;  // panel-local column
-            if (col > j && j0 + col < n) {     // wave-uniform
-              T d = v[0] * pc[cc][0];
+              for (int q = 0; q < 4; ++q) v[q] = Vs[(lane + 64 * q) * VLD + j];
+              const T tj = taus[j0 + j];
+              T d4[4];
 #pragma unroll
-              for (int q = 1; q < 4; ++q) d += v[q] * pc[cc][q];
-              const T f = tj * wave_sum_dpp(d);
+              for (int cc = 0; cc < 4; ++cc) {
+                d4[cc] = v[0] * pc[cc][0];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
+                for (int q = 1; q < 4; ++q) d4[cc] += v[q] * pc[cc][q];
+              }
+              wave_sum_dpp4(d4);
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                const T f = tj * d4[cc];  // columns >= n are all-zero: d = 0, no effect
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
+              }
             }
           }
         }
       }
-    };
-    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
-    step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{}); step(IC<12>{}); step(IC<13>{}); step(IC<14>{}); step(IC<15>{});
+    }
+    stamp();
     {
       // R rows of this panel: row i (< 64) of column 4w+cc sits in lane i, q = 0
       T* __restrict__ Ro = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
@@ -256,7 +291,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
       Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
       if (tid == 0) tau[j0 + j] = T(0);
     }
-    __syncthreads();
+    lds_barrier();
     // (5) S = V^T V over the block (MFMA, K = 256 split over the 4 waves), then the triangular factor T
     {
       Acc s = M::zero();
@@ -268,12 +303,12 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][cl] = s[r];
     }
-    __syncthreads();
+    lds_barrier();
     {
       const int i = tid >> 4, k = tid & 15;
       Ss[i * VLD + k] = (Wp[0][i][k] + Wp[1][i][k]) + (Wp[2][i][k] + Wp[3][i][k]);
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < PW) {  // larft (forward, columnwise): T[0:j,j] = -tau_j T[0:j,0:j] S[0:j,j], T[j][j] = tau_j
       const int i = tid;
       T trow[PW];
@@ -288,7 +323,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
         Tg[pnl * PW * PW + i * PW + jc] = trow[jc];
       }
     }
-    __syncthreads();
+    lds_barrier();
+    stamp();
     if (pnl < NT - 1 && (pnl + 1) * PW < n) {
       // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand
 #pragma unroll
@@ -299,16 +335,16 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
 #pragma unroll
           for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], acc[tm][tn][s], wa);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tn * PW + cl] = wa[r];
+        for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][(tn - 1) * PW + cl] = wa[r];
       }
-      __syncthreads();
+      lds_barrier();
       // W2 = -T^T (sum of the partials)
       {
         const int jc = tid & 63, i4 = tid >> 6;
         if (jc < NP && jc >= (pnl + 1) * PW) {
           T ws[PW];
 #pragma unroll
-          for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+          for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc - PW] + Wp[1][k][jc - PW]) + (Wp[2][k][jc - PW] + Wp[3][k][jc - PW]);
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii) {
             const int i = i4 * 4 + ii;
@@ -319,7 +355,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       // (7) A2 += V W2
 #pragma unroll
       for (int tn = pnl + 1; tn < NT; ++tn)
@@ -330,14 +366,14 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 3 : 1)) void qr_factor_
             acc[tm][tn] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * VLD + ks * 4 + g], W2s[ks * 4 + g][tn * PW + cl],
                                  acc[tm][tn]);
     }
+    stamp();
     // the next panel's first barrier orders (7)'s LDS reads before Vs / W2s are rewritten
   };
   panel(IC<0>{});
   if constexpr (NT > 1) panel(IC<1>{});
   if constexpr (NT > 2) panel(IC<2>{});
   if constexpr (NT > 3) panel(IC<3>{});
-  __syncthreads();
-
+  lds_barrier();
 }
 
 // ---------------------------------------------------------------- apply (form Q [C;0] top-down)
@@ -364,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
   constexpr int NP = PW * NT;
   constexpr int NC = PW * NTC;
   __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];
-  __shared__ T Ts[PW * VLD];
+  __shared__ T Ts[PW * VLD];   // compact-WY factor T of the current panel
   __shared__ T Wp[4][PW][NC];
   __shared__ T W2s[PW][NC + 1];
 
@@ -421,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
       for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((pnl - 1) * PW + j) * BR + tid];
       treg = Tg[(pnl - 1) * PW * PW + tid];
     }
-    __syncthreads();
+    lds_barrier();
     // W = V^T C (per-wave partial over its 64 rows)
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc) {
@@ -433,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tc * PW + cl] = wa[r];
     }
-    __syncthreads();
+    lds_barrier();
     // W2 = -T W
     {
       const int jc = tid & 63, i4 = tid >> 6;
@@ -451,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // C += V W2
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc)
@@ -461,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
         for (int ks = 0; ks < 4; ++ks)
           C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * VLD + ks * 4 + g], W2s[ks * 4 + g][tc * PW + cl],
                              C[tm][tc]);
-    __syncthreads();  // Vs / Ts / W2s are rewritten by the next panel
+    lds_barrier();  // Vs / Ts / W2s are rewritten by the next panel
   }
 
   if (p.pI > 0) {
@@ -536,6 +572,8 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   return make_plan(m, n, batch).total * (dtype == TTR_F64 ? 8 : 4);
 }
 
+long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
+
 struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
   const void* Rm = nullptr;
   int64_t ldrm = 0, strideRm = 0;
@@ -550,6 +588,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
   const int L = pl.levels;
   for (int l = 0; l < L; ++l) {
     QrLevel<T> p;
+    p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
     p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
     p.X = l == 0 ? A : ws + pl.off_x[l];
