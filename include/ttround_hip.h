@@ -45,6 +45,11 @@ extern "C" {
 /* eigenvalue post-processing modes for ttr_eigh_trunc */
 #define TTR_EIG_RAW 0   /* sigma = sqrt(max(w, 0)) */
 #define TTR_EIG_REF 1   /* round.py:118-119: w < 0 -> 1e-8 before the sqrt */
+#define TTR_EIG_MATCH_DIAG 2 /* like RAW, but NOT sorted: V -> I as G -> diagonal.  Tridiagonal solver: the
+                                eigenvector of the r-th largest eigenvalue is written to the column holding
+                                the r-th largest diagonal entry of G; Jacobi: eigenpair i stays in column i
+                                (rotation angles <= pi/4 never swap).  Building block of the block-Jacobi
+                                driver for n above the single-workgroup limit. */
 
 int ttr_version(void);
 const char* ttr_last_error(void);
@@ -144,6 +149,7 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
  * reduction + implicit-shift QL, one wave per matrix, absolute accuracy O(eps*||G||) like LAPACK steqr):
  * ~10x fewer flops, used for the first pass / 'eig'; larger n falls back to Jacobi with abs_floor = 1.
  * `sweeps` (optional, [batch]) receives the number of sweeps (Jacobi) / QL iterations used.
+ * eig_mode = TTR_EIG_MATCH_DIAG: see above (sigma[b] then follows V's column order; info as usual).
  */
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,

@@ -153,6 +153,49 @@ def test_eigh(dt, n, solver):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("solver", [1, 2])
+@pytest.mark.parametrize("n", [7, 40, 64])
+def test_eigh_match_diag(dt, n, solver):
+    """TTR_EIG_MATCH_DIAG: same eigenpairs, but column order follows G's diagonal, so a nearly diagonal G
+    gives V ~ I (up to sign) -- the property the block-Jacobi driver needs from its pair solver."""
+    h = _hip()
+    g = torch.Generator().manual_seed(100 + n)
+    d = (torch.stack([torch.randperm(n, generator=g) for _ in range(2)]) + 1).double()   # gaps >= 1
+    E = torch.randn(2, n, n, generator=g, dtype=torch.float64) * 1e-3
+    G = (torch.diag_embed(d) + E + E.transpose(1, 2)).to(dt)
+    V, sig, info = h.eigh_trunc(G.cuda(), h.EIG_MATCH_DIAG, False, 0.0, n, abs_floor=solver)
+    V, sig = V.cpu().double(), sig.cpu().double()
+    eye = torch.eye(n, dtype=torch.float64)
+    assert (V.abs() - eye).abs().max() < 2e-2                      # near-identity, no sorting swaps
+    assert (sig**2 - d).abs().max() < 2e-2                         # sigma follows the column order
+    resid = (G.double() @ V - V * (sig**2)[:, None, :]).abs().max() / d.max()
+    assert resid < tol(dt, 2e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n,B,solver", [(128, 2, 2), (150, 1, 2), (288, 1, 2), (512, 1, 2), (128, 2, 1), (150, 1, 1)])
+def test_eigh_block_jacobi(dt, n, B, solver):
+    """Large-n driver (_hipops._eigh_any): block Jacobi over pair problems + sorted epilogue.
+    solver 2: tridiagonal pair solver, absolute stop test; solver 1: Jacobi pair solver, relative stop test."""
+    from tntorch_amd import _hipops
+    h = _hip()
+    g = torch.Generator().manual_seed(n)
+    Mx = torch.randn(B, n, 2 * n + 1, generator=g, dtype=torch.float64)
+    Mx = Mx * torch.logspace(0, -3, n, dtype=torch.float64)[None, :, None]
+    G = (Mx @ Mx.transpose(1, 2)).to(dt)
+    V, sig, info = _hipops._eigh_any(G.cuda(), h.EIG_RAW, False, 0.0, n, solver)
+    V, sig, info = V.cpu().double(), sig.cpu().double(), info.cpu()
+    wref = torch.linalg.eigvalsh(G.double()).flip(-1).clamp_min(0)
+    assert (info == n).all()
+    assert (sig[:, :-1] >= sig[:, 1:]).all()
+    assert ((sig**2 - wref).abs().max(dim=1).values / wref[:, 0]).max() < tol(dt, 4e-6, 1e-13)
+    eye = torch.eye(n, dtype=torch.float64)
+    assert (V.transpose(1, 2) @ V - eye).abs().max() < tol(dt, 3e-5, 1e-12)
+    resid = (G.double() @ V - V * (sig**2)[:, None, :]).abs().max() / wref.max()
+    assert resid < tol(dt, 3e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_eigh_rank_rule(dt):
     """Rank rule of round.py:147-158 on a diagonal matrix with known sigma."""
     h = _hip()

@@ -210,6 +210,26 @@ def test_ref_gpu_tt():
     assert torch.abs(y1 - y2).max() < 1e-5
 
 
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+@pytest.mark.parametrize("shape,r,dt", [([16] * 4, 8, torch.float64), ([32] * 4, 16, torch.float32)])
+def test_dense_large_bond(shape, r, dt, alg):
+    """Dense -> TT with I*r = 128 / 512: the bond eigenproblems exceed one workgroup and run through the
+    block-Jacobi driver (C1's structure at a size the oracle finishes in seconds)."""
+    torch.manual_seed(5)
+    low = oracle.tt_to_dense(oracle.tt_randn(shape, r, dtype=torch.float64))   # TT rank r + noise below it
+    X = (low / low.norm() + 1e-3 * torch.randn(shape, dtype=torch.float64) / math.sqrt(low.numel())).to(dt)
+    ref = oracle.dense_to_tt(X, r, algorithm=alg)
+    t = tn.Tensor(X, ranks_tt=r, device="cuda", algorithm=alg)
+    assert list(t.ranks_tt) == ranks(ref)
+    e_o = rel_diff(t.torch().cpu().double(), X.double())
+    e_r = rel_diff(oracle.tt_to_dense([c.double() for c in ref]), X.double())
+    # truncation error within 1 % (fp32) / 1e-6 (fp64) of the reference algorithm's
+    assert e_o <= e_r * (1 + (1e-2 if dt == torch.float32 else 1e-6)) + (2e-6 if dt == torch.float32 else 1e-12), (e_o, e_r)
+    for k, c in enumerate(t.cores[1:], 1):   # right-orthonormal cores (sweep ends at core 0)
+        M = c.reshape(c.shape[0], -1).double().cpu()
+        assert (M @ M.T - torch.eye(M.shape[0], dtype=torch.float64)).abs().max() < (3e-5 if dt == torch.float32 else 1e-11)
+
+
 def test_quirks():
     # default eps=1e-14 drops exactly-zero tails even with rmax (SURVEY A-1)
     t = tn.Tensor(torch.ones(4, 4, 4, dtype=torch.float64).cuda(), ranks_tt=3)

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
-EIG_RAW, EIG_REF = 0, 1
+EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG = 0, 1, 2  # `abs_floor` argument of ttr_eigh_trunc
 PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc")
 

@@ -46,6 +46,141 @@ def qr(A3: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return _hip.qr(A3)
 
 
+# ----------------------------------------------------------------------------------------------
+# Symmetric eigenproblems too large for one workgroup: block Jacobi over the whole GPU.
+#
+# G (n x n) is cut into blocks of b <= 32 columns; a round pairs the blocks (round-robin), the 2b x 2b
+# diagonal pair problems are diagonalised by the single-wave tridiagonal-QL kernel (batched over pairs and
+# matrices) and the pair rotations are applied with the MFMA GEMM:  G <- W^T G W,  V <- V W.  Pairs are kept
+# physically adjacent by permuting the block order between rounds (gather copies -- layout only).
+_BJ_MAX_SWEEPS = 12
+
+
+def _bj_block(n: int) -> Optional[int]:
+    for b in range(32, 7, -1):
+        if n % b == 0 and n // b >= 2:
+            return b
+    return None
+
+
+def _pair_cols(X: torch.Tensor, W: torch.Tensor, npairs: int, w: int) -> torch.Tensor:
+    """X[:, :, p*w:(p+1)*w] <- X[:, :, p*w:(p+1)*w] @ W[b, p]  for the first npairs*w columns."""
+    Bt, rows, n = X.shape
+    used = npairs * w
+    A = X[:, :, :used].reshape(Bt, rows, npairs, w).permute(0, 2, 1, 3).reshape(Bt * npairs, rows, w)
+    out = _hip.gemm(A.contiguous(), W)  # [Bt*npairs, rows, w]
+    out = out.reshape(Bt, npairs, rows, w).permute(0, 2, 1, 3).reshape(Bt, rows, used)
+    if used == n:
+        return out.contiguous()
+    return torch.cat([out, X[:, :, used:]], dim=2)
+
+
+def _pair_rows(X: torch.Tensor, W: torch.Tensor, npairs: int, w: int) -> torch.Tensor:
+    """X[:, p*w:(p+1)*w, :] <- W[b, p]^T @ X[:, p*w:(p+1)*w, :]."""
+    Bt, n, cols = X.shape
+    used = npairs * w
+    A = X[:, :used, :].reshape(Bt * npairs, w, cols)
+    out = _hip.gemm(W, A, transA=True).reshape(Bt, used, cols)
+    if used == n:
+        return out
+    return torch.cat([out, X[:, used:, :]], dim=1)
+
+
+def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eigen-decomposition of symmetric [B, n, n] (n a multiple of a block size in 8..32).
+
+    Returns (V [B, n, n] orthogonal, d [B, n] eigenvalues, unsorted).
+    ``relative=False``: pair problems by tridiagonal QL, stop when ||offdiag|| <= sqrt(n)/2 eps ||G||
+    (absolute accuracy O(eps ||G||): pass 1 / 'eig').  ``relative=True``: pair problems by the Jacobi kernel
+    with its relative rotation test, stop when a whole sweep found nothing to rotate (pass 2 of 'svd': G is
+    an accurately formed, nearly diagonal, graded Gram matrix and small eigenvalues keep relative accuracy).
+    """
+    Bt, n, _ = G.shape
+    b = _bj_block(n)
+    assert b is not None
+    nbk = n // b
+    w = 2 * b
+    dev, dt = G.device, G.dtype
+    G0 = G
+    G = G.clone()
+    V = torch.eye(n, dtype=dt, device=dev).repeat(Bt, 1, 1)
+    circle = list(range(nbk)) + ([-1] if nbk % 2 else [])  # -1: bye
+    phys = list(range(nbk))
+    ar = torch.arange(b, device=dev)
+    eps = torch.finfo(dt).eps
+    gnorm = _hip.norm(G.reshape(Bt, -1))
+    tol = 0.5 * math.sqrt(n) * eps
+    prev = None
+    for sweep in range(_BJ_MAX_SWEEPS):
+        worked = None
+        for _ in range(len(circle) - 1):
+            half = len(circle) // 2
+            pairs = [(circle[i], circle[-1 - i]) for i in range(half)]
+            bye = [x for pr in pairs if -1 in pr for x in pr if x != -1]
+            pairs = [pr for pr in pairs if -1 not in pr]
+            target = [x for pr in pairs for x in pr] + bye
+            if target != phys:  # physical re-ordering of block rows / columns (gather: layout only)
+                slot = {blk: i for i, blk in enumerate(phys)}
+                idx = torch.cat([slot[blk] * b + ar for blk in target])
+                G = G.index_select(1, idx).index_select(2, idx)
+                V = V.index_select(2, idx)
+                phys = target
+            npairs = len(pairs)
+            Gv = G[:, : npairs * w, : npairs * w].reshape(Bt, npairs, w, npairs, w)
+            S = torch.stack([Gv[:, p, :, p, :] for p in range(npairs)], dim=1).reshape(Bt * npairs, w, w)
+            if relative:
+                nsw = torch.zeros(Bt * npairs, dtype=torch.int32, device=dev)
+                W, _, _ = _hip.eigh_trunc(S.contiguous(), _hip.EIG_MATCH_DIAG, False, 0.0, w,
+                                          abs_floor=_hip.SOLVER_JACOBI_ABS, sweeps=nsw)
+                worked = nsw.max() if worked is None else torch.maximum(worked, nsw.max())
+            else:
+                W, _, _ = _hip.eigh_trunc(S.contiguous(), _hip.EIG_MATCH_DIAG, False, 0.0, w,
+                                          abs_floor=_hip.SOLVER_TRIDIAG)
+            G = _pair_cols(G, W, npairs, w)
+            G = _pair_rows(G, W, npairs, w)
+            V = _pair_cols(V, W, npairs, w)
+            circle = [circle[0], circle[-1]] + circle[1:-1]
+        if relative:  # one int32 readback per sweep (control flow only)
+            if int(worked.item()) == 0:
+                break
+            continue
+        # off-diagonal mass per matrix (one small readback per sweep; control flow only)
+        Goff = G.clone()
+        torch.diagonal(Goff, dim1=1, dim2=2).zero_()
+        ratio = float((_hip.norm(Goff.reshape(Bt, -1)) / gnorm.clamp_min(torch.finfo(dt).tiny)).max().item())
+        if ratio <= tol or (prev is not None and sweep >= 3 and ratio > 0.5 * prev):
+            break
+        prev = ratio
+    d = torch.diagonal(G, dim1=1, dim2=2).contiguous()
+    if dt == torch.float32:
+        # one Newton-Schulz step removes the orthogonality drift of the ~100 accumulated fp32 rotations
+        # E = 1.5 I - 0.5 V^T V as ONE GEMM on stacked operands: [V; I]^T [-0.5 V; 1.5 I]
+        eye = torch.eye(n, dtype=dt, device=dev).expand(Bt, n, n)
+        half = torch.full((Bt, n), -0.5, dtype=dt, device=dev)
+        Aa = torch.cat([V, eye], dim=1)
+        Ba = torch.cat([_hip.scale_cols(V, half, _hip.SCALE_MUL), torch.diag_embed(torch.full((Bt, n), 1.5, dtype=dt, device=dev))], dim=1)
+        V = _hip.gemm(V, _hip.gemm(Aa, Ba, transA=True))
+    if not relative:
+        # Rayleigh quotients against the ORIGINAL matrix: the ~100 two-sided fp updates of G accumulate
+        # O(100 eps ||G||) in its diagonal, v_i^T G0 v_i is second order in the eigenvector error
+        d = torch.diagonal(_hip.gemm(V, _hip.gemm(G0, V), transA=True), dim1=1, dim2=2).contiguous()
+    return V, d
+
+
+def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, cap: int, solver: int):
+    """Dispatch on the problem size: n <= 64 -> requested kernel; n <= LDS limit -> LDS Jacobi; larger ->
+    block Jacobi over the GPU, then one (rotation-free) pass of the Jacobi kernel for its epilogue
+    (clamp, sqrt, sort, rank rule)."""
+    n = G.shape[1]
+    lds_limit = _hip.lib().ttr_eigh_max_n_lds(_hip.dtype_code(G.dtype))
+    if n <= lds_limit or _bj_block(n) is None:
+        return _hip.eigh_trunc(G, eig_mode, use_delta, delta2, cap, abs_floor=solver)
+    Vb, d = eigh_block_jacobi(G, relative=(solver != _hip.SOLVER_TRIDIAG))
+    D = torch.diag_embed(d)
+    P, sig, info = _hip.eigh_trunc(D, eig_mode, use_delta, delta2, cap, abs_floor=_hip.SOLVER_JACOBI_ABS)
+    return _hip.gemm(Vb, P), sig, info
+
+
 class Truncation:
     """Result of ``truncate``: ``left_core`` (m x r), optional column scale, ``right`` (r x n)."""
 
@@ -92,12 +227,12 @@ def truncate(
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         if left_side:
             G = _hip.gemm(M, M, transB=True)
-            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG)
             Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
             G = _hip.gemm(Mw, Mw, transB=True)
         else:
             G = _hip.gemm(M, M, transA=True)
-            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG)
             Mw = _hip.gemm(M, V1)                        # M V1
             G = _hip.gemm(Mw, Mw, transA=True)
     else:
@@ -107,8 +242,9 @@ def truncate(
 
     # 'eig' (and pass 1 above): absolute accuracy is all a plain Gram matrix carries -> tridiagonal QL solver;
     # pass 2 of 'svd': graded, accurately formed Gram matrix -> Jacobi (relative accuracy of the small sigmas)
-    V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
-                                   abs_floor=_hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_ABS)
+    # (problems above the LDS limit go through the block-Jacobi driver in either pass: absolute accuracy)
+    V, sig, info = _eigh_any(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
+                             _hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_ABS)
     r = _select_rank(info, batch, rmax, k)
     if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
         z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)

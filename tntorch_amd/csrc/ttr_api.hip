@@ -255,6 +255,8 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t l
   TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(G && V && sigma && info, TTR_E_INVALID, "ttr_eigh_trunc: null pointer");
+  TTR_REQUIRE(eig_mode >= TTR_EIG_RAW && eig_mode <= TTR_EIG_MATCH_DIAG, TTR_E_INVALID, "ttr_eigh_trunc: bad eig_mode %d",
+              eig_mode);
   return eigh_dispatch(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
                        use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       pos += (sj > si) || (sj == si && j < i);
     }
     sig_sorted[pos] = si;
-    posv[i] = pos;
+    // TTR_EIG_MATCH_DIAG: Jacobi rotations (|angle| <= pi/4) never swap, eigenpair i stays in column i
+    posv[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? i : pos;
   }
   __syncthreads();
   T* __restrict__ V = p.V + bt * p.strideV;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
   }
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
-  for (int i = tid; i < n; i += kThreads) sout[i] = sig_sorted[i];
+  for (int i = tid; i < n; i += kThreads) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
   if (tid == 0) {
     int rank;
     const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale
-  T gd = (lane < n) ? fabs(G[(int64_t)lane * p.ldg + lane]) : T(0);
+  const T gdiag = (lane < n) ? G[(int64_t)lane * p.ldg + lane] : T(0);
+  T gd = fabs(gdiag);
   T gmax = gd;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
@@ -523,13 +525,37 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
     posv[lane] = pos;
   }
   __syncthreads();
+  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
+  if (p.eig_mode == TTR_EIG_MATCH_DIAG) {
+    // Column order for block-Jacobi drivers: the eigenvector of the r-th largest eigenvalue goes to the
+    // column holding the r-th largest diagonal entry of G, so that V -> I as G -> diagonal (no sorting
+    // swaps; this is what makes the outer block iteration converge).
+    int* colof = reinterpret_cast<int*>(sv);
+    cv[lane] = gdiag;
+    __syncthreads();
+    if (lane < n) {
+      int dpos = 0;
+      for (int j = 0; j < n; ++j) {
+        const T dj = cv[j];
+        dpos += (dj > gdiag) || (dj == gdiag && j < lane);
+      }
+      colof[dpos] = lane;
+    }
+    __syncthreads();
+    if (lane < n) {
+      const int c = colof[posv[lane]];
+      posv[lane] = c;
+      sout[c] = sig[lane];
+    }
+    __syncthreads();
+  } else if (lane < n) {
+    sout[lane] = sig_sorted[lane];
+  }
   T* __restrict__ V = p.V + bt * p.strideV;
   for (int idx = lane; idx < n * n; idx += kWave) {
     const int row = idx / n, j = idx - row * n;
     V[(int64_t)row * p.ldv + posv[j]] = A[row * ld + j];
   }
-  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
-  if (lane < n) sout[lane] = sig_sorted[lane];
   if (lane == 0) {
     int rank;
     const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
