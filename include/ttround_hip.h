@@ -81,6 +81,19 @@ int ttr_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              int64_t batch, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * C[b] <- beta * C[b] + alpha * op(A[b]) * op(B[b])   (same kernel; C is read only when beta != 0).
+ * Building block of the routines that extend the envelope of the kernels above: block Gram-Schmidt
+ * projections  W <- W - Q (Q^T W)  of the QR for n > ttr_qr_max_cols (torch.linalg.qr, tensor.py:1816/1853)
+ * and the Newton-Schulz step  V <- 1.5 V - 0.5 V (V^T V)  of the large-n eigensolver (round.py:115).
+ */
+int ttr_gemm_axpby(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                   const void* A, int64_t lda, int64_t strideA,
+                   const void* B, int64_t ldb, int64_t strideB,
+                   void* C, int64_t ldc, int64_t strideC,
+                   double alpha, double beta,
+                   int64_t batch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Reduced Householder QR of batch tall (or square/wide) matrices: A[b] (m x n) = Q[b] (m x k) R[b] (k x n),
  * k = min(m, n), LAPACK sign convention (geqrf: beta = -sign(alpha)*norm), R upper triangular/trapezoidal.
  * Replaces: torch.linalg.qr at tensor.py:1816 (left_orthogonalize) and tensor.py:1853/1859

@@ -242,6 +242,50 @@ def test_norm_and_scale(dt):
     assert torch.allclose(o, x / s[:, None, :], rtol=tol(dt, 1e-6, 1e-14))
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_axpby(dt):
+    h = _hip()
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K, B, tA, tB, al, be) in [(70, 33, 129, 2, False, False, -1.0, 1.0), (64, 64, 5000, 1, True, False, 0.5, 0.0),
+                                          (17, 90, 40, 3, False, True, 2.0, -0.25)]:
+        A = torch.randn(B, *((K, M) if tA else (M, K)), generator=g, dtype=torch.float64)
+        Bm = torch.randn(B, *((N, K) if tB else (K, N)), generator=g, dtype=torch.float64)
+        C = torch.randn(B, M, N, generator=g, dtype=torch.float64)
+        ref = be * C + al * ((A.transpose(1, 2) if tA else A) @ (Bm.transpose(1, 2) if tB else Bm))
+        Cd = C.to(dt).cuda()
+        out = h.gemm_axpby(A.to(dt).cuda(), Bm.to(dt).cuda(), Cd, al, be, transA=tA, transB=tB)
+        assert out.data_ptr() == Cd.data_ptr()
+        assert (out.cpu().double() - ref).abs().max() / ref.abs().max() < tol(dt, 2e-6, 1e-14)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("m,n,B", [(1000, 100, 2), (300, 200, 1), (128, 128, 1), (40, 150, 2), (100, 260, 1)])
+def test_qr_blocked(dt, m, n, B):
+    """QR above the 64-column TSQR panel: block Gram-Schmidt with re-orthogonalisation around the kernel."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(m + n)
+    A = torch.randn(B, m, n, generator=g, dtype=torch.float64).to(dt)
+    Q, R = _hipops.qr(A.cuda())
+    Q, R = Q.cpu().double(), R.cpu().double()
+    k = min(m, n)
+    assert Q.shape == (B, m, k) and R.shape == (B, k, n)
+    assert (Q.transpose(1, 2) @ Q - torch.eye(k, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 1e-12)
+    assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 2e-5, 1e-12)
+    assert torch.tril(R[:, :, :k], -1).abs().max() < tol(dt, 1e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_qr_blocked_rank_deficient(dt):
+    """Rank-96 matrix with 160 columns: Q must stay orthonormal (second Gram-Schmidt pass on the normalised panel)."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(1, 700, 96, generator=g, dtype=torch.float64) @ torch.randn(1, 96, 160, generator=g, dtype=torch.float64)).to(dt)
+    Q, R = _hipops.qr(A.cuda())
+    Q, R = Q.cpu().double(), R.cpu().double()
+    assert (Q.transpose(1, 2) @ Q - torch.eye(160, dtype=torch.float64)).abs().max() < tol(dt, 5e-5, 1e-11)
+    assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 2e-5, 1e-12)
+
+
 def test_unsupported_shapes_raise():
     h = _hip()
     with pytest.raises(NotImplementedError):

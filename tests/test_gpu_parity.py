@@ -230,6 +230,38 @@ def test_dense_large_bond(shape, r, dt, alg):
         assert (M @ M.T - torch.eye(M.shape[0], dtype=torch.float64)).abs().max() < (3e-5 if dt == torch.float32 else 1e-11)
 
 
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_round_rank_above_64(dt, alg):
+    """TT ranks above the 64-column TSQR panel (here 96: a rank-48 train added to itself): blocked QR with
+    explicit Q in the L2R sweep, 96 x 96 bond eigenproblems in the R2L sweep."""
+    torch.manual_seed(7)
+    g = oracle.tt_randn([12, 10, 12, 10, 12], 48, dtype=torch.float64)
+    inp = [c.to(dt) for c in oracle.tt_add(g, g)]
+    assert max(ranks(inp)) == 96
+    ref = oracle.round_tt([c.clone() for c in inp], rmax=48, algorithm=alg)
+    t = gpu_tensor(inp)
+    t.round_tt(rmax=48, algorithm=alg)
+    ours = to_list(t.cores)
+    assert ranks(ours) == ranks(ref)
+    tolr = 3e-5 if dt == torch.float32 else 1e-10
+    X = dense(inp)
+    assert rel_diff(dense(ours), dense(ref)) <= tolr
+    assert rel_diff(dense(ours), X) <= tolr          # the redundant input is reproduced
+    # eps mode on the same train
+    t2 = gpu_tensor(inp)
+    t2.round_tt(eps=1e-3 if dt == torch.float32 else 1e-8, algorithm=alg)
+    assert max(t2.ranks_tt) <= 48 and rel_diff(dense(to_list(t2.cores)), X) <= (2e-3 if dt == torch.float32 else 2e-8)
+    # orthogonalize() with wide-rank cores: all cores left of mu orthonormal, tensor unchanged
+    t3 = gpu_tensor(inp)
+    t3.orthogonalize(3)
+    assert rel_diff(dense(to_list(t3.cores)), X) <= tolr
+    for k in range(3):
+        c = t3.cores[k]
+        M = c.reshape(-1, c.shape[-1]).double().cpu()
+        assert (M.T @ M - torch.eye(M.shape[1], dtype=torch.float64)).abs().max() < (5e-5 if dt == torch.float32 else 1e-11)
+
+
 def test_quirks():
     # default eps=1e-14 drops exactly-zero tails even with rmax (SURVEY A-1)
     t = tn.Tensor(torch.ones(4, 4, 4, dtype=torch.float64).cuda(), ranks_tt=3)

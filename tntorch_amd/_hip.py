@@ -39,6 +39,12 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
          c_int64, c_void_p, c_int64, c_void_p],
     ),
+    "ttr_gemm_axpby": (
+        c_int,
+        [c_int, c_int, c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_double, c_double, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "ttr_qr_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_qr": (
         c_int,
@@ -198,6 +204,33 @@ def gemm(
         batch, ws.data_ptr() if ws is not None else None, wsb, _stream(),
     )
     _check(code, "ttr_gemm")
+    return C
+
+
+def gemm_axpby(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, alpha: float, beta: float,
+               transA: bool = False, transB: bool = False) -> torch.Tensor:
+    """In place: C[b] <- beta * C[b] + alpha * op(A[b]) @ op(B[b]); C must be contiguous [batch, M, N]."""
+    L = lib()
+    dt = dtype_code(A.dtype)
+    assert A.dtype == B.dtype == C.dtype and A.shape[0] == B.shape[0] == C.shape[0]
+    assert C.is_contiguous()
+    A, lda, sA = _mat(A)
+    B, ldb, sB = _mat(B)
+    batch = A.shape[0]
+    M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
+    K2, N = (B.shape[2], B.shape[1]) if transB else (B.shape[1], B.shape[2])
+    if K != K2 or tuple(C.shape) != (batch, M, N):
+        raise ValueError(f"gemm_axpby: shapes do not match ({K} vs {K2}, C {tuple(C.shape)})")
+    if M == 0 or N == 0 or batch == 0:
+        return C
+    wsb = L.ttr_gemm_workspace_bytes(dt, M, N, K, batch)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=A.device) if wsb > 0 else None
+    code = L.ttr_gemm_axpby(
+        dt, int(transA), int(transB), M, N, K,
+        A.data_ptr(), lda, sA, B.data_ptr(), ldb, sB, C.data_ptr(), N, M * N,
+        float(alpha), float(beta), batch, ws.data_ptr() if ws is not None else None, wsb, _stream(),
+    )
+    _check(code, "ttr_gemm_axpby")
     return C
 
 

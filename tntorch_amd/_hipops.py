@@ -43,7 +43,44 @@ def _rank_cap(rmax: Optional[int], k: int) -> int:
 
 
 def qr(A3: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    return _hip.qr(A3)
+    """Reduced QR of [B, m, n]: the TSQR kernel up to its column limit, block Gram-Schmidt around it above."""
+    if A3.shape[2] <= _hip.max_qr_cols(A3.dtype):
+        return _hip.qr(A3)
+    return _qr_blocked(A3)
+
+
+def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """QR for more columns than one TSQR panel holds (TT ranks > 64): block classical Gram-Schmidt with
+    re-orthogonalisation (BCGS2) over 64-column panels -- every panel is projected against the finished
+    Q (two MFMA GEMMs), factored by the Householder TSQR kernel, and the normalised panel is projected and
+    factored once more ("twice is enough"; also keeps Q orthonormal when the panel is rank deficient).
+    Wide inputs (m < n): Q from the leading m x m block, R = [R_L | Q^T A_R] (what geqrf returns)."""
+    Bt, m, n = A.shape
+    if m < n:
+        Q, RL = qr(A[:, :, :m].contiguous())
+        return Q, torch.cat([RL, _hip.gemm(Q, A[:, :, m:], transA=True)], dim=2)
+    pw = _hip.max_qr_cols(A.dtype)
+    R = torch.zeros((Bt, n, n), dtype=A.dtype, device=A.device)
+    Q = torch.empty((Bt, m, n), dtype=A.dtype, device=A.device)
+    for j0 in range(0, n, pw):
+        j1 = min(j0 + pw, n)
+        W = A[:, :, j0:j1].contiguous()
+        if j0 == 0:
+            Qj, Rjj = _hip.qr(W)
+        else:
+            Qp = Q[:, :, :j0]
+            C1 = _hip.gemm(Qp, W, transA=True)                 # j0 x w
+            _hip.gemm_axpby(Qp, C1, W, -1.0, 1.0)              # W -= Qp C1
+            Q1, R1 = _hip.qr(W)
+            C2 = _hip.gemm(Qp, Q1, transA=True)
+            _hip.gemm_axpby(Qp, C2, Q1, -1.0, 1.0)             # Q1 -= Qp C2
+            Qj, R2 = _hip.qr(Q1)
+            Rjj = _hip.gemm(R2, R1)
+            _hip.gemm_axpby(C2, R1, C1, 1.0, 1.0)              # C1 += C2 R1
+            R[:, :j0, j0:j1] = C1
+        Q[:, :, j0:j1] = Qj
+        R[:, j0:j1, j0:j1] = Rjj
+    return Q, R
 
 
 # ----------------------------------------------------------------------------------------------
@@ -154,12 +191,8 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
     d = torch.diagonal(G, dim1=1, dim2=2).contiguous()
     if dt == torch.float32:
         # one Newton-Schulz step removes the orthogonality drift of the ~100 accumulated fp32 rotations
-        # E = 1.5 I - 0.5 V^T V as ONE GEMM on stacked operands: [V; I]^T [-0.5 V; 1.5 I]
-        eye = torch.eye(n, dtype=dt, device=dev).expand(Bt, n, n)
-        half = torch.full((Bt, n), -0.5, dtype=dt, device=dev)
-        Aa = torch.cat([V, eye], dim=1)
-        Ba = torch.cat([_hip.scale_cols(V, half, _hip.SCALE_MUL), torch.diag_embed(torch.full((Bt, n), 1.5, dtype=dt, device=dev))], dim=1)
-        V = _hip.gemm(V, _hip.gemm(Aa, Ba, transA=True))
+        Vn = V.clone()
+        V = _hip.gemm_axpby(V, _hip.gemm(V, V, transA=True), Vn, -0.5, 1.5)   # 1.5 V - 0.5 V (V^T V)
     if not relative:
         # Rayleigh quotients against the ORIGINAL matrix: the ~100 two-sided fp updates of G accumulate
         # O(100 eps ||G||) in its diagonal, v_i^T G0 v_i is second order in the eigenvector error
@@ -316,6 +349,17 @@ def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     return L
 
 
+class _ExplicitQ:
+    """Stand-in for ``_hip.QrFactors`` when Q had to be formed (blocked QR above the TSQR column limit)."""
+
+    def __init__(self, Q: torch.Tensor, R: torch.Tensor):
+        self.Q, self.R, self.batch = Q, R, Q.shape[0]
+
+
+def _apply_q(f, C: torch.Tensor) -> torch.Tensor:
+    return _hip.gemm(f.Q, C) if isinstance(f, _ExplicitQ) else _hip.qr_apply(f, C)
+
+
 def round_tt(
     cores4: Sequence[torch.Tensor],
     eps: float,
@@ -337,16 +381,18 @@ def round_tt(
     Rprev = None  # R factor still to be pushed into the current core
     for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
         Bt, r0, I, r1 = c[mu].shape
-        if Rprev is None:
+        rows_k = r0 if Rprev is None else Rprev.shape[1]
+        if r1 > _hip.max_qr_cols(c[mu].dtype):
+            # more columns than a TSQR panel holds (TT rank > 64): explicit Q from the blocked QR
+            A = c[mu] if Rprev is None else _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1))
+            f = _ExplicitQ(*qr(A.reshape(Bt, rows_k * I, r1)))
+        elif Rprev is None:
             f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1))
-            rows_k = r0
         elif _hip.pushed_supported(Rprev.shape[1], r0, I, r1, c[mu].dtype):
             f = _hip.qr_factor_pushed(Rprev, c[mu])  # QR of (Rprev @ core) without materialising it
-            rows_k = Rprev.shape[1]
         else:
             pushed = _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1)).reshape(Bt, Rprev.shape[1], I, r1)
             f = _hip.qr_factor(pushed.reshape(Bt, Rprev.shape[1] * I, r1))
-            rows_k = Rprev.shape[1]
         facs.append((f, rows_k, I))
         Rprev = f.R
         c[mu] = None
@@ -364,13 +410,13 @@ def round_tt(
             M4 = c[mu]
         else:
             f, r0, I = facs[mu]
-            M4 = _hip.qr_apply(f, left).reshape(f.batch, r0, I, left.shape[2])
+            M4 = _apply_q(f, left).reshape(f.batch, r0, I, left.shape[2])
         Bt, R, I, rn = M4.shape
         t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch)
         c[mu] = t.right.reshape(Bt, t.rank, I, rn)
         left = t.left_scaled()
     f, r0, I = facs[0]
-    c[0] = _hip.qr_apply(f, left).reshape(f.batch, r0, I, left.shape[2])
+    c[0] = _apply_q(f, left).reshape(f.batch, r0, I, left.shape[2])
     return c
 
 

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kThreads) void scale_cols_kernel(int64_t rows, int6
 int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
                   const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
-                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream);
+                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream, int axpby = 0, double alpha = 1.0,
+                  double beta = 0.0);
 int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch);
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
                        void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
@@ -180,6 +181,19 @@ int ttr_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
   return gemm_dispatch(dtype, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rowscale,
                        stride_rs, rowscale_mode, colscale, stride_cs, colscale_mode, batch, workspace, workspace_bytes,
                        (hipStream_t)stream);
+}
+
+int ttr_gemm_axpby(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
+                   double alpha, double beta, int64_t batch, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_gemm_axpby: bad dtype %d", dtype);
+  TTR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, TTR_E_INVALID, "ttr_gemm_axpby: negative dimension");
+  if (M == 0 || N == 0 || batch == 0) return TTR_OK;
+  TTR_REQUIRE(K >= 1, TTR_E_INVALID, "ttr_gemm_axpby: K must be >= 1");
+  TTR_REQUIRE(A && B && C, TTR_E_INVALID, "ttr_gemm_axpby: null operand");
+  return gemm_dispatch(dtype, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, nullptr, 0,
+                       TTR_SCALE_NONE, nullptr, 0, TTR_SCALE_NONE, batch, workspace, workspace_bytes,
+                       (hipStream_t)stream, 1, alpha, beta);
 }
 
 int64_t ttr_qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {

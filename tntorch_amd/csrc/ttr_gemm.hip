@@ -43,6 +43,8 @@ struct GemmArgs {
   int64_t k_chunk;  // K range per split (multiple of BK)
   T* part;          // [nsplit][batch][M][N] when nsplit > 1
   int64_t batch;
+  int axpby;        // C <- beta * C + alpha * op(A) op(B)   (ttr_gemm_axpby)
+  T alpha, beta;
 };
 
 template <typename T>
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
           if (direct) {
             v = apply_scale(v, p.rs ? p.rs + b * p.stride_rs : nullptr, row, p.rs ? p.rs_mode : TTR_SCALE_NONE);
             v = apply_scale(v, p.cs ? p.cs + b * p.stride_cs : nullptr, col, p.cs ? p.cs_mode : TTR_SCALE_NONE);
+            if (p.axpby) v = p.alpha * v + (p.beta != T(0) ? p.beta * C[row * ldc + col] : T(0));
           }
           C[row * ldc + col] = v;
         }
@@ -162,7 +165,9 @@ __global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(GemmArgs<T> p) 
     const int64_t row = idx / p.N, col = idx % p.N;
     s = apply_scale(s, p.rs ? p.rs + b * p.stride_rs : nullptr, row, p.rs ? p.rs_mode : TTR_SCALE_NONE);
     s = apply_scale(s, p.cs ? p.cs + b * p.stride_cs : nullptr, col, p.cs ? p.cs_mode : TTR_SCALE_NONE);
-    p.C[b * p.strideC + row * p.ldc + col] = s;
+    T* dst = p.C + b * p.strideC + row * p.ldc + col;
+    if (p.axpby) s = p.alpha * s + (p.beta != T(0) ? p.beta * *dst : T(0));
+    *dst = s;
   }
 }
 
@@ -182,8 +187,10 @@ template <typename T>
 static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                      int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc,
                      int64_t strideC, const void* rs, int64_t stride_rs, int rs_mode, const void* cs,
-                     int64_t stride_cs, int cs_mode, int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                     int64_t stride_cs, int cs_mode, int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream,
+                     int axpby, double alpha, double beta) {
   GemmArgs<T> p;
+  p.axpby = axpby; p.alpha = (T)alpha; p.beta = (T)beta;
   p.M = M; p.N = N; p.K = K;
   p.A = (const T*)A; p.strideA = strideA;
   if (!transA) { p.a_rs = lda; p.a_cs = 1; } else { p.a_rs = 1; p.a_cs = lda; }
@@ -229,12 +236,12 @@ int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t
 int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
                   const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
-                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                  int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream, int axpby, double alpha, double beta) {
   if (dtype == TTR_F32)
     return gemm_impl<float>(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rs, stride_rs,
-                            rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream);
+                            rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream, axpby, alpha, beta);
   return gemm_impl<double>(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rs, stride_rs,
-                           rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream);
+                           rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream, axpby, alpha, beta);
 }
 
 }  // namespace ttr
