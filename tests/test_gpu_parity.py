@@ -283,6 +283,47 @@ def test_quirks():
         tn.Tensor(held).round_tt(rmax=[2, 2])
 
 
+# ------------------------------------------------------------------ consumers on the device
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_device_dot_norm_decompress(dt):
+    """metrics.dot / norm / dist / relative_error and Tensor.torch() on device tensors (ttr_gemm chains)
+    against the oracle's float64 contraction."""
+    torch.manual_seed(21)
+    a = oracle.tt_randn([9, 7, 8, 6, 5], 5, dtype=torch.float64)
+    b = oracle.tt_randn([9, 7, 8, 6, 5], 3, dtype=torch.float64)
+    ta, tb = gpu_tensor([c.to(dt) for c in a]), gpu_tensor([c.to(dt) for c in b])
+    rt = 2e-5 if dt == torch.float32 else 1e-12
+    A, Bd = oracle.tt_to_dense(a), oracle.tt_to_dense(b)
+    assert rel_diff(ta.torch().cpu().double(), A) <= rt
+    ref = oracle.tt_dot(a, b).item()
+    scale = math.sqrt(oracle.tt_dot(a, a).item() * oracle.tt_dot(b, b).item())
+    assert abs(tn.dot(ta, tb).item() - ref) <= rt * scale
+    assert abs(tn.norm(ta).item() - A.norm().item()) <= rt * A.norm().item()
+    assert abs(tn.dist(ta, tb).item() - (A - Bd).norm().item()) <= 50 * rt * A.norm().item()
+    # dense-vs-TT branches (metrics.py:135-151)
+    Xd = A.to(dt).cuda()
+    assert tn.relative_error(Xd, ta).item() <= 10 * rt
+    assert abs(tn.relative_error(Xd, tb).item() - ((A - Bd).norm() / A.norm()).item()) <= 10 * rt
+    assert abs(tn.dot(Xd, tb).item() - (A * Bd).sum().item()) <= rt * scale
+    # boundary ranks > 1 are summed away by torch() (tensor.py:1639-1687)
+    cs = [torch.randn(3, 4, 2, dtype=torch.float64), torch.randn(2, 5, 4, dtype=torch.float64)]
+    full = torch.einsum("aib,bjc->ij", cs[0], cs[1])
+    assert rel_diff(gpu_tensor([c.to(dt) for c in cs]).torch().cpu().double(), full) <= rt
+    # batch decompression
+    gb = oracle.tt_randn([6, 5, 4], 3, dtype=torch.float64, batch_size=3)
+    tb3 = gpu_tensor([c.to(dt) for c in gb], batch=True)
+    assert rel_diff(tb3.torch().cpu().double(), oracle.tt_to_dense(gb, batch=True)) <= rt
+
+
+def test_device_norm_metric_size():
+    """||t|| of a 64^8 rank-32 fp32 train on the device vs the oracle's float64 inner product."""
+    torch.manual_seed(3)
+    g = oracle.tt_randn([64] * 8, 32, dtype=torch.float32)
+    t = gpu_tensor(g)
+    ref = math.sqrt(oracle.tt_dot([c.double() for c in g], [c.double() for c in g]).item())
+    assert abs(tn.norm(t).item() - ref) <= 1e-5 * ref
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""

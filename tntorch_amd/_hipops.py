@@ -455,3 +455,59 @@ def dense_tt_svd(
         rn = t.rank
     cores[0] = C.reshape(Bt, 1, shape[0], rn).contiguous()
     return cores  # type: ignore[return-value]
+
+
+# ---------------------------------------------------------------------------------------------- consumers (SURVEY 8f-4)
+def _sum_last(x3: torch.Tensor) -> torch.Tensor:
+    """[B, r, c] -> [B, r, 1]: sum over the last axis as a GEMM with a ones vector."""
+    ones = torch.ones((x3.shape[0], x3.shape[2], 1), dtype=x3.dtype, device=x3.device)
+    return _hip.gemm(x3, ones)
+
+
+def decompress(c: Sequence[torch.Tensor]) -> torch.Tensor:
+    """tensor.py:1639-1687 for TT cores [B, r0, I, r1]: chain of unfolding GEMMs, left to right.
+    Returns [B, I_1, ..., I_N] (boundary ranks > 1 are summed away, as the reference does)."""
+    Bt = c[0].shape[0]
+    acc = c[0].reshape(Bt, -1, c[0].shape[-1])
+    for core in c[1:]:
+        acc = _hip.gemm(acc, core.reshape(Bt, core.shape[1], -1)).reshape(Bt, -1, core.shape[-1])
+    r0, rN = c[0].shape[1], c[-1].shape[-1]
+    if rN > 1:
+        acc = _sum_last(acc)
+    if r0 > 1:
+        acc = _sum_last(acc.reshape(Bt, r0, -1).transpose(1, 2).contiguous())
+    return acc.reshape([Bt] + [core.shape[2] for core in c])
+
+
+def dot(c1: Sequence[torch.Tensor], c2: Sequence[torch.Tensor]) -> torch.Tensor:
+    """metrics.py:28-116 (k = N, TT cores only) for cores [1, r, I, r']: the left-to-right ``Lprod``
+    contraction, two GEMMs per core; returns a 0-d tensor on the device."""
+    a0, b0 = c1[0], c2[0]
+    L = torch.ones((1, b0.shape[1], a0.shape[1]), dtype=a0.dtype, device=a0.device)
+    for a, b in zip(c1, c2):
+        _, r, I, r1 = a.shape
+        _, s_, _, s1 = b.shape
+        U = _hip.gemm(L, a.reshape(1, r, I * r1)).reshape(1, s_ * I, r1)       # einsum("sr,rai->sai")
+        L = _hip.gemm(b.reshape(1, s_ * I, s1), U, transA=True)                # left_unf(b)^T left_unf(U)
+    if L.numel() > 1:
+        L = _sum_last(_sum_last(L).transpose(1, 2).contiguous())
+    return L.reshape(())
+
+
+def dense_dot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """<a, b> of two dense device tensors: a 1 x n x 1 GEMM (split-K over the CUs)."""
+    n = a.numel()
+    return _hip.gemm(a.reshape(1, 1, n), b.reshape(1, n, 1)).reshape(())
+
+
+def dense_norm(a: torch.Tensor) -> torch.Tensor:
+    return _hip.norm(a.reshape(1, -1))[0]
+
+
+def dense_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """||a - b||: the difference through ttr_gemm_axpby (b as an n x 1 times 1 x 1 product), then ttr_norm."""
+    n = a.numel()
+    d = a.reshape(1, n, 1).clone()
+    one = torch.ones((1, 1, 1), dtype=a.dtype, device=a.device)
+    _hip.gemm_axpby(b.reshape(1, n, 1), one, d, -1.0, 1.0)
+    return _hip.norm(d.reshape(1, -1))[0]

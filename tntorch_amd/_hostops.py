@@ -180,3 +180,39 @@ def full_rank_tt(X: torch.Tensor) -> List[torch.Tensor]:
 def dense_tt_svd(X: torch.Tensor, eps, rmax, algorithm, batch) -> List[torch.Tensor]:
     """tensor.py:401-408 exactly as the reference does it: full-rank TT, then round_tt."""
     return round_tt(full_rank_tt(X), eps, rmax, algorithm, batch)
+
+
+# ---------------------------------------------------------------------------------------------- consumers (SURVEY 8f-4)
+def decompress(c: Sequence[torch.Tensor]) -> torch.Tensor:
+    """tensor.py:1639-1687 for TT cores [B, r0, I, r1] -> [B, I_1, ..., I_N]."""
+    Bt = c[0].shape[0]
+    acc = c[0].reshape(Bt, -1, c[0].shape[-1])
+    for core in c[1:]:
+        acc = torch.bmm(acc, core.reshape(Bt, core.shape[1], -1)).reshape(Bt, -1, core.shape[-1])
+    # ranks_tt[0] and ranks_tt[-1] may exceed 1: the reference sums the boundary indices away
+    r0 = c[0].shape[1]
+    acc = acc.reshape(Bt, r0, -1, c[-1].shape[-1]).sum(dim=(1, 3))
+    return acc.reshape([Bt] + [core.shape[2] for core in c])
+
+
+def dot(c1: Sequence[torch.Tensor], c2: Sequence[torch.Tensor]) -> torch.Tensor:
+    """metrics.py:28-116 (k = N, TT cores only) on cores [1, r, I, r']."""
+    a0, b0 = c1[0][0], c2[0][0]
+    L = torch.ones([b0.shape[0], a0.shape[0]], device=a0.device, dtype=a0.dtype)
+    for a, b in zip(c1, c2):
+        a, b = a[0], b[0]
+        U = torch.einsum("sr,rai->sai", L, a)
+        L = b.reshape(-1, b.shape[-1]).t() @ U.reshape(-1, U.shape[-1])
+    return torch.sum(L)
+
+
+def dense_dot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return a.flatten().dot(b.flatten())
+
+
+def dense_norm(a: torch.Tensor) -> torch.Tensor:
+    return torch.norm(a)
+
+
+def dense_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return torch.dist(a, b)

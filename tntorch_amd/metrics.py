@@ -1,14 +1,14 @@
 """Inner products / error metrics on tensor trains used by the parity tests.
 
 Mirror of the TT subset of ``tntorch/metrics.py`` (``dot`` 28-116, ``dist`` 119-132,
-``relative_error`` 135-151, ``normsq`` 457-466, ``norm`` 469-478).  Thin torch code: these are
-consumers of the hot path, not part of it.
+``relative_error`` 135-151, ``normsq`` 457-466, ``norm`` 469-478): the consumers of the hot path
+(SURVEY 8f-4).  The contraction runs on the HIP GEMM for device tensors and on torch for CPU tensors.
 """
 
 import torch
 
+from ._dispatch import ops_for
 from .tensor import Tensor
-from .tools import left_unfolding
 
 __all__ = ["dot", "dist", "relative_error", "normsq", "norm"]
 
@@ -21,23 +21,20 @@ def dot(t1, t2):
     """Full inner product <t1, t2> (metrics.py:28-116 with k = N, no Tucker factors)."""
     if not isinstance(t1, Tensor) or not isinstance(t2, Tensor):
         a, b = _dense(t1), _dense(t2)
-        return a.flatten().dot(b.flatten())
+        return ops_for(a).dense_dot(a, b)
     if t1.batch or t2.batch:
         raise ValueError("Batched tensors are not supproted.")
     if t1.shape != t2.shape:
         raise ValueError("Dot product requires leading dimensions to be equal, but they are {} and {}".format(t1.shape, t2.shape))
-    c0 = t1.cores[0]
-    L = torch.ones([t2.cores[0].shape[0], c0.shape[0]], device=c0.device, dtype=c0.dtype)
-    for a, b in zip(t1.cores, t2.cores):
-        U = torch.einsum("sr,rai->sai", L, a)
-        L = left_unfolding(b).t() @ left_unfolding(U)
-    return torch.sum(L)
+    c1 = t1._norm4()
+    return ops_for(c1[0]).dot(c1, t2._norm4())  # device tensors: Lprod chain on ttr_gemm
 
 
 def dist(t1, t2):
     """Euclidean distance (metrics.py:119-132)."""
     if not isinstance(t1, Tensor) or not isinstance(t2, Tensor):
-        return torch.dist(_dense(t1), _dense(t2))
+        a, b = _dense(t1), _dense(t2)
+        return ops_for(a).dense_dist(a, b)
     return torch.sqrt((dot(t1, t1) + dot(t2, t2) - 2 * dot(t1, t2)).clamp(0))
 
 
@@ -49,7 +46,8 @@ def relative_error(gt, approx):
     """
     if not isinstance(gt, Tensor) or not isinstance(approx, Tensor):
         a, b = _dense(gt), _dense(approx)
-        return torch.dist(a, b) / torch.norm(a)
+        ops = ops_for(a)
+        return ops.dense_dist(a, b) / ops.dense_norm(a)
     dotgt = dot(gt, gt)
     return torch.sqrt((dotgt + dot(approx, approx) - 2 * dot(gt, approx)).clamp(0)) / torch.sqrt(dotgt.clamp(0))
 

@@ -196,14 +196,7 @@ class Tensor(object):
     def torch(self):
         """Decompress into a dense torch tensor (tensor.py:1639-1687, TT cores only)."""
         c = self._norm4()
-        Bt = c[0].shape[0]
-        acc = c[0].reshape(Bt, -1, c[0].shape[-1])
-        for core in c[1:]:
-            acc = torch.bmm(acc, core.reshape(Bt, core.shape[1], -1)).reshape(Bt, -1, core.shape[-1])
-        # ranks_tt[0] and ranks_tt[-1] may exceed 1: the reference sums the boundary indices away
-        r0 = c[0].shape[1]
-        acc = acc.reshape(Bt, r0, -1, c[-1].shape[-1]).sum(dim=(1, 3))
-        out = acc.reshape([Bt] + [core.shape[2] for core in c])
+        out = ops_for(c[0]).decompress(c)  # device tensors: chain of MFMA GEMMs (ttr_gemm)
         return out if self.batch else out[0]
 
     def numpy(self):
