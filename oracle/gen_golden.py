@@ -187,6 +187,95 @@ def case_orthogonalize():
     )
 
 
+def _tucker_input(dtype, batch=None, seed=11):
+    """TT whose modes are Tucker-compressible: cores with mode sizes S absorbed with random factors I x S."""
+    torch.manual_seed(seed)
+    S, I, r = [6, 5, 7, 6], [12, 10, 14, 11], 3
+    if batch is None:
+        g = tn.rand(S, ranks_tt=r)
+        cores = [c.to(dtype) for c in g.cores]
+        Us = [torch.randn(i, s_, dtype=dtype) for i, s_ in zip(I, S)]
+        absorbed = [torch.einsum("iak,ja->ijk", c, U) for c, U in zip(cores, Us)]
+    else:
+        ranks = [1, r, r, r, 1]
+        cores = [torch.rand(batch, ranks[k], S[k], ranks[k + 1], dtype=dtype) for k in range(4)]
+        Us = [torch.randn(batch, i, s_, dtype=dtype) for i, s_ in zip(I, S)]
+        absorbed = [torch.einsum("biak,bja->bijk", c, U) for c, U in zip(cores, Us)]
+    return absorbed
+
+
+def case_round_tucker():
+    torch.set_default_dtype(torch.float64)
+    inp = _tucker_input(torch.float64)
+    groups = {"inp": npl(inp)}
+    for alg in ("svd", "eig"):
+        t = tn.Tensor([c.clone() for c in inp])
+        t.round_tucker(eps=1e-8, algorithm=alg)
+        groups[f"{alg}_cores"] = npl(t.cores)
+        groups[f"{alg}_Us"] = npl(t.Us)
+    save("round_tucker_eps_f64",
+         {"what": "TT 12x10x14x11 (ranks 3) with Tucker ranks 6,5,7,6; t.round_tucker(eps=1e-8)", "ref": "tensor.py:1911-2006",
+          "dtype": "float64", "eps": 1e-8}, **groups)
+
+    torch.set_default_dtype(torch.float32)
+    inp = _tucker_input(torch.float32, seed=12)
+    groups = {"inp": npl(inp)}
+    for alg in ("svd", "eig"):
+        t = tn.Tensor([c.clone() for c in inp])
+        t.round_tucker(rmax=3, algorithm=alg)
+        groups[f"{alg}_cores"] = npl(t.cores)
+        groups[f"{alg}_Us"] = npl(t.Us)
+    save("round_tucker_rmax_f32",
+         {"what": "same structure, float32; t.round_tucker(rmax=3)", "ref": "tensor.py:1911-2006", "dtype": "float32", "rmax": 3}, **groups)
+
+    # batch mode: the reference's truncated_svd crashes for tall factors with left_ortho=True (round.py:176,
+    # torch.diag on a [B, r] tensor), i.e. whenever I_k > R_k * R_{k+1}; only small modes work.
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(13)
+    ranks = [1, 4, 4, 4, 1]
+    I = [3, 4, 3, 3]
+    inp = [torch.rand(3, ranks[k], I[k], ranks[k + 1]) for k in range(4)]
+    groups = {"inp": npl(inp)}
+    for alg in ("svd", "eig"):
+        t = tn.Tensor([c.clone() for c in inp], batch=True)
+        t.round_tucker(rmax=2, algorithm=alg)
+        groups[f"{alg}_cores"] = npl(t.cores)
+        groups[f"{alg}_Us"] = npl(t.Us)
+    save("round_tucker_batch_f64",
+         {"what": "batch of 3 TTs 3x4x3x3 rank 4; t.round_tucker(rmax=2) (eps ignored in batch mode)", "ref": "tensor.py:1911-2006",
+          "dtype": "float64", "rmax": 2, "batch": True}, **groups)
+
+
+def case_ctor_tucker():
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(14)
+    low = tn.rand([12, 10, 9, 11], ranks_tt=3, ranks_tucker=4).torch()
+    X = low / low.norm() + 1e-3 * torch.randn(12, 10, 9, 11) / np.sqrt(low.numel())
+    groups = {"inp": X.numpy()}
+    for alg in ("svd", "eig"):
+        t = tn.Tensor(X, ranks_tucker=4, ranks_tt=3, algorithm=alg)
+        groups[f"{alg}_cores"] = npl(t.cores)
+        groups[f"{alg}_Us"] = npl(t.Us)
+    save("ctor_tucker_f64",
+         {"what": "tn.Tensor(X, ranks_tucker=4, ranks_tt=3), X = TT-Tucker(3; 4) + 1e-3 noise, 12x10x9x11", "ref": "tensor.py:401-408",
+          "dtype": "float64"}, **groups)
+
+
+def case_round_general():
+    torch.set_default_dtype(torch.float64)
+    inp = _tucker_input(torch.float64, seed=15)
+    t0 = tn.Tensor([c.clone() for c in inp])
+    t0 = t0 + t0  # redundant TT ranks as well
+    groups = {"inp": npl(t0.cores)}
+    for alg in ("svd", "eig"):
+        t = tn.round(t0, eps=1e-6, algorithm=alg)
+        groups[f"{alg}_cores"] = npl(t.cores)
+        groups[f"{alg}_Us"] = npl([U for U in t.Us])
+    save("round_general_f64",
+         {"what": "t0 = t+t (TT ranks 6, Tucker ranks 6,5,7,6 inside 12x10x14x11); tn.round(t0, eps=1e-6)", "ref": "tensor.py:2085-2098",
+          "dtype": "float64", "eps": 1e-6}, **groups)
+
+
 def case_known_answers():
     """docs/tutorials/decompositions.ipynb cells 1, 3, 18 (analytic 128^3 function)."""
     torch.set_default_dtype(torch.float64)
@@ -200,8 +289,12 @@ def case_known_answers():
         t.round_tt(eps=1e-5, algorithm=alg)
         out[f"ranks_eps1e-5_{alg}"] = t.ranks_tt.tolist()
         out[f"relerr_eps1e-5_{alg}"] = tn.relative_error(full, t).item()
+    te = tn.Tensor(full, eps=1e-5)
+    out["eps_ctor_ranks_tt"] = te.ranks_tt.tolist()
+    out["eps_ctor_ranks_tucker"] = te.ranks_tucker.tolist()
+    out["eps_ctor_relerr"] = tn.relative_error(full, te).item()
     META["known_answers"] = {
-        "source": "docs/tutorials/decompositions.ipynb cell 1 (function), cell 3 (ranks_tt=3: ranks [1,3,3,1], rel. error 0.0005), cell 18 (round_tt(eps=1e-5): ranks [1,4,6,1], rel. error 8.3358e-06)",
+        "source": "docs/tutorials/decompositions.ipynb cell 1 (function), cell 3 (ranks_tt=3: ranks [1,3,3,1], rel. error 0.0005), cell 18 (round_tt(eps=1e-5): ranks [1,4,6,1], rel. error 8.3358e-06), cell 14 (tn.Tensor(full, eps=1e-5): TT ranks [1,4,6,1], Tucker ranks 4,5,6, rel. error 8.3402e-06)",
         "measured_with_reference_here": out,
     }
 
@@ -215,6 +308,9 @@ if __name__ == "__main__":
     case_c0()
     case_truncated_svd()
     case_orthogonalize()
+    case_round_tucker()
+    case_ctor_tucker()
+    case_round_general()
     case_known_answers()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(META, f, indent=1, sort_keys=True)

@@ -32,6 +32,12 @@ __all__ = [
     "right_orthogonalize",
     "orthogonalize",
     "round_tt",
+    "round_tucker",
+    "round_general",
+    "tucker_absorb",
+    "tucker_to_dense",
+    "dense_to_tucker_tt",
+    "relative_error_tt",
     "full_rank_tt",
     "dense_to_tt",
     "tt_to_dense",
@@ -171,9 +177,22 @@ def truncated_svd(
 # --------------------------------------------------------------------------
 # orthogonalisation sweeps -- tensor.py:1800-1909 (pure TT cores, Us = None)
 # --------------------------------------------------------------------------
-def left_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Tensor:
+def factor_orthogonalize(cores: Cores, Us, mu: int, batch: bool = False) -> None:
+    """tensor.py:1771-1798: QR of the Tucker factor, R pushed into the core (no-op without a factor)."""
+    if Us is None or Us[mu] is None:
+        return
+    Q, R = torch.linalg.qr(Us[mu])
+    Us[mu] = Q
+    if batch:
+        cores[mu] = torch.einsum("bijk,baj->biak", cores[mu], R)
+    else:
+        cores[mu] = torch.einsum("ijk,aj->iak", cores[mu], R)
+
+
+def left_orthogonalize(cores: Cores, mu: int, batch: bool = False, Us=None) -> torch.Tensor:
     """tensor.py:1800-1833: reduced QR of the left unfolding; R is pushed right."""
     assert 0 <= mu < len(cores) - 1
+    factor_orthogonalize(cores, Us, mu, batch)  # tensor.py:1815
     core = cores[mu]
     Q, R = torch.linalg.qr(left_unfolding(core, batch))
     cores[mu] = Q.reshape(core.shape[:-1] + (Q.shape[-1],))
@@ -186,9 +205,10 @@ def left_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Tens
     return R
 
 
-def right_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Tensor:
+def right_orthogonalize(cores: Cores, mu: int, batch: bool = False, Us=None) -> torch.Tensor:
     """tensor.py:1835-1879: QR of the transposed right unfolding; L is pushed left."""
     assert 1 <= mu < len(cores)
+    factor_orthogonalize(cores, Us, mu, batch)  # tensor.py:1850
     core = cores[mu]
     Q, L = torch.linalg.qr(_t(right_unfolding(core, batch)))
     Q, L = _t(Q), _t(L)
@@ -201,16 +221,16 @@ def right_orthogonalize(cores: Cores, mu: int, batch: bool = False) -> torch.Ten
     return L
 
 
-def orthogonalize(cores: Cores, mu: int, batch: bool = False):
-    """tensor.py:1881-1909: make the train mu-orthogonal (in place on the list)."""
+def orthogonalize(cores: Cores, mu: int, batch: bool = False, Us=None):
+    """tensor.py:1881-1909: make the train mu-orthogonal (in place on the list, and on ``Us`` if given)."""
     N = len(cores)
     if mu < 0:
         mu += N
     R = L = None
     for i in range(mu):
-        R = left_orthogonalize(cores, i, batch)
+        R = left_orthogonalize(cores, i, batch, Us)
     for i in range(N - 1, mu, -1):
-        L = right_orthogonalize(cores, i, batch)
+        L = right_orthogonalize(cores, i, batch, Us)
     return R, L
 
 
@@ -223,15 +243,17 @@ def round_tt(
     rmax: Union[None, int, Sequence[Optional[int]]] = None,
     algorithm: str = "svd",
     batch: bool = False,
+    Us=None,
 ) -> Cores:
-    """tensor.py:2008-2083.  Returns the rounded cores (input list untouched)."""
+    """tensor.py:2008-2083.  Returns the rounded cores (input list untouched).  ``Us`` (optional list of
+    Tucker factors) is modified IN PLACE by the factor orthogonalisations of the L2R sweep."""
     cores = [c.clone() for c in cores]
     N = len(cores)
     if not hasattr(rmax, "__len__"):
         rmax = [rmax] * (N - 1)
     assert len(rmax) == N - 1  # tensor.py:2029
 
-    orthogonalize(cores, N - 1, batch)  # tensor.py:2033
+    orthogonalize(cores, N - 1, batch, Us)  # tensor.py:2033
     if batch:  # tensor.py:2036-2037
         delta = None
     else:  # tensor.py:2039-2051 (float64 factor times the core's norm)
@@ -255,6 +277,112 @@ def round_tt(
             cores[mu] = right.reshape(-1, core.shape[1], core.shape[2])
         cores[mu - 1] = cores[mu - 1] @ left if not batch else torch.matmul(cores[mu - 1], left[:, None])
     return cores
+
+
+# --------------------------------------------------------------------------
+# Tucker rounding and the general round() -- tensor.py:1911-2006, 2085-2098
+# A TT-Tucker tensor is (cores, Us): cores [R_k, S_k, R_{k+1}], Us[k] = None or [I_k, S_k]
+# (batch=True prepends B to both).
+# --------------------------------------------------------------------------
+def round_tucker(
+    cores: Sequence[torch.Tensor],
+    Us: Optional[Sequence[Optional[torch.Tensor]]] = None,
+    eps: float = 1e-14,
+    rmax: Union[None, int, Sequence[Optional[int]]] = None,
+    dim="all",
+    algorithm: str = "svd",
+    batch: bool = False,
+):
+    """tensor.py:1911-2006.  Returns (cores, Us) (inputs untouched)."""
+    cores = [c.clone() for c in cores]
+    N = len(cores)
+    Us = [None] * N if Us is None else [None if U is None else U.clone() for U in Us]
+    if not hasattr(rmax, "__len__"):
+        rmax = [rmax] * N
+    assert len(rmax) == N  # tensor.py:1933
+    if dim == "all":
+        dim = range(N)
+    if not hasattr(dim, "__len__"):
+        dim = [dim] * N
+    orthogonalize(cores, N - 1, batch, Us)  # tensor.py:1944
+    for mu in range(N - 1, -1, -1):  # tensor.py:1945
+        core = cores[mu]
+        if Us[mu] is None:  # tensor.py:1946-1958
+            if batch:
+                Us[mu] = torch.eye(core.shape[2], dtype=core.dtype).repeat(core.shape[0], 1, 1)
+            else:
+                Us[mu] = torch.eye(core.shape[1], dtype=core.dtype)
+        # send non-orthogonality to the factor (tensor.py:1960-1984)
+        if batch:
+            Q, R = torch.linalg.qr(core.permute(0, 1, 3, 2).reshape(core.shape[0], -1, core.shape[2]))
+            cores[mu] = Q.reshape(core.shape[0], core.shape[1], core.shape[3], -1).permute(0, 1, 3, 2)
+        else:
+            Q, R = torch.linalg.qr(core.permute(0, 2, 1).reshape(-1, core.shape[1]))
+            cores[mu] = Q.reshape(core.shape[0], core.shape[2], -1).permute(0, 2, 1)
+        Us[mu] = Us[mu] @ _t(R)  # tensor.py:1986
+        left, right = truncated_svd(  # tensor.py:1989-1996
+            Us[mu], eps=eps / math.sqrt(len(dim)), rmax=rmax[mu], left_ortho=True, algorithm=algorithm, batch=batch
+        )
+        Us[mu] = left.to(core.dtype)
+        right = right.to(core.dtype)
+        if batch:  # tensor.py:1999-2002
+            cores[mu] = torch.einsum("bijk,baj->biak", cores[mu], right)
+        else:
+            cores[mu] = torch.einsum("ijk,aj->iak", cores[mu], right)
+        if mu > 0:  # tensor.py:2005-2006
+            right_orthogonalize(cores, mu, batch, Us)
+    return cores, Us
+
+
+def tucker_absorb(cores: Sequence[torch.Tensor], Us: Optional[Sequence[Optional[torch.Tensor]]], batch: bool = False) -> Cores:
+    """Contract every factor into its core (what ``Tensor.torch()`` does per mode, tensor.py:1639-1687)."""
+    out = []
+    for k, c in enumerate(cores):
+        U = None if Us is None else Us[k]
+        if U is None:
+            out.append(c)
+        elif batch:
+            out.append(torch.einsum("biak,bja->bijk", c, U))
+        else:
+            out.append(torch.einsum("iak,ja->ijk", c, U))
+    return out
+
+
+def tucker_to_dense(cores, Us, batch: bool = False) -> torch.Tensor:
+    return tt_to_dense(tucker_absorb(cores, Us, batch), batch)
+
+
+def relative_error_tt(gt: Sequence[torch.Tensor], approx: Sequence[torch.Tensor]) -> torch.Tensor:
+    """metrics.py:135-151 between two compressed tensors (the <a,a>+<b,b>-2<a,b> formula)."""
+    dotgt = tt_dot(gt, gt)
+    return torch.sqrt((dotgt + tt_dot(approx, approx) - 2 * tt_dot(gt, approx)).clamp(0)) / torch.sqrt(dotgt.clamp(0))
+
+
+def round_general(cores: Sequence[torch.Tensor], eps: float = 1e-14, algorithm: str = "svd"):
+    """tensor.py:2085-2098 ``Tensor.round`` for a pure-TT input: TT rounding, then Tucker rounding with the
+    remaining error budget.  Returns (cores, Us)."""
+    copy = [c.clone() for c in cores]
+    out = round_tt(cores, eps=eps, algorithm=algorithm)  # pure TT input: no factors to orthogonalise
+    reached = relative_error_tt(copy, out)
+    Us = [None] * len(out)
+    if reached < eps:
+        out, Us = round_tucker(out, None, (1 + eps) / (1 + reached.item()) - 1, algorithm=algorithm)
+    return out, Us
+
+
+def dense_to_tucker_tt(data: torch.Tensor, ranks_tucker=None, ranks_tt=None, eps=None, algorithm: str = "svd",
+                       batch: bool = False):
+    """tensor.py:401-408, 436-439: ``tn.Tensor(data, ranks_tucker=, ranks_tt=)`` / ``tn.Tensor(data, eps=)``."""
+    cores = full_rank_tt(data, batch)
+    Us = [None] * len(cores)
+    if eps is not None:
+        assert not batch
+        return round_general(cores, eps, algorithm)
+    if ranks_tucker is not None:
+        cores, Us = round_tucker(cores, None, rmax=ranks_tucker, algorithm=algorithm, batch=batch)
+    if ranks_tt is not None:
+        cores = round_tt(cores, rmax=ranks_tt, algorithm=algorithm, batch=batch, Us=Us)
+    return cores, Us
 
 
 # --------------------------------------------------------------------------

@@ -324,6 +324,94 @@ def test_device_norm_metric_size():
     assert abs(tn.norm(t).item() - ref) <= 1e-5 * ref
 
 
+# ------------------------------------------------------------------ Tucker rounding / round() on the device
+def _tk(cores):
+    return [c.shape[-2] for c in cores]
+
+
+def _tucker_dense(t):
+    return oracle.tucker_to_dense([c.cpu().double() for c in t.cores], [None if U is None else U.cpu().double() for U in t.Us],
+                                  batch=t.batch)
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_round_tucker(alg):
+    g = load_case("round_tucker_eps_f64")
+    t = gpu_tensor(g["inp"])
+    t.round_tucker(eps=1e-8, algorithm=alg)
+    assert _tk(t.cores) == _tk(g[f"{alg}_cores"]) and tuple(t.shape) == (12, 10, 14, 11)
+    ref = oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert rel_diff(_tucker_dense(t), ref) <= 1e-10
+    assert rel_diff(t.torch().cpu(), ref) <= 1e-10          # device decompression with factors
+    for U in t.Us:                                           # orthonormal factors (left_ortho=True)
+        Uc = U.cpu()
+        assert (Uc.T @ Uc - torch.eye(Uc.shape[1], dtype=Uc.dtype)).abs().max() < 1e-10
+    # float32, rank cap
+    g = load_case("round_tucker_rmax_f32")
+    t = gpu_tensor(g["inp"])
+    t.round_tucker(rmax=3, algorithm=alg)
+    assert _tk(t.cores) == [3, 3, 3, 3]
+    X = dense(g["inp"])
+    e_o = rel_diff(_tucker_dense(t), X)
+    e_r = rel_diff(oracle.tucker_to_dense([c.double() for c in g[f"{alg}_cores"]], [U.double() for U in g[f"{alg}_Us"]]), X)
+    assert abs(e_o - e_r) <= 1e-5
+    # batch
+    g = load_case("round_tucker_batch_f64")
+    t = gpu_tensor(g["inp"], batch=True)
+    t.round_tucker(rmax=2, algorithm=alg)
+    ref = oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"], batch=True)
+    assert rel_diff(_tucker_dense(t), ref) <= 1e-10
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_ctor_tucker_and_round(alg):
+    g = load_case("ctor_tucker_f64")
+    t = tn.Tensor(g["inp"], ranks_tucker=4, ranks_tt=3, algorithm=alg, device="cuda")   # dense ST-HOSVD + TT-SVD
+    assert t.ranks_tt.tolist() == [1, 3, 3, 3, 1] and t.ranks_tucker.tolist() == [4, 4, 4, 4]
+    ref = oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert rel_diff(_tucker_dense(t), ref) <= 1e-9
+    t = tn.Tensor(g["inp"], ranks_tucker=4, algorithm=alg, device="cuda")                # Tucker only
+    assert t.ranks_tucker.tolist() == [4, 4, 4, 4]
+    rt, _ = oracle.dense_to_tucker_tt(g["inp"], ranks_tucker=4, algorithm=alg)
+    e_r = rel_diff(oracle.tucker_to_dense(*oracle.dense_to_tucker_tt(g["inp"], ranks_tucker=4, algorithm=alg)), g["inp"])
+    assert abs(rel_diff(_tucker_dense(t), g["inp"]) - e_r) <= 1e-10
+    g = load_case("round_general_f64")
+    t = tn.round(gpu_tensor(g["inp"]), eps=1e-6, algorithm=alg)
+    assert ranks(to_list(t.cores)) == ranks(g[f"{alg}_cores"]) and _tk(t.cores) == _tk(g[f"{alg}_cores"])
+    ref = oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert rel_diff(_tucker_dense(t), ref) <= 1e-9
+    u = t + t                                              # factors survive + / dot / scalar *
+    assert rel_diff(u.torch().cpu(), 2 * ref) <= 1e-9
+    assert abs(tn.dot(t, t).item() - (ref * ref).sum().item()) <= 1e-9 * (ref * ref).sum().item()
+
+
+def test_known_answer_eps_ctor_device():
+    """decompositions.ipynb cell 14 on the device: tn.Tensor(full, eps=1e-5) -> TT [1,4,6,1], Tucker 4,5,6, 8.3402e-06."""
+    from parity import analytic_128
+    full = analytic_128()
+    t = tn.Tensor(full, eps=1e-5, device="cuda")
+    assert t.ranks_tt.tolist() == [1, 4, 6, 1] and t.ranks_tucker.tolist() == [4, 5, 6]
+    assert abs(rel_diff(_tucker_dense(t), full) - 8.340228167320888e-06) < 1e-9
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_round_tucker_wide_modes(dt):
+    """Mode size 96 > 64: the factor QR runs through the blocked path, the factor eigenproblem is 96 x 96."""
+    torch.manual_seed(17)
+    S, I = [7, 9, 8], [96, 20, 96]
+    g = oracle.tt_randn(S, 4, dtype=torch.float64)
+    Us = [torch.randn(i, s_, dtype=torch.float64) for i, s_ in zip(I, S)]
+    inp = [c.to(dt) for c in oracle.tucker_absorb(g, Us)]
+    cores_r, Us_r = oracle.round_tucker(inp, None, eps=1e-4 if dt == torch.float32 else 1e-9)
+    t = gpu_tensor(inp)
+    t.round_tucker(eps=1e-4 if dt == torch.float32 else 1e-9)
+    assert _tk(t.cores) == _tk(cores_r) == [4, 9, 4]
+    X = dense(inp)
+    assert rel_diff(_tucker_dense(t), X) <= (2e-4 if dt == torch.float32 else 1e-9)
+    assert rel_diff(_tucker_dense(t), oracle.tucker_to_dense([c.double() for c in cores_r], [U.double() for U in Us_r])) <= (
+        2e-4 if dt == torch.float32 else 1e-9)
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""

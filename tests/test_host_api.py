@@ -196,3 +196,57 @@ def test_api_errors_and_quirks():
     assert torch.allclose((a + 1.5).torch(), a.torch() + 1.5)
     assert abs(tn.dot(a, b).item() - (a.torch() * b.torch()).sum().item()) < 1e-9
     assert abs(tn.norm(a).item() - a.torch().norm().item()) < 1e-9
+
+
+# ------------------------------------------------------------------ Tucker rounding / round() on the host mirror (8f-2)
+def _tk(cores):
+    return [c.shape[-2] for c in cores]
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_host_round_tucker_golden(alg):
+    from parity import load_case
+    g = load_case("round_tucker_eps_f64")
+    t = tn.Tensor([c.clone() for c in g["inp"]])
+    t.round_tucker(eps=1e-8, algorithm=alg)
+    assert _tk(t.cores) == _tk(g[f"{alg}_cores"])
+    assert max((a - b).abs().max().item() for a, b in zip(t.cores, g[f"{alg}_cores"])) < 1e-8
+    assert max((a - b).abs().max().item() for a, b in zip(t.Us, g[f"{alg}_Us"])) < 1e-8
+    assert tuple(t.shape) == (12, 10, 14, 11) and t.ranks_tucker.tolist() == _tk(t.cores)
+    X = oracle.tt_to_dense(g["inp"])
+    assert (t.torch() - X).norm() / X.norm() < 1e-8
+    # batch mode
+    gb = load_case("round_tucker_batch_f64")
+    tb = tn.Tensor([c.clone() for c in gb["inp"]], batch=True)
+    tb.round_tucker(rmax=2, algorithm=alg)
+    assert max((a - b).abs().max().item() for a, b in zip(tb.cores, gb[f"{alg}_cores"])) < 1e-9
+    assert max((a - b).abs().max().item() for a, b in zip(tb.Us, gb[f"{alg}_Us"])) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_host_ctor_tucker_and_round_golden(alg):
+    from parity import load_case
+    g = load_case("ctor_tucker_f64")
+    t = tn.Tensor(g["inp"], ranks_tucker=4, ranks_tt=3, algorithm=alg)
+    assert t.ranks_tt.tolist() == [1, 3, 3, 3, 1] and t.ranks_tucker.tolist() == [4, 4, 4, 4]
+    assert max((a - b).abs().max().item() for a, b in zip(t.cores, g[f"{alg}_cores"])) < 1e-8
+    assert max((a - b).abs().max().item() for a, b in zip(t.Us, g[f"{alg}_Us"])) < 1e-8
+    g = load_case("round_general_f64")
+    t = tn.round(tn.Tensor([c.clone() for c in g["inp"]]), eps=1e-6, algorithm=alg)
+    assert oracle.tt_ranks(t.cores) == oracle.tt_ranks(g[f"{alg}_cores"]) and _tk(t.cores) == _tk(g[f"{alg}_cores"])
+    ref = oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert (t.torch() - ref).norm() / ref.norm() < 1e-9
+    # factors survive +, scalar *, clone, dot
+    u = t + t
+    assert (u.torch() - 2 * ref).norm() / ref.norm() < 1e-9
+    assert abs(tn.dot(t, t).item() - (ref * ref).sum().item()) < 1e-9 * (ref * ref).sum().item()
+    assert ((t * 3).torch() - 3 * ref).norm() / ref.norm() < 1e-9
+
+
+def test_host_known_answer_eps_ctor():
+    """decompositions.ipynb cell 14: tn.Tensor(full, eps=1e-5)."""
+    from parity import analytic_128
+    full = analytic_128()
+    t = tn.Tensor(full, eps=1e-5)
+    assert t.ranks_tt.tolist() == [1, 4, 6, 1] and t.ranks_tucker.tolist() == [4, 5, 6]
+    assert abs(tn.relative_error(full, t).item() - 8.340228167320888e-06) < 1e-9

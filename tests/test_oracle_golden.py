@@ -117,3 +117,61 @@ def test_known_answers_notebook():
     assert oracle.tt_ranks(t) == [1, 4, 6, 1] == ka["ranks_eps1e-5_svd"]
     e = ((oracle.tt_to_dense(t) - full).norm() / full.norm()).item()
     assert abs(e - 8.3358e-06) < 1e-9
+
+
+# ------------------------------------------------------------------ Tucker rounding / round()
+def _tucker_ranks(cores):
+    return [c.shape[-2] for c in cores]
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_tucker_eps_f64(alg):
+    g = load_case("round_tucker_eps_f64")
+    cores, Us = oracle.round_tucker(g["inp"], None, eps=1e-8, algorithm=alg)
+    assert _tucker_ranks(cores) == _tucker_ranks(g[f"{alg}_cores"]) == [3, 5, 7, 3]  # bounded by R_k * R_{k+1}
+    assert _max_abs(cores, g[f"{alg}_cores"]) < 1e-8 and _max_abs(Us, g[f"{alg}_Us"]) < 1e-8
+    X = oracle.tt_to_dense(g["inp"])
+    assert (oracle.tucker_to_dense(cores, Us) - X).norm() / X.norm() < 1e-8
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_tucker_rmax_f32(alg):
+    g = load_case("round_tucker_rmax_f32")
+    cores, Us = oracle.round_tucker(g["inp"], None, rmax=3, algorithm=alg)
+    assert _tucker_ranks(cores) == [3, 3, 3, 3]
+    d_out, d_ref = oracle.tucker_to_dense(cores, Us), oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert (d_out - d_ref).norm() / d_ref.norm() < 1e-4
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_tucker_batch_f64(alg):
+    g = load_case("round_tucker_batch_f64")
+    cores, Us = oracle.round_tucker(g["inp"], None, rmax=2, algorithm=alg, batch=True)
+    assert _max_abs(cores, g[f"{alg}_cores"]) < 1e-9 and _max_abs(Us, g[f"{alg}_Us"]) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_ctor_tucker_f64(alg):
+    g = load_case("ctor_tucker_f64")
+    cores, Us = oracle.dense_to_tucker_tt(g["inp"], ranks_tucker=4, ranks_tt=3, algorithm=alg)
+    assert oracle.tt_ranks(cores) == [1, 3, 3, 3, 1] and _tucker_ranks(cores) == [4, 4, 4, 4]
+    assert _max_abs(cores, g[f"{alg}_cores"]) < 1e-8 and _max_abs(Us, g[f"{alg}_Us"]) < 1e-8
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_round_general_f64(alg):
+    g = load_case("round_general_f64")
+    cores, Us = oracle.round_general(g["inp"], eps=1e-6, algorithm=alg)
+    assert oracle.tt_ranks(cores) == oracle.tt_ranks(g[f"{alg}_cores"])
+    assert _tucker_ranks(cores) == _tucker_ranks(g[f"{alg}_cores"])
+    d_out, d_ref = oracle.tucker_to_dense(cores, Us), oracle.tucker_to_dense(g[f"{alg}_cores"], g[f"{alg}_Us"])
+    assert (d_out - d_ref).norm() / d_ref.norm() < 1e-9
+
+
+def test_known_answer_eps_ctor():
+    """decompositions.ipynb cell 14: tn.Tensor(full, eps=1e-5) -> TT ranks [1,4,6,1], Tucker 4,5,6, 8.3402e-06."""
+    full = analytic_128()
+    cores, Us = oracle.dense_to_tucker_tt(full, eps=1e-5)
+    assert oracle.tt_ranks(cores) == [1, 4, 6, 1] and _tucker_ranks(cores) == [4, 5, 6]
+    err = ((oracle.tucker_to_dense(cores, Us) - full).norm() / full.norm()).item()
+    assert abs(err - 8.340228167320888e-06) < 1e-10

@@ -323,8 +323,27 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
 
 
 # ----------------------------------------------------------------------------------------------
-def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+def mode_mul(core4: torch.Tensor, M3: torch.Tensor) -> torch.Tensor:
+    """[B, r0, S, r1] x_2 [B, a, S] -> [B, r0, a, r1] (the einsum of tensor.py:1790-1798, 1999-2002) as one
+    batched GEMM on the mode unfolding (the two permutes are layout copies)."""
+    Bt, r0, S, r1 = core4.shape
+    A = core4.permute(0, 2, 1, 3).reshape(Bt, S, r0 * r1)
+    out = _hip.gemm(M3, A)  # [B, a, r0*r1]
+    return out.reshape(Bt, M3.shape[1], r0, r1).permute(0, 2, 1, 3).contiguous()
+
+
+def factor_orthogonalize(c: List[torch.Tensor], Us, mu: int) -> None:
+    """tensor.py:1771-1798: QR of the Tucker factor [B, I, S], R pushed into the core."""
+    if Us is None or Us[mu] is None:
+        return
+    Q, R = qr(Us[mu].contiguous())
+    Us[mu] = Q
+    c[mu] = mode_mul(c[mu], R)
+
+
+def left_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor:
     """tensor.py:1800-1833 on [B, r0, I, r1] cores (in place on the list); returns R [B, k, r1]."""
+    factor_orthogonalize(c, Us, mu)
     Bt, r0, I, r1 = c[mu].shape
     Q, R = qr(c[mu].reshape(Bt, r0 * I, r1))
     k = Q.shape[2]
@@ -335,8 +354,9 @@ def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     return R
 
 
-def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+def right_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor:
     """tensor.py:1835-1879: QR of the transposed right unfolding; returns L [B, r0, k]."""
+    factor_orthogonalize(c, Us, mu)
     Bt, r0, I, r1 = c[mu].shape
     Mt = c[mu].reshape(Bt, r0, I * r1).transpose(1, 2).contiguous()  # layout only
     Q, Lt = qr(Mt)  # Mt (I r1 x r0) = Q (I r1 x k) Lt (k x r0)
@@ -366,8 +386,11 @@ def round_tt(
     rmax: Sequence[Optional[int]],
     algorithm: str,
     batch: bool,
+    Us=None,
 ) -> List[torch.Tensor]:
     """tensor.py:2008-2083 on [B, r0, I, r1] cores.  Returns new cores (inputs untouched).
+    ``Us``: Tucker factors; those of modes 0..N-2 are orthogonalised in place first (tensor.py:1815 inside the
+    L2R sweep; independent of the core QRs, so hoisting them keeps the fused sweep).
 
     Same two sweeps as the reference, with one fusion: the left-orthogonal cores Q_mu of the L2R sweep
     are never materialised.  Each QR leaves its reflectors in a workspace; in the R2L sweep the core
@@ -377,6 +400,8 @@ def round_tt(
     """
     c = list(cores4)
     N = len(c)
+    for i in range(N - 1):
+        factor_orthogonalize(c, Us, i)
     facs = []
     Rprev = None  # R factor still to be pushed into the current core
     for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
@@ -418,6 +443,63 @@ def round_tt(
     f, r0, I = facs[0]
     c[0] = _apply_q(f, left).reshape(f.batch, r0, I, left.shape[2])
     return c
+
+
+def round_tucker(cores4: Sequence[torch.Tensor], Us, eps, rmax, ndims, algorithm, batch):
+    """tensor.py:1911-2006 on [B, r0, S, r1] cores and [B, I, S] factors; returns (cores, Us).
+    Same kernel sequence as the TT sweeps: TSQR of the mode unfolding, truncated SVD of the small factor,
+    mode products as batched GEMMs."""
+    c = list(cores4)
+    N = len(c)
+    Us = [None] * N if Us is None else list(Us)
+    for i in range(N - 1):  # orthogonalize(-1), tensor.py:1944
+        left_orthogonalize(c, i, Us)
+    for mu in range(N - 1, -1, -1):
+        Bt, r0, S, r1 = c[mu].shape
+        if Us[mu] is None:  # tensor.py:1946-1958
+            Us[mu] = torch.eye(S, dtype=c[mu].dtype, device=c[mu].device).repeat(Bt, 1, 1)
+        Q, R = qr(c[mu].permute(0, 1, 3, 2).reshape(Bt, r0 * r1, S))  # tensor.py:1960-1984
+        c[mu] = Q.reshape(Bt, r0, r1, Q.shape[2]).permute(0, 1, 3, 2).contiguous()
+        Um = _hip.gemm(Us[mu], R, transB=True)  # tensor.py:1986
+        left, right = truncated_svd(Um, None, eps / math.sqrt(ndims), rmax[mu], True, algorithm, batch)
+        Us[mu] = left
+        c[mu] = mode_mul(c[mu], right)  # tensor.py:1999-2002
+        if mu > 0:
+            right_orthogonalize(c, mu, Us)
+    return c, Us
+
+
+def absorb_factors(cores4: Sequence[torch.Tensor], Us) -> List[torch.Tensor]:
+    """Contract every Tucker factor into its core (what tensor.py:1639-1687 does per mode)."""
+    return [c if U is None else mode_mul(c, U.contiguous()) for c, U in zip(cores4, Us)]
+
+
+def dense_tucker_tt(X: torch.Tensor, ranks_tucker, ranks_tt, algorithm, batch):
+    """``tn.Tensor(X, ranks_tucker=, ranks_tt=)`` for a dense device tensor (tensor.py:401-408).
+
+    The reference builds the full-rank TT, rounds the Tucker ranks mode N-1 .. 0 and then the TT ranks.  On the
+    orthogonalised full-rank train the factor of mode mu has the singular values / left singular vectors of the
+    mode-mu unfolding of the (already partly truncated) tensor, so this is the sequentially truncated HOSVD:
+    per mode, Gram + eigensolver + projection on the dense unfolding (same kernels as ``dense_tt_svd``),
+    followed by the TT-SVD of the small Tucker core."""
+    from . import _hostops
+
+    Bt = X.shape[0]
+    N = X.dim() - 1
+    Us: List[Optional[torch.Tensor]] = [None] * N
+    for mu in range(N - 1, -1, -1):
+        shp = list(X.shape)
+        Xp = X.movedim(mu + 1, 1).reshape(Bt, shp[mu + 1], -1)
+        if not Xp.is_contiguous():
+            Xp = Xp.contiguous()
+        left, right = truncated_svd(Xp, None, 1e-14 / math.sqrt(N), ranks_tucker[mu], True, algorithm, batch)
+        Us[mu] = left
+        S = left.shape[2]
+        rest = shp[1:mu + 1] + shp[mu + 2:]
+        X = right.reshape([Bt, S] + rest).movedim(1, mu + 1).contiguous()
+    if ranks_tt is None:
+        return _hostops.full_rank_tt(X), Us  # views / identity cores only (layout)
+    return dense_tt_svd(X, 1e-14, list(ranks_tt), algorithm, batch), Us
 
 
 def dense_tt_svd(

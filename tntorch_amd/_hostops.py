@@ -109,8 +109,25 @@ def _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch, squeeze):
     return left, M2
 
 
-def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+def mode_mul(core4: torch.Tensor, M3: torch.Tensor) -> torch.Tensor:
+    """[B, r0, S, r1] x_2 [B, a, S] -> [B, r0, a, r1] (the einsum of tensor.py:1790-1798, 1999-2002)."""
+    if core4.shape[0] == 1:
+        return torch.einsum("ijk,aj->iak", core4[0], M3[0])[None]
+    return torch.einsum("bijk,baj->biak", core4, M3)
+
+
+def factor_orthogonalize(c: List[torch.Tensor], Us, mu: int) -> None:
+    """tensor.py:1771-1798: QR of the Tucker factor [B, I, S], R pushed into the core."""
+    if Us is None or Us[mu] is None:
+        return
+    Q, R = qr(Us[mu])
+    Us[mu] = Q
+    c[mu] = mode_mul(c[mu], R)
+
+
+def left_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor:
     """tensor.py:1800-1833 on [B, r0, I, r1] cores."""
+    factor_orthogonalize(c, Us, mu)
     Bt, r0, I, r1 = c[mu].shape
     Q, R = qr(c[mu].reshape(Bt, r0 * I, r1))
     k = Q.shape[2]
@@ -120,8 +137,9 @@ def left_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     return R
 
 
-def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
+def right_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor:
     """tensor.py:1835-1879."""
+    factor_orthogonalize(c, Us, mu)
     Bt, r0, I, r1 = c[mu].shape
     Q, Lt = qr(_t(c[mu].reshape(Bt, r0, I * r1)))
     Q, L = _t(Q), _t(Lt)
@@ -132,12 +150,12 @@ def right_orthogonalize(c: List[torch.Tensor], mu: int) -> torch.Tensor:
     return L
 
 
-def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch) -> List[torch.Tensor]:
-    """tensor.py:2008-2083."""
+def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch, Us=None) -> List[torch.Tensor]:
+    """tensor.py:2008-2083 (``Us``: Tucker factors, orthogonalised in place by the L2R sweep)."""
     c = list(cores4)
     N = len(c)
     for mu in range(N - 1):
-        left_orthogonalize(c, mu)
+        left_orthogonalize(c, mu, Us)
     if batch:
         delta = None
     else:
@@ -151,6 +169,43 @@ def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch) -> Lis
         prev = c[mu - 1]
         c[mu - 1] = _mm(prev.reshape(Bt, prev.shape[1] * prev.shape[2], R), left).reshape(Bt, prev.shape[1], prev.shape[2], r)
     return c
+
+
+def round_tucker(cores4: Sequence[torch.Tensor], Us, eps, rmax, ndims, algorithm, batch):
+    """tensor.py:1911-2006 on [B, r0, S, r1] cores and [B, I, S] factors; returns (cores, Us)."""
+    c = list(cores4)
+    N = len(c)
+    Us = [None] * N if Us is None else list(Us)
+    for i in range(N - 1):  # orthogonalize(-1), tensor.py:1944
+        left_orthogonalize(c, i, Us)
+    for mu in range(N - 1, -1, -1):
+        Bt, r0, S, r1 = c[mu].shape
+        if Us[mu] is None:  # tensor.py:1946-1958
+            Us[mu] = torch.eye(S, dtype=c[mu].dtype, device=c[mu].device).repeat(Bt, 1, 1)
+        Q, R = qr(c[mu].permute(0, 1, 3, 2).reshape(Bt, r0 * r1, S))  # tensor.py:1960-1984
+        c[mu] = Q.reshape(Bt, r0, r1, Q.shape[2]).permute(0, 1, 3, 2)
+        Us[mu] = _mm(Us[mu], _t(R))  # tensor.py:1986
+        left, right = truncated_svd(Us[mu], None, eps / math.sqrt(ndims), rmax[mu], True, algorithm, batch)
+        Us[mu] = left.to(c[mu].dtype)
+        c[mu] = mode_mul(c[mu], right.to(c[mu].dtype))  # tensor.py:1999-2002
+        if mu > 0:
+            right_orthogonalize(c, mu, Us)
+    return c, Us
+
+
+def absorb_factors(cores4: Sequence[torch.Tensor], Us) -> List[torch.Tensor]:
+    """Contract every Tucker factor into its core (what tensor.py:1639-1687 does per mode)."""
+    return [c if U is None else mode_mul(c, U) for c, U in zip(cores4, Us)]
+
+
+def dense_tucker_tt(X: torch.Tensor, ranks_tucker, ranks_tt, algorithm, batch):
+    """tensor.py:401-408: full-rank TT, ``round_tucker(rmax=ranks_tucker)``, ``round_tt(rmax=ranks_tt)``."""
+    c = full_rank_tt(X)
+    N = len(c)
+    c, Us = round_tucker(c, None, 1e-14, ranks_tucker, N, algorithm, batch)
+    if ranks_tt is not None:
+        c = round_tt(c, 1e-14, ranks_tt, algorithm, batch, Us)
+    return c, Us
 
 
 def full_rank_tt(X: torch.Tensor) -> List[torch.Tensor]:

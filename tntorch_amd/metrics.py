@@ -26,8 +26,8 @@ def dot(t1, t2):
         raise ValueError("Batched tensors are not supproted.")
     if t1.shape != t2.shape:
         raise ValueError("Dot product requires leading dimensions to be equal, but they are {} and {}".format(t1.shape, t2.shape))
-    c1 = t1._norm4()
-    return ops_for(c1[0]).dot(c1, t2._norm4())  # device tensors: Lprod chain on ttr_gemm
+    c1 = t1._absorbed4()  # Tucker factors contracted in (the reference contracts U1^T U2 instead: same value)
+    return ops_for(c1[0]).dot(c1, t2._absorbed4())  # device tensors: Lprod chain on ttr_gemm
 
 
 def dist(t1, t2):

@@ -1,17 +1,19 @@
 """``Tensor``: the tensor-train container behind which the MI355X sweeps sit.
 
-Drop-in for the TT subset of ``tntorch.Tensor`` (tntorch/tensor.py:107-2287): same
+Drop-in for the TT / TT-Tucker subset of ``tntorch.Tensor`` (tntorch/tensor.py:107-2287): same
 constructor keywords, attributes (``cores``, ``Us``, ``batch``, ``idxs``) and methods on
 the orthogonalisation / rounding path -- ``left_orthogonalize`` / ``right_orthogonalize`` /
-``orthogonalize`` (tensor.py:1800-1909), ``round_tt`` (tensor.py:2008-2083), the dense
-``ranks_tt=`` constructor (tensor.py:401-408) -- plus the thin helpers the reference's
-tests use around them (``torch()``, ``clone()``, ``ranks_tt``, ``+``, scalar ``* /``).
+``orthogonalize`` / ``factor_orthogonalize`` (tensor.py:1771-1909), ``round_tt`` (tensor.py:2008-2083),
+``round_tucker`` (tensor.py:1911-2006), ``round`` (tensor.py:2085-2098), the dense
+``ranks_tt=`` / ``ranks_tucker=`` / ``eps=`` constructors (tensor.py:401-408, 436-439) -- plus the thin
+helpers the reference's tests use around them (``torch()``, ``clone()``, ``ranks_tt``, ``+``, scalar ``* /``).
 
 Cores are ``[R_k, I_k, R_{k+1}]`` row-major tensors (``batch=True`` prepends ``B``); the
 methods REBIND list entries and never write into the storage of the tensors they were
 given (tensor.py:1818-1832, 2066-2083).  CPU cores run the host mirror, device cores run
-the HIP kernels; CP cores, Tucker factors and the other tensor-network formats of the
-reference are outside this package's scope and raise ``NotImplementedError``.
+the HIP kernels; Tucker factors ``Us[n]`` are ``[I_n, S_n]`` matrices (or ``None``); CP cores and the
+other tensor-network formats of the reference are outside this package's scope and raise
+``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -58,9 +60,7 @@ class Tensor(object):
         nb = 1 if self.batch else 0
         if ranks_cp is not None:
             _not_in_scope("CP-ALS (ranks_cp)")
-        if ranks_tucker is not None:
-            _not_in_scope("Tucker rounding (ranks_tucker)")
-
+        dense_Us = None
         if isinstance(data, (list, tuple)):  # explicit cores (tensor.py:165-192)
             cores = list(data)
             if not all(isinstance(c, torch.Tensor) and nb + 2 <= c.dim() <= nb + 3 for c in cores):
@@ -84,22 +84,44 @@ class Tensor(object):
                 )
             if data.dim() == 0:
                 data = data * torch.ones(1, device=data.device, dtype=data.dtype)
-            if eps is not None and ranks_tt is not None:
+            if eps is not None and (ranks_tt is not None or ranks_tucker is not None):
                 raise ValueError("Specify eps or ranks, but not both")
-            self.cores = self._from_dense(data, ranks_tt, eps, algorithm)
+            if ranks_tucker is not None:
+                self.cores, dense_Us = self._from_dense_tucker(data, ranks_tucker, ranks_tt, algorithm)
+            else:
+                self.cores = self._from_dense(data, ranks_tt, eps, algorithm)
 
         N = len(self.cores)
+        if dense_Us is not None:
+            Us = dense_Us
         if Us is None:
             Us = [None] * N
-        if any(U is not None for U in Us):
-            _not_in_scope("Tucker factors (Us)")
-        self.Us = list(Us)
+        Us = list(Us)
+        if len(Us) != N:
+            raise ValueError("There must be one Tucker factor (or None) per core")
+        for n in range(N):  # tensor.py:410-424
+            if Us[n] is None:
+                continue
+            if device is not None:
+                Us[n] = Us[n].to(device)
+            assert Us[n].dim() == nb + 2
+            assert self.cores[n].shape[-2] == Us[n].shape[-1]
+        self.Us = Us
         if requires_grad:
             for n in range(N):
                 self.cores[n].requires_grad_()
+                if self.Us[n] is not None:
+                    self.Us[n].requires_grad_()
         if idxs is None:
             idxs = [torch.arange(sh, device=self.cores[0].device) for sh in self.shape]
         self.idxs = idxs
+        if eps is not None:  # tensor.py:436-439
+            if isinstance(data, (list, tuple)):
+                if ranks_tt is not None or ranks_tucker is not None:
+                    raise ValueError("Specify eps or ranks, but not both")
+                self.round(eps, algorithm=algorithm)
+            else:  # the TT stage of round() already ran inside _from_dense
+                self._round_tucker_stage(data, eps, algorithm)
 
     # ------------------------------------------------------------------ dense -> TT
     def _from_dense(self, data: torch.Tensor, ranks_tt, eps, algorithm) -> List[torch.Tensor]:
@@ -113,8 +135,8 @@ class Tensor(object):
         if N == 1:
             return self._denorm([X.reshape(X.shape[0], 1, X.shape[1], 1)])
         if eps is not None:
-            # tensor.py:436-439 goes through round(): TT rounding, then Tucker rounding with the
-            # remaining budget.  Only the TT part belongs to this path.
+            # tensor.py:436-439 goes through round(): TT rounding here, then (``_round_tucker_stage``) Tucker
+            # rounding with the remaining budget.
             rmax = [None] * (N - 1)
             e = eps
         else:
@@ -124,6 +146,35 @@ class Tensor(object):
         ops = ops_for(X)
         return self._denorm(ops.dense_tt_svd(X, e, rmax, algorithm, self.batch))
 
+    def _from_dense_tucker(self, data: torch.Tensor, ranks_tucker, ranks_tt, algorithm):
+        """tensor.py:401-408 with ``ranks_tucker`` (and optionally ``ranks_tt``)."""
+        X = data if self.batch else data[None]
+        N = X.dim() - 1
+        rtk = list(ranks_tucker) if hasattr(ranks_tucker, "__len__") else [ranks_tucker] * N
+        assert len(rtk) == N
+        rtt = None
+        if ranks_tt is not None:
+            rtt = list(ranks_tt) if hasattr(ranks_tt, "__len__") else [ranks_tt] * (N - 1)
+            assert len(rtt) == N - 1
+        c, Us = ops_for(X).dense_tucker_tt(X, rtk, rtt, algorithm, self.batch)
+        return self._denorm(c), [U if self.batch else U[0] for U in Us]
+
+    def _round_tucker_stage(self, data: torch.Tensor, eps: float, algorithm):
+        """Second half of ``round(eps)`` for the ``eps=`` constructor (tensor.py:2094-2098): the error reached
+        by the TT stage is measured against the dense input itself."""
+        from . import _hostops
+        from .metrics import relative_error
+
+        if self.dim() == 1:
+            return
+        if data.device.type == "cpu":  # exactly the reference: TT-vs-TT error against the full-rank train
+            X = data if self.batch else data[None]
+            reached = float(relative_error(Tensor(self._denorm(_hostops.full_rank_tt(X)), batch=self.batch), self))
+        else:
+            reached = float(relative_error(data, self))
+        if reached < eps:
+            self.round_tucker((1 + eps) / (1 + reached) - 1, algorithm=algorithm)
+
     # ------------------------------------------------------------------ layout helpers
     def _norm4(self) -> List[torch.Tensor]:
         """Cores as [B, r0, I, r1] views (B = 1 for non-batch tensors)."""
@@ -132,9 +183,22 @@ class Tensor(object):
     def _denorm(self, cores4: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         return list(cores4) if self.batch else [c[0] for c in cores4]
 
-    def _check_tt(self):
-        if any(U is not None for U in self.Us):
-            _not_in_scope("Tucker factors (Us)")
+    def _norm_us(self) -> List[Optional[torch.Tensor]]:
+        """Factors as [B, I, S] (B = 1 for non-batch tensors)."""
+        return [U if (U is None or self.batch) else U[None] for U in self.Us]
+
+    def _denorm_us(self, Us3) -> List[Optional[torch.Tensor]]:
+        return [U if (U is None or self.batch) else U[0] for U in Us3]
+
+    def _has_factors(self) -> bool:
+        return any(U is not None for U in self.Us)
+
+    def _absorbed4(self) -> List[torch.Tensor]:
+        """Cores [B, r0, I, r1] with the Tucker factors contracted in."""
+        c = self._norm4()
+        if not self._has_factors():
+            return c
+        return ops_for(c[0]).absorb_factors(c, self._norm_us())
 
     # ------------------------------------------------------------------ properties (tensor.py:836-919)
     @property
@@ -142,8 +206,8 @@ class Tensor(object):
         shape = []
         if self.batch:
             shape.append(len(self.cores[0]))
-        for c in self.cores:
-            shape.append(c.shape[-2])
+        for c, U in zip(self.cores, self.Us):
+            shape.append(c.shape[-2] if U is None else U.shape[-2])  # tensor.py:836-859
         return torch.Size(shape)
 
     def size(self):
@@ -175,27 +239,30 @@ class Tensor(object):
         return torch.round(torch.prod(torch.tensor(self.shape).double()))
 
     def numcoef(self):
-        return sum(c.numel() for c in self.cores)
+        return sum(c.numel() for c in self.cores) + sum(U.numel() for U in self.Us if U is not None)
 
     def __repr__(self):
         fmt = "{}D TT tensor (batch)" if self.batch else "{}D TT tensor"
-        return fmt.format(self.dim()) + ": shape {}, TT ranks {}, device {}, dtype {}".format(
-            list(self.shape), self.ranks_tt.tolist(), self.cores[0].device, self.cores[0].dtype
+        return fmt.format(self.dim()) + ": shape {}, TT ranks {}, Tucker ranks {}, device {}, dtype {}".format(
+            list(self.shape), self.ranks_tt.tolist(), self.ranks_tucker.tolist(), self.cores[0].device,
+            self.cores[0].dtype
         )
 
     # ------------------------------------------------------------------ copies / conversion
     def clone(self):
         """tensor.py:2213-2229."""
-        return Tensor([c.clone() for c in self.cores], idxs=self.idxs, batch=self.batch)
+        Us = [None if U is None else U.clone() for U in self.Us]
+        return Tensor([c.clone() for c in self.cores], Us=Us, idxs=self.idxs, batch=self.batch)
 
     def to(self, device):
         """tensor.py:1689-1700 (in place, returns self)."""
         self.cores = [c.to(device) for c in self.cores]
+        self.Us = [None if U is None else U.to(device) for U in self.Us]
         return self
 
     def torch(self):
-        """Decompress into a dense torch tensor (tensor.py:1639-1687, TT cores only)."""
-        c = self._norm4()
+        """Decompress into a dense torch tensor (tensor.py:1639-1687, TT / TT-Tucker)."""
+        c = self._absorbed4()
         out = ops_for(c[0]).decompress(c)  # device tensors: chain of MFMA GEMMs (ttr_gemm)
         return out if self.batch else out[0]
 
@@ -219,11 +286,14 @@ class Tensor(object):
         if self.shape != other.shape:
             raise ValueError("tntorch_amd: + requires equal shapes (broadcasting is out of scope)")
         N = self.dim()
+        # Tucker factors are contracted into the cores first (the reference concatenates them instead,
+        # tensor.py:445-668: same tensor, different -- equally redundant -- representation)
+        ca, cb = self._denorm(self._absorbed4()), other._denorm(other._absorbed4())
         if N == 1:
-            return Tensor([self.cores[0] + other.cores[0]], batch=self.batch)
+            return Tensor([ca[0] + cb[0]], batch=self.batch)
         cores = []
         for n in range(N):
-            a, b = self.cores[n], other.cores[n]
+            a, b = ca[n], cb[n]
             if n == 0:
                 cores.append(torch.cat([a, b], dim=-1))
             elif n == N - 1:
@@ -251,7 +321,7 @@ class Tensor(object):
             _not_in_scope("the Hadamard product of two tensor trains")
         cores = [c.clone() for c in self.cores]
         cores[0] = cores[0] * other
-        return Tensor(cores, batch=self.batch)
+        return Tensor(cores, Us=[None if U is None else U.clone() for U in self.Us], batch=self.batch)
 
     def __rmul__(self, other):
         return self * other
@@ -265,20 +335,24 @@ class Tensor(object):
     def left_orthogonalize(self, mu: int):
         """Make core ``mu`` left-orthogonal, push ``R`` into core ``mu+1`` (tensor.py:1800-1833)."""
         assert 0 <= mu < self.dim() - 1
-        self._check_tt()
-        c = self._norm4()
-        R = ops_for(c[mu]).left_orthogonalize(c, mu)
-        self.cores = self._denorm(c)
+        c, Us = self._norm4(), self._norm_us()
+        R = ops_for(c[mu]).left_orthogonalize(c, mu, Us)
+        self.cores, self.Us = self._denorm(c), self._denorm_us(Us)
         return R if self.batch else R[0]
 
     def right_orthogonalize(self, mu: int):
         """Make core ``mu`` right-orthogonal, push ``L`` into core ``mu-1`` (tensor.py:1835-1879)."""
         assert 1 <= mu < self.dim()
-        self._check_tt()
-        c = self._norm4()
-        L = ops_for(c[mu]).right_orthogonalize(c, mu)
-        self.cores = self._denorm(c)
+        c, Us = self._norm4(), self._norm_us()
+        L = ops_for(c[mu]).right_orthogonalize(c, mu, Us)
+        self.cores, self.Us = self._denorm(c), self._denorm_us(Us)
         return L if self.batch else L[0]
+
+    def factor_orthogonalize(self, mu: int):
+        """Push the non-orthogonal part of factor ``mu`` into its core (tensor.py:1771-1798)."""
+        c, Us = self._norm4(), self._norm_us()
+        ops_for(c[mu]).factor_orthogonalize(c, Us, mu)
+        self.cores, self.Us = self._denorm(c), self._denorm_us(Us)
 
     def orthogonalize(self, mu: int):
         """Make the train ``mu``-orthogonal; returns the last ``R, L`` (tensor.py:1881-1909)."""
@@ -314,27 +388,50 @@ class Tensor(object):
         assert algorithm in ("svd", "eig")
         for r in rmax:
             assert r is None or r >= 1
-        self._check_tt()
         if N == 1:
             return
-        c = self._norm4()
+        c, Us = self._norm4(), self._norm_us()
         ops = ops_for(c[0])
         start = time.time()
-        out = ops.round_tt(c, eps, list(rmax), algorithm, self.batch)
+        out = ops.round_tt(c, eps, list(rmax), algorithm, self.batch, Us if self._has_factors() else None)
+        self.Us = self._denorm_us(Us)
         if verbose:
             if c[0].is_cuda:
                 torch.cuda.synchronize()
             print("round_tt time (orthogonalization + truncation sweeps):", time.time() - start)
         self.cores = self._denorm(out)
 
-    def round_tucker(self, *args, **kwargs):
-        _not_in_scope("round_tucker (SURVEY 8f-2)")
+    def round_tucker(
+        self,
+        eps: float = 1e-14,
+        rmax: Optional[Union[int, Sequence[int]]] = None,
+        dim: Optional[Union[Sequence[int], str]] = "all",
+        algorithm: Optional[str] = "svd",
+    ):
+        """Recompress in place by reducing the Tucker ranks (tensor.py:1911-2006).
+
+        As in the reference every mode is processed; ``dim`` only sets how the error budget is split
+        (``eps / sqrt(len(dim))`` per mode, tensor.py:1936-1939, 1991)."""
+        N = self.dim()
+        if not hasattr(rmax, "__len__"):
+            rmax = [rmax] * N
+        assert len(rmax) == N
+        assert algorithm in ("svd", "eig")
+        if dim == "all":
+            dim = range(N)
+        if not hasattr(dim, "__len__"):
+            dim = [dim] * N
+        c, Us = self._norm4(), self._norm_us()
+        c, Us = ops_for(c[0]).round_tucker(c, Us, eps, list(rmax), len(dim), algorithm, self.batch)
+        self.cores, self.Us = self._denorm(c), self._denorm_us(Us)
 
     def round(self, eps: float = 1e-14, **kwargs):
-        """tensor.py:2085-2098 restricted to the TT format: ``round_tt(eps)``.
+        """General recompression (tensor.py:2085-2098): TT ranks first, then Tucker rounding with the
+        remaining error budget."""
+        from .metrics import relative_error
 
-        The reference spends any leftover error budget on a Tucker rounding of the modes;
-        that second stage is outside this package's scope, so the result here keeps
-        ``Us = None`` and satisfies the same error bound with TT ranks only.
-        """
+        copy = self.clone()
         self.round_tt(eps, **kwargs)
+        reached = relative_error(copy, self)
+        if reached < eps:
+            self.round_tucker((1 + eps) / (1 + float(reached)) - 1, **kwargs)
