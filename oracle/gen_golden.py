@@ -276,6 +276,29 @@ def case_round_general():
           "dtype": "float64", "eps": 1e-6}, **groups)
 
 
+def case_cp_als():
+    """tn.Tensor(X, ranks_cp=R) -- tensor.py:210-400 (config C4's algorithm at a size that fits a fixture)."""
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(16)
+    fac = [torch.randn(i, 3) for i in (12, 10, 9, 11)]
+    low = torch.einsum("ar,br,cr,dr->abcd", *fac)
+    X = low / low.norm() + 1e-2 * torch.randn(12, 10, 9, 11) / np.sqrt(low.numel())
+    groups = {"inp": X.numpy()}
+    meta = {"what": "tn.Tensor(X, ranks_cp=R, max_iter=K), X = rank-3 CP + 1e-2 noise, 12x10x9x11", "ref": "tensor.py:210-400",
+            "dtype": "float64", "runs": {}}
+    for name, R, K in (("r3_it1", 3, 1), ("r3_it25", 3, 25), ("r5_it4", 5, 4)):
+        t = tn.Tensor(X, ranks_cp=R, max_iter=K)
+        groups[name] = npl(t.cores)
+        meta["runs"][name] = {"R": R, "max_iter": K, "relerr": tn.relative_error(X, t).item()}
+    torch.manual_seed(17)
+    Y = torch.randn(8, 7, 6, dtype=torch.float32)
+    t = tn.Tensor(Y, ranks_cp=4, max_iter=6)
+    groups["f32_inp"] = Y.numpy()
+    groups["f32_r4_it6"] = npl(t.cores)
+    meta["runs"]["f32_r4_it6"] = {"R": 4, "max_iter": 6, "relerr": tn.relative_error(Y, t).item()}
+    save("cp_als", meta, **groups)
+
+
 def case_known_answers():
     """docs/tutorials/decompositions.ipynb cells 1, 3, 18 (analytic 128^3 function)."""
     torch.set_default_dtype(torch.float64)
@@ -311,6 +334,7 @@ if __name__ == "__main__":
     case_round_tucker()
     case_ctor_tucker()
     case_round_general()
+    case_cp_als()
     case_known_answers()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(META, f, indent=1, sort_keys=True)

@@ -38,6 +38,9 @@ __all__ = [
     "tucker_to_dense",
     "dense_to_tucker_tt",
     "relative_error_tt",
+    "cp_hosvd_init",
+    "cp_to_dense",
+    "cp_als",
     "full_rank_tt",
     "dense_to_tt",
     "tt_to_dense",
@@ -383,6 +386,60 @@ def dense_to_tucker_tt(data: torch.Tensor, ranks_tucker=None, ranks_tt=None, eps
     if ranks_tt is not None:
         cores = round_tt(cores, rmax=ranks_tt, algorithm=algorithm, batch=batch, Us=Us)
     return cores, Us
+
+
+# --------------------------------------------------------------------------
+# CP-ALS -- tensor.py:210-400, ``tn.Tensor(data, ranks_cp=R)``, non-batch,
+# ranks_tucker=None.  A CP tensor is a list of 2-D factors [I_n, R].
+# --------------------------------------------------------------------------
+def cp_hosvd_init(data: torch.Tensor, R: int) -> Cores:
+    """tensor.py:228-277: leading R eigenvectors of every mode Gram matrix (eigh ascending -> reversed);
+    random completion when I_n < R (consumes the global torch RNG exactly like the reference)."""
+    cores = []
+    for n in range(data.dim()):
+        gram = unfolding(data, n)
+        gram = gram @ _t(gram)
+        eigvals, eigvecs = torch.linalg.eigh(gram)
+        reverse = torch.arange(len(eigvals) - 1, -1, -1)
+        idx = torch.argsort(eigvals)[reverse[:R]]
+        c = eigvecs[:, idx]
+        if c.shape[1] < R:
+            c = torch.cat((c, torch.randn(c.shape[0], R - c.shape[1], dtype=c.dtype)), dim=1)
+        cores.append(c)
+    return cores
+
+
+def cp_to_dense(cores: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Dense tensor of a CP decomposition: sum_r prod_n cores[n][i_n, r] (tensor.py:1639-1687 on 2-D cores)."""
+    acc = cores[0]  # [I_0, R]
+    for c in cores[1:]:
+        acc = torch.einsum("ar,ir->air", acc, c).reshape(-1, c.shape[1])
+    return acc.sum(dim=1).reshape([c.shape[0] for c in cores])
+
+
+def cp_als(data: torch.Tensor, R: int, max_iter: int = 25, tol: float = 1e-4, init: Optional[Cores] = None):
+    """tensor.py:279-394.  Returns (cores, errors) -- ``errors[k]`` = relative error after sweep k."""
+    N = data.dim()
+    cores = cp_hosvd_init(data, R) if init is None else [c.clone() for c in init]
+    data_norm = torch.norm(data)
+    grams = [None] + [_t(cores[n]) @ cores[n] for n in range(1, N)]  # tensor.py:279-282
+    errors = []
+    for _ in range(max_iter):  # tensor.py:295
+        for n in range(N):
+            khatri = torch.ones(1, R, dtype=data.dtype)
+            prod = torch.ones(R, R, dtype=data.dtype)
+            for m in range(N - 1, -1, -1):  # tensor.py:328-334
+                if m != n:
+                    prod = prod * grams[m]
+                    khatri = torch.einsum("ir,jr->ijr", cores[m], khatri).reshape(-1, R)
+            unf = unfolding(data, n)
+            unf_khatri_t = _t(unf @ khatri)  # MTTKRP, tensor.py:336-338
+            cores[n] = _t(torch.linalg.lstsq(prod, unf_khatri_t).solution)  # tensor.py:339-341
+            grams[n] = _t(cores[n]) @ cores[n]
+        errors.append(torch.norm(data - cp_to_dense(cores)) / data_norm)  # tensor.py:373-379
+        if len(errors) >= 2 and errors[-2] - errors[-1] < tol:  # tensor.py:380-381
+            break
+    return cores, errors
 
 
 # --------------------------------------------------------------------------

@@ -175,3 +175,19 @@ def test_known_answer_eps_ctor():
     assert oracle.tt_ranks(cores) == [1, 4, 6, 1] and _tucker_ranks(cores) == [4, 5, 6]
     err = ((oracle.tucker_to_dense(cores, Us) - full).norm() / full.norm()).item()
     assert abs(err - 8.340228167320888e-06) < 1e-10
+
+
+# ------------------------------------------------------------------ CP-ALS (SURVEY 8f-1, config C4's algorithm)
+def test_cp_als_golden():
+    g = load_case("cp_als")
+    runs = load_meta()["cases"]["cp_als"]["runs"]
+    X = g["inp"]
+    for name in ("r3_it1", "r3_it25", "r5_it4"):
+        cores, errors = oracle.cp_als(X, runs[name]["R"], max_iter=runs[name]["max_iter"])
+        assert max((a - b).abs().max().item() for a, b in zip(cores, g[name])) < 1e-7, name
+        err = ((oracle.cp_to_dense(cores) - X).norm() / X.norm()).item()
+        assert abs(err - runs[name]["relerr"]) < 1e-10 and abs(errors[-1].item() - err) < 1e-12
+    Y = g["f32_inp"]
+    cores, _ = oracle.cp_als(Y, 4, max_iter=6)
+    d_o, d_r = oracle.cp_to_dense(cores), oracle.cp_to_dense(g["f32_r4_it6"])
+    assert (d_o - d_r).norm() / d_r.norm() < 1e-4
