@@ -175,6 +175,20 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * CP-ALS building blocks (tn.Tensor(X, ranks_cp=R), tensor.py:279-394; BASELINE config C4).
+ * ttr_krp_contract:  out[p, q, r] = sum_j T[p, j, q, r] * B[j, r]   (T contiguous [P, J, Q, R], B is J x R with
+ * leading dimension ldb, out contiguous [P, Q, R]).  One step of a fused MTTKRP: the reference materialises the
+ * Khatri-Rao matrix (`torch.einsum("ir,jr->ijr")` chain, tensor.py:328-334) and a permuted copy of the dense
+ * unfolding (tensor.py:336) and multiplies them (tensor.py:338); here the tensor is first contracted with one
+ * factor by ttr_gemm (X read once) and the remaining modes are folded in with this kernel (Q = 1: trailing mode,
+ * P = 1: leading mode), each reading its input exactly once.
+ * ttr_hadamard: out[i] = a[i] * b[i] -- the Gram Hadamard product `prod *= grams[m]` (tensor.py:331).
+ */
+int ttr_krp_contract(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R,
+                     const void* T, const void* B, int64_t ldb, void* out, void* stream);
+int ttr_hadamard(int dtype, int64_t count, const void* a, const void* b, void* out, void* stream);
+
+/*
  * out[b] = sqrt(sum(x[b]^2)) over `count` contiguous elements (accumulated in double, stored in dtype).
  * Replaces: torch.norm(cores[-1]) tensor.py:2039-2051 and torch.norm(M) round.py:80.
  */

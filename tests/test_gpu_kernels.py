@@ -286,6 +286,23 @@ def test_qr_blocked_rank_deficient(dt):
     assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 2e-5, 1e-12)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_krp_contract_and_hadamard(dt):
+    """ttr_krp_contract: out[p,q,r] = sum_j T[p,j,q,r] B[j,r] (trailing mode Q = 1, leading mode P = 1, general)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(5)
+    for (P, J, Q, R) in [(37, 19, 1, 32), (1, 23, 301, 32), (5, 7, 3, 5), (70000, 3, 1, 4), (1, 256, 1000, 32), (3, 1, 2, 64), (2, 300, 9, 33)]:
+        T = torch.randn(P, J, Q, R, generator=g, dtype=torch.float64)
+        B = torch.randn(J, R, generator=g, dtype=torch.float64)
+        ref = torch.einsum("pjqr,jr->pqr", T, B)
+        out = h.krp_contract(T.to(dt).cuda(), B.to(dt).cuda()).cpu().double()
+        assert out.shape == (P, Q, R)
+        assert (out - ref).abs().max() / ref.abs().max() < tol(dt, 5e-6, 1e-13), (P, J, Q, R)
+    a = torch.randn(33, 65, generator=g, dtype=torch.float64)
+    b = torch.randn(33, 65, generator=g, dtype=torch.float64)
+    assert torch.allclose(h.hadamard(a.to(dt).cuda(), b.to(dt).cuda()).cpu().double(), (a.to(dt) * b.to(dt)).double(), rtol=0, atol=0)
+
+
 def test_unsupported_shapes_raise():
     h = _hip()
     with pytest.raises(NotImplementedError):

@@ -412,6 +412,43 @@ def test_round_tucker_wide_modes(dt):
         2e-4 if dt == torch.float32 else 1e-9)
 
 
+# ------------------------------------------------------------------ CP-ALS on the device (SURVEY 8f-1, config C4's algorithm)
+def test_golden_cp_als():
+    """tn.Tensor(X, ranks_cp=R) on the device vs the reference's factors (golden): HOSVD-initialised ALS is
+    deterministic up to the signs of the initial eigenvectors, which cancel in the reconstruction."""
+    g = load_case("cp_als")
+    runs = load_meta()["cases"]["cp_als"]["runs"]
+    X = g["inp"]
+    for name, tol_rec in (("r3_it1", 1e-9), ("r3_it25", 1e-7), ("r5_it4", 1e-6)):
+        t = tn.Tensor(X, ranks_cp=runs[name]["R"], max_iter=runs[name]["max_iter"], device="cuda")
+        assert all(c.dim() == 2 and c.is_cuda for c in t.cores) and tuple(t.shape) == (12, 10, 9, 11)
+        ours = oracle.cp_to_dense([c.cpu() for c in t.cores])
+        ref = oracle.cp_to_dense(g[name])
+        assert rel_diff(ours, ref) <= tol_rec, (name, rel_diff(ours, ref))
+        assert abs(rel_diff(ours, X) - runs[name]["relerr"]) <= 1e-8
+        assert abs(t.cp_errors[-1] - runs[name]["relerr"]) <= 1e-6      # algebraic error estimate of the sweep
+        assert rel_diff(t.torch().cpu(), ours) <= 1e-12                   # CP -> TT diagonal cores on the device
+    Y = g["f32_inp"]
+    t = tn.Tensor(Y, ranks_cp=4, max_iter=6, device="cuda")
+    e_o = rel_diff(oracle.cp_to_dense([c.cpu().double() for c in t.cores]), Y)
+    assert abs(e_o - runs["f32_r4_it6"]["relerr"]) <= 2e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_cp_als_recovers_low_rank(dt):
+    """tests/test_tensor.py:52-62 style: exact rank-R data is recovered; 5-mode and 2-mode tensors exercise
+    every branch of the fused MTTKRP (trailing / leading contractions, no contraction)."""
+    torch.manual_seed(23)
+    for shape, R in (([9, 8, 7, 6, 5], 3), ([40, 30], 4), ([20, 18, 16], 5)):
+        fac = [torch.randn(i, R, dtype=torch.float64) for i in shape]
+        X = oracle.cp_to_dense(fac).to(dt)
+        t = tn.Tensor(X, ranks_cp=R, max_iter=60, tol=1e-9 if dt == torch.float64 else 1e-6, device="cuda")
+        err = rel_diff(oracle.cp_to_dense([c.cpu().double() for c in t.cores]), X)
+        ref_cores, ref_err = oracle.cp_als(X.double(), R, max_iter=60, tol=1e-9 if dt == torch.float64 else 1e-6)
+        e_ref = rel_diff(oracle.cp_to_dense(ref_cores), X)
+        assert err <= max(10 * e_ref, 5e-3 if dt == torch.float32 else 1e-5), (shape, err, e_ref)
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""

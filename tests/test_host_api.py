@@ -176,7 +176,7 @@ def test_api_errors_and_quirks():
     with pytest.raises(AssertionError):
         t.left_orthogonalize(2)
     with pytest.raises(NotImplementedError):
-        tn.Tensor(torch.rand(4, 4, 4), ranks_cp=2)
+        tn.Tensor(torch.rand(3, 4, 4, 4), ranks_cp=2, batch=True)   # batched CP-ALS is out of scope
     # quirks 1, 5, 13, 14
     assert tn.Tensor(torch.ones(4, 4, 4), ranks_tt=3).ranks_tt.tolist() == [1, 1, 1, 1]
     z = tn.Tensor([torch.zeros(1, 5, 3), torch.zeros(3, 5, 3), torch.zeros(3, 5, 1)])
@@ -250,3 +250,24 @@ def test_host_known_answer_eps_ctor():
     t = tn.Tensor(full, eps=1e-5)
     assert t.ranks_tt.tolist() == [1, 4, 6, 1] and t.ranks_tucker.tolist() == [4, 5, 6]
     assert abs(tn.relative_error(full, t).item() - 8.340228167320888e-06) < 1e-9
+
+
+# ------------------------------------------------------------------ CP-ALS on the host mirror (8f-1)
+def test_host_cp_als_golden():
+    from parity import load_case, load_meta
+    g = load_case("cp_als")
+    runs = load_meta()["cases"]["cp_als"]["runs"]
+    for name in ("r3_it1", "r3_it25", "r5_it4"):
+        t = tn.Tensor(g["inp"], ranks_cp=runs[name]["R"], max_iter=runs[name]["max_iter"])
+        assert all(c.dim() == 2 for c in t.cores) and tuple(t.shape) == (12, 10, 9, 11)
+        assert max((a - b).abs().max().item() for a, b in zip(t.cores, g[name])) < 1e-9
+        assert abs(tn.relative_error(g["inp"], t).item() - runs[name]["relerr"]) < 1e-12
+    # CP factors behave as TT cores with diagonal slices everywhere else (tensor.py:1717-1769)
+    ref = oracle.cp_to_dense(g["r5_it4"])
+    assert (t.torch() - ref).norm() / ref.norm() < 1e-13
+    assert t.ranks_tt.tolist() == [5, 5, 5, 5, 5]
+    u = t.clone()
+    u.round_tt(eps=1e-10)
+    assert u.ranks_tt.tolist() == [1, 5, 5, 5, 1] and (u.torch() - ref).norm() / ref.norm() < 1e-9
+    with pytest.raises(ValueError):
+        tn.Tensor(g["inp"], ranks_cp=3, ranks_tt=2)

@@ -88,6 +88,8 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
          c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_krp_contract": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ttr_hadamard": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_debug_set_qr_stamps": (c_int, [c_void_p]),
     "ttr_prof_enable": (c_int, [c_int]),
     "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
@@ -372,6 +374,15 @@ def norm(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty((batch,), dtype=x.dtype, device=x.device)
     if batch == 0:
         return out
+    if count >= (1 << 20) and batch < 512:
+        # ttr_norm runs one workgroup per batch item: split long items into k chunks (norm of the chunk
+        # norms is exact: the second stage squares and sums in double) so that the whole chip streams
+        k = 4096
+        while k > 1 and count % k:
+            k //= 2
+        if k > 1:
+            part = norm(x.reshape(batch * k, count // k))
+            return norm(part.reshape(batch, k))
     _check(L.ttr_norm(dt, count, batch, x.data_ptr(), count, out.data_ptr(), _stream()), "ttr_norm")
     return out
 
@@ -389,6 +400,31 @@ def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
     code = L.ttr_scale_cols(dt, rows, cols, batch, X.data_ptr(), ldx, sX, s.data_ptr(), s.shape[-1], mode,
                             out.data_ptr(), cols, rows * cols, _stream())
     _check(code, "ttr_scale_cols")
+    return out
+
+
+def krp_contract(T: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """out[p, q, r] = sum_j T[p, j, q, r] * B[j, r] for contiguous T [P, J, Q, R], B [J, R]."""
+    L = lib()
+    dt = dtype_code(T.dtype)
+    assert T.dim() == 4 and B.dim() == 2 and T.is_cuda and T.dtype == B.dtype
+    P, J, Q, R = T.shape
+    assert B.shape[0] == J and B.shape[1] == R
+    T = T.contiguous()
+    B = B.contiguous()
+    out = torch.empty((P, Q, R), dtype=T.dtype, device=T.device)
+    code = L.ttr_krp_contract(dt, P, J, Q, R, T.data_ptr(), B.data_ptr(), R, out.data_ptr(), _stream())
+    _check(code, "ttr_krp_contract")
+    return out
+
+
+def hadamard(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    L = lib()
+    dt = dtype_code(a.dtype)
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_cuda
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    _check(L.ttr_hadamard(dt, a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "ttr_hadamard")
     return out
 
 

@@ -593,3 +593,106 @@ def dense_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     one = torch.ones((1, 1, 1), dtype=a.dtype, device=a.device)
     _hip.gemm_axpby(b.reshape(1, n, 1), one, d, -1.0, 1.0)
     return _hip.norm(d.reshape(1, -1))[0]
+
+
+# ---------------------------------------------------------------------------------------------- CP-ALS
+def _sum_all(x: torch.Tensor) -> torch.Tensor:
+    """Sum of all entries as a 1 x n x 1 GEMM with a ones vector (split-K); returns a 0-d tensor."""
+    n = x.numel()
+    ones = torch.ones((1, n, 1), dtype=x.dtype, device=x.device)
+    return _hip.gemm(x.reshape(1, 1, n), ones).reshape(())
+
+
+def cp_hosvd_init(X: torch.Tensor, R: int) -> List[torch.Tensor]:
+    """tensor.py:228-277: leading R eigenvectors of every mode Gram matrix X_(n) X_(n)^T (split-K MFMA GEMM on
+    the dense unfolding; first / last mode without a copy, middle modes through one permuted copy)."""
+    N = X.dim()
+    cores = []
+    for n in range(N):
+        I = X.shape[n]
+        if n == N - 1 and N > 1:
+            A = X.reshape(1, -1, I)
+            G = _hip.gemm(A, A, transA=True)
+        else:
+            A = (X if n == 0 else X.movedim(n, 0).contiguous()).reshape(1, I, -1)
+            G = _hip.gemm(A, A, transB=True)
+        V, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, I, _hip.SOLVER_TRIDIAG)  # columns by decreasing eigenvalue
+        c = V[0][:, :R].contiguous()
+        if c.shape[1] < R:  # complete with random entries (tensor.py:262-277)
+            c = torch.cat((c, torch.randn(I, R - c.shape[1], dtype=c.dtype, device=c.device)), dim=1)
+        cores.append(c)
+    return cores
+
+
+def _cp_solve(prod: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """A = Y prod^+ for the symmetric PSD R x R Hadamard-of-Grams matrix (``torch.linalg.lstsq(prod, Y^T)``,
+    tensor.py:339-341): eigen-decomposition prod = V diag(s^2) V^T, A = ((Y V) / s / s) V^T."""
+    R = prod.shape[-1]
+    V, sg, _ = _eigh_any(prod.reshape(1, R, R), _hip.EIG_RAW, False, 0.0, R, _hip.SOLVER_TRIDIAG)
+    Z = _hip.gemm(Y[None], V, colscale=sg, colscale_mode=_hip.SCALE_DIV)
+    Z = _hip.scale_cols(Z, sg, _hip.SCALE_DIV)
+    return _hip.gemm(Z, V, transB=True)[0]
+
+
+def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False):
+    """``tn.Tensor(X, ranks_cp=R)`` for a dense device tensor (tensor.py:210-400, non-batch, HOSVD init).
+
+    Same alternating sweep as the reference (mode 0 .. N-1, Gauss-Seidel), restructured so that the dense
+    tensor is read TWICE per sweep instead of N times and nothing of size I^(N-1) x R or I^N is ever written:
+      * modes 0..N-2 start from  P = X x_{N-1} A_{N-1}  (one ttr_gemm over X; A_{N-1} only changes at the end
+        of the sweep) and fold the other factors in with ttr_krp_contract (trailing modes, then leading modes);
+      * mode N-1 starts from  X_(0)^T A_0  (second ttr_gemm over X) and folds modes 1..N-2 in;
+      * the R x R normal equations use the Hadamard product of the Gram matrices (ttr_hadamard) and the
+        tridiagonal eigensolver; the relative error comes from ||X||^2 - 2<X,T> + ||T||^2 with <X,T> taken from
+        the last MTTKRP (no dense reconstruction, tensor.py:373-379) -- resolved down to ~sqrt(eps).
+    Returns (factors [I_n, R], errors)."""
+    N = X.dim()
+    if N < 2:
+        raise NotImplementedError("tntorch_amd: CP-ALS needs at least 2 modes")
+    shape = list(X.shape)
+    A = cp_hosvd_init(X, R)
+    grams = [None] + [_hip.gemm(A[n][None], A[n][None], transA=True)[0] for n in range(1, N)]
+    xnorm = float(_hip.norm(X.reshape(1, -1))[0].item())
+    errors: List[float] = []
+
+    def had(skip):
+        out = None
+        for m in range(N - 1, -1, -1):
+            if m != skip:
+                out = grams[m] if out is None else _hip.hadamard(out, grams[m])
+        return out
+
+    for it in range(max_iter):
+        P_last = _hip.gemm(X.reshape(1, -1, shape[-1]), A[N - 1][None])[0]  # [I_0 * .. * I_{N-2}, R]
+        for n in range(N - 1):
+            T = P_last
+            for m in range(N - 2, n, -1):  # trailing modes
+                Pm = 1
+                for d in shape[:m]:
+                    Pm *= d
+                T = _hip.krp_contract(T.reshape(Pm, shape[m], 1, R), A[m])
+            for m in range(0, n):  # leading modes
+                Qm = 1
+                for d in shape[m + 1:n + 1]:
+                    Qm *= d
+                T = _hip.krp_contract(T.reshape(1, shape[m], Qm, R), A[m])
+            A[n] = _cp_solve(had(n), T.reshape(shape[n], R))
+            grams[n] = _hip.gemm(A[n][None], A[n][None], transA=True)[0]
+        T = _hip.gemm(X.reshape(1, shape[0], -1), A[0][None], transA=True)[0]  # [I_1 * .. * I_{N-1}, R]
+        for m in range(1, N - 1):
+            Qm = 1
+            for d in shape[m + 1:]:
+                Qm *= d
+            T = _hip.krp_contract(T.reshape(1, shape[m], Qm, R), A[m])
+        Y = T.reshape(shape[N - 1], R)
+        A[N - 1] = _cp_solve(had(N - 1), Y)
+        grams[N - 1] = _hip.gemm(A[N - 1][None], A[N - 1][None], transA=True)[0]
+        xt = float(dense_dot(Y, A[N - 1]).item())
+        tt = float(_sum_all(_hip.hadamard(had(N - 1), grams[N - 1])).item())
+        err = math.sqrt(max(xnorm * xnorm - 2.0 * xt + tt, 0.0)) / xnorm
+        errors.append(err)
+        if verbose:
+            print("iter: {} | eps: {:.8f}".format(it, err))
+        if len(errors) >= 2 and errors[-2] - errors[-1] < tol:  # tensor.py:380-381
+            break
+    return A, errors

@@ -271,3 +271,46 @@ def dense_norm(a: torch.Tensor) -> torch.Tensor:
 
 def dense_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.dist(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- CP-ALS
+def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False):
+    """tensor.py:210-400 (non-batch, HOSVD init), the reference's operator sequence on the CPU."""
+    N = X.dim()
+
+    def unf(n):
+        return X.permute([n] + list(range(n)) + list(range(n + 1, N))).reshape(X.shape[n], -1)
+
+    A = []
+    for n in range(N):  # tensor.py:228-277
+        g = unf(n)
+        g = g @ _t(g)
+        w, V = torch.linalg.eigh(g)
+        reverse = torch.arange(len(w) - 1, -1, -1)
+        idx = torch.argsort(w)[reverse[:R]]
+        c = V[:, idx]
+        if c.shape[1] < R:
+            c = torch.cat((c, torch.randn(c.shape[0], R - c.shape[1], dtype=c.dtype, device=c.device)), dim=1)
+        A.append(c)
+    xnorm = torch.norm(X)
+    grams = [None] + [_t(A[n]) @ A[n] for n in range(1, N)]
+    errors = []
+    for it in range(max_iter):
+        for n in range(N):
+            khatri = torch.ones(1, R, dtype=X.dtype, device=X.device)
+            prod = torch.ones(R, R, dtype=X.dtype, device=X.device)
+            for m in range(N - 1, -1, -1):
+                if m != n:
+                    prod *= grams[m]
+                    khatri = torch.reshape(torch.einsum("ir,jr->ijr", (A[m], khatri)), [-1, R])
+            A[n] = _t(torch.linalg.lstsq(prod, _t(unf(n) @ khatri)).solution)
+            grams[n] = _t(A[n]) @ A[n]
+        acc = A[0]
+        for c in A[1:]:
+            acc = torch.einsum("ar,ir->air", acc, c).reshape(-1, R)
+        errors.append(float(torch.norm(X - acc.sum(dim=1).reshape(X.shape)) / xnorm))
+        if verbose:
+            print("iter: {} | eps: {:.8f}".format(it, errors[-1]))
+        if len(errors) >= 2 and errors[-2] - errors[-1] < tol:
+            break
+    return A, errors

@@ -127,6 +127,9 @@ int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64
                   int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream, int axpby = 0, double alpha = 1.0,
                   double beta = 0.0);
 int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch);
+int krp_contract_dispatch(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* Tn, const void* B,
+                          int64_t ldb, void* out, hipStream_t stream);
+int hadamard_dispatch(int dtype, int64_t count, const void* a, const void* b, void* out, hipStream_t stream);
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
                        void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
@@ -313,6 +316,23 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
                        stride_out);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
+}
+
+int ttr_krp_contract(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* T, const void* B, int64_t ldb,
+                     void* out, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_krp_contract: bad dtype %d", dtype);
+  TTR_REQUIRE(P >= 0 && J >= 1 && Q >= 0 && R >= 1 && ldb >= R, TTR_E_INVALID, "ttr_krp_contract: bad sizes");
+  if (P == 0 || Q == 0) return TTR_OK;
+  TTR_REQUIRE(T && B && out, TTR_E_INVALID, "ttr_krp_contract: null pointer");
+  return krp_contract_dispatch(dtype, P, J, Q, R, T, B, ldb, out, (hipStream_t)stream);
+}
+
+int ttr_hadamard(int dtype, int64_t count, const void* a, const void* b, void* out, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_hadamard: bad dtype %d", dtype);
+  TTR_REQUIRE(count >= 0, TTR_E_INVALID, "ttr_hadamard: negative count");
+  if (count == 0) return TTR_OK;
+  TTR_REQUIRE(a && b && out, TTR_E_INVALID, "ttr_hadamard: null pointer");
+  return hadamard_dispatch(dtype, count, a, b, out, (hipStream_t)stream);
 }
 
 int ttr_debug_set_qr_stamps(void* device_buffer) {

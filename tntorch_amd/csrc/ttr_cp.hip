@@ -1,0 +1,108 @@
+// CP-ALS building blocks (tensor.py:279-394): the Khatri-Rao contraction that turns the
+// partially contracted tensor of a fused MTTKRP into the next one, and the Hadamard product of the R x R
+// Gram matrices.  HBM-streaming kernels: T is read exactly once, coalesced; no Khatri-Rao matrix and no
+// permuted unfolding copy is ever materialised.
+#include "ttr_common.h"
+
+namespace ttr {
+
+// out[p, x] = sum_j T[p, j, x] * B[j, x % R],  x in [0, inner = Q*R).
+// Workgroup = (p, x-chunk of XC columns); the 256 threads form JS = 256 / XC slices over j that are reduced
+// through LDS at the end.  Consecutive threads read consecutive x: every wave load is one contiguous segment.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void krp_contract_kernel(const T* __restrict__ Tn, const T* __restrict__ B,
+                                                                 T* __restrict__ out, int64_t J, int64_t inner,
+                                                                 int64_t R, int64_t ldb, int XC, int JS) {
+  __shared__ T red[kThreads];
+  const int tid = threadIdx.x;
+  const int xl = tid % XC, js = tid / XC;
+  const int64_t p = blockIdx.y;
+  const int64_t x = (int64_t)blockIdx.x * XC + xl;
+  const bool act = js < JS && x < inner;
+  T acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+  if (act) {
+    const int64_t r = x % R;
+    const T* __restrict__ tp = Tn + p * J * inner + x;
+    int64_t j = js;
+    const int64_t step = JS;
+    for (; j + 3 * step < J; j += 4 * step) {  // four independent loads in flight per thread
+      const T t0 = tp[j * inner], t1 = tp[(j + step) * inner], t2 = tp[(j + 2 * step) * inner],
+              t3 = tp[(j + 3 * step) * inner];
+      acc0 += t0 * B[j * ldb + r];
+      acc1 += t1 * B[(j + step) * ldb + r];
+      acc2 += t2 * B[(j + 2 * step) * ldb + r];
+      acc3 += t3 * B[(j + 3 * step) * ldb + r];
+    }
+    for (; j < J; j += step) acc0 += tp[j * inner] * B[j * ldb + r];
+  }
+  red[tid] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (js == 0 && x < inner) {
+    T s = red[xl];
+    for (int k = 1; k < JS; ++k) s += red[k * XC + xl];
+    out[p * inner + x] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void hadamard_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                             T* __restrict__ out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads)
+    out[i] = a[i] * b[i];
+}
+
+int krp_contract_dispatch(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* Tn, const void* B,
+                          int64_t ldb, void* out, hipStream_t stream) {
+  const int64_t inner = Q * R;
+  int XC = inner >= kThreads ? kThreads : (int)inner;
+  int JS = kThreads / XC;
+  if (JS > J) JS = (int)J;
+  const int64_t chunks = ceil_div(inner, XC);
+  TTR_REQUIRE(P <= 65535 || chunks == 1, TTR_E_UNSUPPORTED, "ttr_krp_contract: P = %lld > 65535 with inner > 256",
+              (long long)P);
+  dim3 grid, block(kThreads);
+  // grid.y is limited to 65535: for inner <= 256 (one chunk) p goes to grid.x instead
+  ProfScope prof(TTR_PROF_MISC, stream);
+  if (chunks == 1) {
+    // p on x: emulate blockIdx.y = p by launching with (1, P) when P fits, else fold through pointer offsets
+    int64_t done = 0;
+    while (done < P) {
+      const int64_t n = (P - done) < 65535 ? (P - done) : 65535;
+      grid = dim3(1, (unsigned)n);
+      const int64_t off = done * J * inner, ooff = done * inner;
+      if (dtype == TTR_F32)
+        hipLaunchKernelGGL(krp_contract_kernel<float>, grid, block, 0, stream, (const float*)Tn + off, (const float*)B,
+                           (float*)out + ooff, J, inner, R, ldb, XC, JS);
+      else
+        hipLaunchKernelGGL(krp_contract_kernel<double>, grid, block, 0, stream, (const double*)Tn + off,
+                           (const double*)B, (double*)out + ooff, J, inner, R, ldb, XC, JS);
+      done += n;
+    }
+  } else {
+    grid = dim3((unsigned)chunks, (unsigned)P);
+    if (dtype == TTR_F32)
+      hipLaunchKernelGGL(krp_contract_kernel<float>, grid, block, 0, stream, (const float*)Tn, (const float*)B,
+                         (float*)out, J, inner, R, ldb, XC, JS);
+    else
+      hipLaunchKernelGGL(krp_contract_kernel<double>, grid, block, 0, stream, (const double*)Tn, (const double*)B,
+                         (double*)out, J, inner, R, ldb, XC, JS);
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int hadamard_dispatch(int dtype, int64_t count, const void* a, const void* b, void* out, hipStream_t stream) {
+  int64_t gx = ceil_div(count, kThreads);
+  if (gx > 4096) gx = 4096;
+  ProfScope prof(TTR_PROF_MISC, stream);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(hadamard_kernel<float>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const float*)a,
+                       (const float*)b, (float*)out, count);
+  else
+    hipLaunchKernelGGL(hadamard_kernel<double>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const double*)a,
+                       (const double*)b, (double*)out, count);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+}  // namespace ttr

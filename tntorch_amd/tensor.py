@@ -58,17 +58,14 @@ class Tensor(object):
     ):
         self.batch = bool(batch)
         nb = 1 if self.batch else 0
-        if ranks_cp is not None:
-            _not_in_scope("CP-ALS (ranks_cp)")
         dense_Us = None
         if isinstance(data, (list, tuple)):  # explicit cores (tensor.py:165-192)
             cores = list(data)
             if not all(isinstance(c, torch.Tensor) and nb + 2 <= c.dim() <= nb + 3 for c in cores):
                 raise ValueError("All tensor cores must have 2 (for CP) or 3 (for TT) dimensions")
-            if any(c.dim() == nb + 2 for c in cores):
-                _not_in_scope("CP cores (2-D factor matrices)")
-            for n in range(len(cores) - 1):
-                if cores[n].shape[-1] != cores[n + 1].shape[nb]:
+            for n in range(len(cores) - 1):  # tensor.py:172-189 (a 2-D core is a CP factor [I, R])
+                nxt = cores[n + 1]
+                if cores[n].shape[-1] != (nxt.shape[nb] if nxt.dim() == nb + 3 else nxt.shape[nb + 1]):
                     raise ValueError("Core ranks do not match")
             if device is not None:
                 cores = [c.to(device) for c in cores]
@@ -86,7 +83,14 @@ class Tensor(object):
                 data = data * torch.ones(1, device=data.device, dtype=data.dtype)
             if eps is not None and (ranks_tt is not None or ranks_tucker is not None):
                 raise ValueError("Specify eps or ranks, but not both")
-            if ranks_tucker is not None:
+            if ranks_cp is not None:  # CP-ALS, tensor.py:210-400
+                if ranks_tt is not None:
+                    raise ValueError("ALS for CP-TT is not yet supported")
+                assert not hasattr(ranks_cp, "__len__")
+                if self.batch or ranks_tucker is not None:
+                    _not_in_scope("batched CP-ALS / CP-ALS on a Tucker core")
+                self.cores, self.cp_errors = ops_for(data).cp_als(data, int(ranks_cp), max_iter, tol, verbose)
+            elif ranks_tucker is not None:
                 self.cores, dense_Us = self._from_dense_tucker(data, ranks_tucker, ranks_tt, algorithm)
             else:
                 self.cores = self._from_dense(data, ranks_tt, eps, algorithm)
@@ -177,8 +181,25 @@ class Tensor(object):
 
     # ------------------------------------------------------------------ layout helpers
     def _norm4(self) -> List[torch.Tensor]:
-        """Cores as [B, r0, I, r1] views (B = 1 for non-batch tensors)."""
-        return list(self.cores) if self.batch else [c[None] for c in self.cores]
+        """Cores as [B, r0, I, r1] views (B = 1 for non-batch tensors); CP factors [I, R] become TT cores whose
+        slices are diagonal (tensor.py:1717-1769: first [1, I, R], last [R, I, 1], middle [R, I, R])."""
+        cs = list(self.cores) if self.batch else [c[None] for c in self.cores]
+        N = len(cs)
+        out = []
+        for n, c in enumerate(cs):
+            if c.dim() == 4:
+                out.append(c)
+            elif n == 0:
+                out.append(c[:, None])
+            elif n == N - 1:
+                out.append(c.transpose(-1, -2)[..., None])
+            else:
+                Bt, I, R = c.shape
+                core = c.new_zeros((Bt, R, I, R))
+                idx = torch.arange(R, device=c.device)
+                core[:, idx, :, idx] = c.permute(2, 0, 1)
+                out.append(core)
+        return out
 
     def _denorm(self, cores4: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         return list(cores4) if self.batch else [c[0] for c in cores4]
@@ -224,7 +245,9 @@ class Tensor(object):
     @property
     def ranks_tt(self):
         """tensor.py:861-883: CPU int64 tensor ``[R_0, R_1, ..., R_N]``."""
-        first = self.cores[0].shape[1 if self.batch else 0]
+        nb = 1 if self.batch else 0
+        c0 = self.cores[0]
+        first = c0.shape[nb + 1] if c0.dim() == nb + 2 else c0.shape[nb]  # CP factor: R (tensor.py:878-881)
         return torch.tensor([first] + [c.shape[-1] for c in self.cores])
 
     @ranks_tt.setter
