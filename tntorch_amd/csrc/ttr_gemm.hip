@@ -12,7 +12,7 @@
 // transposes come for free; the LDS image of a tile is chosen per operand so that the
 // global read is coalesced along the unit-stride axis AND the MFMA fragment reads are
 // bank-conflict free:
-//   k-contiguous operand  -> LDS [mn][k], leading dim 17   (fragment read: 17*i + k)
+//   k-contiguous operand  -> LDS [mn][k], leading dim BK+1 (fragment read: (BK+1)*i + k)
 //   mn-contiguous operand -> LDS [k][mn], leading dim 80   (fragment read: 80*k + i)
 // Optional split-K (blockIdx.y) writes partial tiles to a workspace, reduced (and
 // scaled) by a second kernel -- used for the Gram matrices of very tall unfoldings.
@@ -20,8 +20,14 @@
 
 namespace ttr {
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int LDS_TILE = 1280;  // max(64 * 17, 16 * 80)
+constexpr int BK = 16;  // K step; 32 measured slower on every shape of the path (metric GEMMs 12.8 -> 17.1 ms/step)
+constexpr int BKL = 4;  // log2(BK)
+// Tile shapes: every wave always owns a 32 x 32 block of C (2 x 2 MFMA tiles); the four waves are laid out
+// 2 x 2 (64 x 64 tile), 4 x 1 (128 x 32: products with <= 32 columns, e.g. X[I^3, I] @ A[I, R] of the MTTKRP or
+// the rank-32 projections) or 1 x 4 (32 x 128: <= 32 rows).  With the square tile such products waste half of
+// the MFMA issue slots -- and fp32 MFMA runs at the vector rate, so that half decides whether the kernel is
+// HBM- or issue-bound.
+constexpr int lds_tile(int bm) { return bm * (BK + 1) > BK * (bm + 16) ? bm * (BK + 1) : BK * (bm + 16); }
 
 template <typename T>
 struct GemmArgs {
@@ -55,14 +61,15 @@ __device__ __forceinline__ T apply_scale(T v, const T* s, int64_t idx, int mode)
   return (fabs((double)x) < (double)Num<T>::tiny()) ? T(0) : v / x;
 }
 
-template <typename T>
+template <typename T, int BM, int BN, int WN>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
-  __shared__ T As[LDS_TILE];
-  __shared__ T Bs[LDS_TILE];
+  constexpr int EA = BM * BK / kThreads, EB = BN * BK / kThreads;  // staged elements per thread and K step
+  __shared__ T As[lds_tile(BM)];
+  __shared__ T Bs[lds_tile(BN)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int64_t b = blockIdx.z;
   const int tm_idx = blockIdx.x / p.tilesN;
   const int tn_idx = blockIdx.x % p.tilesN;
@@ -77,16 +84,20 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
 
   const bool a_kc = (p.a_cs == 1);   // op(A) contiguous along k
   const bool b_kc = (p.b_rs == 1);   // op(B) contiguous along k
-  const int sa_i = a_kc ? 17 : 1, sa_k = a_kc ? 1 : 80;
-  const int sb_j = b_kc ? 17 : 1, sb_k = b_kc ? 1 : 80;
+  const int sa_i = a_kc ? BK + 1 : 1, sa_k = a_kc ? 1 : BM + 16;
+  const int sb_j = b_kc ? BK + 1 : 1, sb_k = b_kc ? 1 : BN + 16;
 
-  // per-thread staging coordinates (4 elements of each operand per K step)
-  int ai[4], ak[4], bj[4], bk[4];
+  // per-thread staging coordinates (EA / EB elements of the operands per K step)
+  int ai[EA], ak[EA], bj[EB], bk[EB];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < EA; ++e) {
     const int idx = tid + kThreads * e;
-    if (a_kc) { ak[e] = idx & 15; ai[e] = idx >> 4; } else { ai[e] = idx & 63; ak[e] = idx >> 6; }
-    if (b_kc) { bk[e] = idx & 15; bj[e] = idx >> 4; } else { bj[e] = idx & 63; bk[e] = idx >> 6; }
+    if (a_kc) { ak[e] = idx & (BK - 1); ai[e] = idx >> BKL; } else { ai[e] = idx % BM; ak[e] = idx / BM; }
+  }
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    const int idx = tid + kThreads * e;
+    if (b_kc) { bk[e] = idx & (BK - 1); bj[e] = idx >> BKL; } else { bj[e] = idx % BN; bk[e] = idx / BN; }
   }
 
   typename Mfma<T>::Acc acc[2][2];
@@ -95,12 +106,15 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::zero();
 
-  T ra[4], rb[4];
+  T ra[EA], rb[EB];
   auto fetch = [&](int64_t k0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < EA; ++e) {
       const int64_t gi = m0 + ai[e], gk = k0 + ak[e];
       ra[e] = (gi < p.M && gk < k_end) ? A[gi * p.a_rs + gk * p.a_cs] : T(0);
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
       const int64_t gj = n0 + bj[e], gk2 = k0 + bk[e];
       rb[e] = (gj < p.N && gk2 < k_end) ? B[gk2 * p.b_rs + gj * p.b_cs] : T(0);
     }
@@ -109,10 +123,9 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmArgs<T> p) {
   if (k_begin < k_end) fetch(k_begin);
   for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      As[ai[e] * sa_i + ak[e] * sa_k] = ra[e];
-      Bs[bj[e] * sb_j + bk[e] * sb_k] = rb[e];
-    }
+    for (int e = 0; e < EA; ++e) As[ai[e] * sa_i + ak[e] * sa_k] = ra[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) Bs[bj[e] * sb_j + bk[e] * sb_k] = rb[e];
     __syncthreads();
     if (k0 + BK < k_end) fetch(k0 + BK);  // overlaps the MFMAs below
 #pragma unroll
@@ -183,6 +196,17 @@ static int pick_nsplit(int64_t tiles, int64_t batch, int64_t K) {
   return (int)(s < 1 ? 1 : s);
 }
 
+// 0: 64 x 64 (2 x 2 waves), 1: 128 x 32 (4 x 1), 2: 32 x 128 (1 x 4)
+static int pick_shape(int64_t M, int64_t N) {
+  if (N <= 32 && M >= 128) return 1;
+  if (M <= 32 && N >= 128) return 2;
+  return 0;
+}
+static void tile_dims(int shape, int64_t& bm, int64_t& bn) {
+  bm = shape == 1 ? 128 : (shape == 2 ? 32 : 64);
+  bn = shape == 1 ? 32 : (shape == 2 ? 128 : 64);
+}
+
 template <typename T>
 static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                      int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc,
@@ -200,6 +224,9 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   p.rs = (const T*)rs; p.stride_rs = stride_rs; p.rs_mode = rs_mode;
   p.cs = (const T*)cs; p.stride_cs = stride_cs; p.cs_mode = cs_mode;
   p.batch = batch;
+  const int shape = pick_shape(M, N);
+  int64_t BM, BN;
+  tile_dims(shape, BM, BN);
   const int64_t tilesM = ceil_div(M, BM), tilesN = ceil_div(N, BN);
   p.tilesN = (int)tilesN;
   int nsplit = pick_nsplit(tilesM * tilesN, batch, K);
@@ -215,7 +242,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   dim3 grid((unsigned)(tilesM * tilesN), (unsigned)nsplit, (unsigned)batch);
   {
     ProfScope prof(TTR_PROF_GEMM, stream);
-    hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(kThreads), 0, stream, p);
+    if (shape == 1)
+      hipLaunchKernelGGL((gemm_kernel<T, 128, 32, 1>), grid, dim3(kThreads), 0, stream, p);
+    else if (shape == 2)
+      hipLaunchKernelGGL((gemm_kernel<T, 32, 128, 4>), grid, dim3(kThreads), 0, stream, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2>), grid, dim3(kThreads), 0, stream, p);
     if (nsplit > 1) {
       int64_t gx = ceil_div(M * N, kThreads);
       if (gx > 1024) gx = 1024;
@@ -227,6 +259,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
 }
 
 int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch) {
+  int64_t BM, BN;
+  tile_dims(pick_shape(M, N), BM, BN);
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
   const int ns = pick_nsplit(tiles, batch, K);
   if (ns == 1) return 0;
