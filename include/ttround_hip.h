@@ -189,6 +189,15 @@ int ttr_krp_contract(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R,
 int ttr_hadamard(int dtype, int64_t count, const void* a, const void* b, void* out, void* stream);
 
 /*
+ * Slice-wise Kronecker product of two TT cores (the Hadamard product of two tensor trains multiplies the ranks):
+ *   out[b, r1*S1 + s1, i, r2*S2 + s2] = a[b, r1, i, r2] * c[b, s1, i, s2],   a [B, R1, I, R2], c [B, S1, I, S2] contiguous.
+ * Replaces: `_core_kron` tensor.py:2309-2320 (called from `Tensor.__mul__`, tensor.py:687-773), the producer of the
+ * rank-inflated trains the rounding sweeps exist for.
+ */
+int ttr_core_kron(int dtype, int64_t batch, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2,
+                  const void* a, const void* c, void* out, void* stream);
+
+/*
  * out[b] = sqrt(sum(x[b]^2)) over `count` contiguous elements (accumulated in double, stored in dtype).
  * Replaces: torch.norm(cores[-1]) tensor.py:2039-2051 and torch.norm(M) round.py:80.
  */

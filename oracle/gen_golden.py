@@ -299,6 +299,26 @@ def case_cp_als():
     save("cp_als", meta, **groups)
 
 
+def case_producers():
+    """TT x TT product and the rounding tree (tensor.py:687-773, tools.py:460-512)."""
+    import operator
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(18)
+    a = tn.rand([7, 6, 8, 5], ranks_tt=3)
+    b = tn.rand([7, 6, 8, 5], ranks_tt=2)
+    prod = a * b
+    ts = [tn.rand([7, 6, 8, 5], ranks_tt=2) for _ in range(5)]
+    red = tn.reduce(ts, operator.add, eps=1e-6)  # (at eps <= 1e-8 the TT-vs-TT error estimate of round() is cancellation noise)
+    red3 = tn.reduce(ts, operator.add, rmax=3)
+    groups = {"a": npl(a.cores), "b": npl(b.cores), "prod": npl(prod.cores), "red_dense": red.torch().numpy(),
+              "red_ranks_tt": red.ranks_tt.numpy(), "red_ranks_tucker": red.ranks_tucker.numpy(), "red3_cores": npl(red3.cores)}
+    for i, t in enumerate(ts):
+        groups[f"t{i}"] = npl(t.cores)
+    assert all(U is None for U in red3.Us)
+    save("producers_f64", {"what": "a*b (ranks 3 x 2 -> 6); tn.reduce(5 rank-2 TTs, operator.add, eps=1e-6) and (rmax=3)",
+                           "ref": "tensor.py:687-773, 2309-2320; tools.py:460-512", "dtype": "float64"}, **groups)
+
+
 def case_known_answers():
     """docs/tutorials/decompositions.ipynb cells 1, 3, 18 (analytic 128^3 function)."""
     torch.set_default_dtype(torch.float64)
@@ -312,6 +332,8 @@ def case_known_answers():
         t.round_tt(eps=1e-5, algorithm=alg)
         out[f"ranks_eps1e-5_{alg}"] = t.ranks_tt.tolist()
         out[f"relerr_eps1e-5_{alg}"] = tn.relative_error(full, t).item()
+    ones = tn.ones([32] * 4)
+    out["arith_round_ranks"] = tn.round((ones + ones) * (ones - 2)).ranks_tt.tolist()
     te = tn.Tensor(full, eps=1e-5)
     out["eps_ctor_ranks_tt"] = te.ranks_tt.tolist()
     out["eps_ctor_ranks_tucker"] = te.ranks_tucker.tolist()
@@ -322,20 +344,24 @@ def case_known_answers():
     }
 
 
+CASES = [case_round_eps_f64, case_round_rmax_f32, case_round_batch_f64, case_dense_f64, case_dense_batch_f32, case_c0,
+         case_truncated_svd, case_orthogonalize, case_round_tucker, case_ctor_tucker, case_round_general, case_cp_als,
+         case_producers, case_known_answers]
+
 if __name__ == "__main__":
-    case_round_eps_f64()
-    case_round_rmax_f32()
-    case_round_batch_f64()
-    case_dense_f64()
-    case_dense_batch_f32()
-    case_c0()
-    case_truncated_svd()
-    case_orthogonalize()
-    case_round_tucker()
-    case_ctor_tucker()
-    case_round_general()
-    case_cp_als()
-    case_known_answers()
-    with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+    # no arguments: regenerate everything; otherwise only the named cases (the CP-ALS case is reproducible only
+    # to ~1e-12: multi-threaded LAPACK in the reference), merging into the existing golden_meta.json
+    only = set(sys.argv[1:])
+    meta_path = os.path.join(OUT, "golden_meta.json")
+    if only and os.path.exists(meta_path):
+        with open(meta_path) as f:
+            old = json.load(f)
+        META["cases"].update(old.get("cases", {}))
+        if "known_answers" in old:
+            META["known_answers"] = old["known_answers"]
+    for fn in CASES:
+        if not only or fn.__name__ in only:
+            fn()
+    with open(meta_path, "w") as f:
         json.dump(META, f, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(OUT)))

@@ -45,6 +45,8 @@ __all__ = [
     "dense_to_tt",
     "tt_to_dense",
     "tt_add",
+    "tt_mul",
+    "reduce_sum",
     "tt_scale",
     "tt_randn",
     "tt_rand",
@@ -518,6 +520,49 @@ def tt_add(a: Sequence[torch.Tensor], b: Sequence[torch.Tensor], batch: bool = F
             zb = torch.zeros(cb.shape[:-1] + (ca.shape[-1],), dtype=ca.dtype)
             out.append(torch.cat([torch.cat([ca, za], -1), torch.cat([zb, cb], -1)], dim=-3))
     return out
+
+
+def tt_mul(a: Sequence[torch.Tensor], b: Sequence[torch.Tensor]) -> Cores:
+    """tensor.py:687-773 for two pure TT tensors: slice-wise Kronecker product ``_core_kron`` (tensor.py:2309-2320)."""
+    out = []
+    for ca, cb in zip(a, b):
+        c = ca[:, None, :, :, None] * cb[None, :, :, None, :]
+        out.append(c.reshape([ca.shape[0] * cb.shape[0], -1, ca.shape[-1] * cb.shape[-1]]))
+    return out
+
+
+def reduce_sum(ts: Sequence[Sequence[torch.Tensor]], eps: float = 0, rmax=None, algorithm: str = "svd"):
+    """tools.py:460-512 ``tn.reduce(ts, operator.add, eps, rmax)`` for pure TT inputs: binary-counter tree, every
+    intermediate sum goes through ``tn.round`` (TT rounding, then Tucker rounding with the left-over budget).
+    Works on (cores, Us) pairs; returns (cores, Us)."""
+    def add(x, y):
+        return tt_add(tucker_absorb(*x), tucker_absorb(*y)), None
+
+    def rnd(x):
+        cores, _ = x
+        copy = [c.clone() for c in cores]
+        out = round_tt(cores, eps=eps, rmax=rmax, algorithm=algorithm)
+        reached = relative_error_tt(copy, out)
+        Us = [None] * len(out)
+        if reached < eps:
+            rm = None if rmax is None else rmax
+            out, Us = round_tucker(out, None, (1 + eps) / (1 + reached.item()) - 1, rmax=rm, algorithm=algorithm)
+        return out, Us
+
+    d = dict()
+    for elem in ts:
+        elem = (list(elem), None)
+        climb = 0
+        while climb in d:
+            elem = rnd(add(d[climb], elem))
+            d.pop(climb)
+            climb += 1
+        d[climb] = elem
+    keys = list(d.keys())
+    result = d[keys[0]]
+    for key in keys[1:]:
+        result = rnd(add(result, d[key]))
+    return result
 
 
 def tt_scale(cores: Sequence[torch.Tensor], s: float) -> Cores:

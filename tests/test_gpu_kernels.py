@@ -303,6 +303,19 @@ def test_krp_contract_and_hadamard(dt):
     assert torch.allclose(h.hadamard(a.to(dt).cuda(), b.to(dt).cuda()).cpu().double(), (a.to(dt) * b.to(dt)).double(), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_core_kron(dt):
+    """ttr_core_kron vs the reference's broadcasting formula (tensor.py:2309-2320)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(8)
+    for (B, R1, S1, I, R2, S2) in [(1, 3, 2, 7, 4, 5), (3, 1, 1, 9, 6, 2), (2, 8, 8, 33, 8, 8), (1, 5, 4, 1, 1, 1)]:
+        a = torch.randn(B, R1, I, R2, generator=g, dtype=torch.float64).to(dt)
+        c = torch.randn(B, S1, I, S2, generator=g, dtype=torch.float64).to(dt)
+        ref = (a[:, :, None, :, :, None] * c[:, None, :, :, None, :]).reshape(B, R1 * S1, I, R2 * S2)
+        out = h.core_kron(a.cuda(), c.cuda()).cpu()
+        assert torch.equal(out, ref)
+
+
 def test_unsupported_shapes_raise():
     h = _hip()
     with pytest.raises(NotImplementedError):

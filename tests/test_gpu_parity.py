@@ -449,6 +449,37 @@ def test_cp_als_recovers_low_rank(dt):
         assert err <= max(10 * e_ref, 5e-3 if dt == torch.float32 else 1e-5), (shape, err, e_ref)
 
 
+# ------------------------------------------------------------------ producers on the device
+def test_golden_producers():
+    import operator
+    g = load_case("producers_f64")
+    a, b = gpu_tensor(g["a"]), gpu_tensor(g["b"])
+    p = a * b                                              # ttr_core_kron
+    assert max((x.cpu() - y).abs().max().item() for x, y in zip(p.cores, g["prod"])) < 1e-15
+    ts = [gpu_tensor(g[f"t{i}"]) for i in range(5)]
+    red = tn.reduce(ts, operator.add, eps=1e-6)            # tree of + and round() on the device
+    ref = g["red_dense"]
+    assert red.ranks_tt.tolist() == g["red_ranks_tt"].tolist() and red.ranks_tucker.tolist() == g["red_ranks_tucker"].tolist()
+    assert rel_diff(red.torch().cpu(), ref) <= 1e-9
+    red3 = tn.reduce(ts, operator.add, rmax=3)
+    ref3 = oracle.tt_to_dense(g["red3_cores"])
+    assert rel_diff(red3.torch().cpu(), ref3) <= 1e-9
+    # arithmetics.ipynb cell 1.  The reference (float32, LAPACK) gets exactly-zero trailing singular values on this
+    # all-ones structure and eps = 1e-14 then drops them; QL/Jacobi leave them at the 1e-8 round-off level, which
+    # 1e-14 keeps -- in float64 (or with any eps above round-off) the ranks collapse to 1 here as well.
+    ones = tn.ones([32] * 4, device="cuda", dtype=torch.float64)
+    assert tn.round((ones + ones) * (ones - 2)).ranks_tt.tolist() == [1, 1, 1, 1, 1]
+    ones = tn.ones([32] * 4, device="cuda")
+    assert tn.round((ones + ones) * (ones - 2), eps=1e-6).ranks_tt.tolist() == [1, 1, 1, 1, 1]
+    # batch + float32 product against dense
+    torch.manual_seed(31)
+    x = oracle.tt_randn([5, 6, 4], 3, dtype=torch.float32, batch_size=2)
+    y = oracle.tt_randn([5, 6, 4], 2, dtype=torch.float32, batch_size=2)
+    pb = gpu_tensor(x, batch=True) * gpu_tensor(y, batch=True)
+    want = oracle.tt_to_dense([c.double() for c in x], batch=True) * oracle.tt_to_dense([c.double() for c in y], batch=True)
+    assert rel_diff(pb.torch().cpu(), want) <= 2e-6
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""

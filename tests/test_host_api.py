@@ -271,3 +271,25 @@ def test_host_cp_als_golden():
     assert u.ranks_tt.tolist() == [1, 5, 5, 5, 1] and (u.torch() - ref).norm() / ref.norm() < 1e-9
     with pytest.raises(ValueError):
         tn.Tensor(g["inp"], ranks_cp=3, ranks_tt=2)
+
+
+# ------------------------------------------------------------------ producers on the host mirror (8f-3)
+def test_host_producers_golden():
+    import operator
+    from parity import load_case, load_meta
+    g = load_case("producers_f64")
+    a, b = tn.Tensor(g["a"]), tn.Tensor(g["b"])
+    p = a * b
+    assert max((x - y).abs().max().item() for x, y in zip(p.cores, g["prod"])) == 0
+    assert (p.torch() - a.torch() * b.torch()).abs().max() < 1e-12
+    ts = [tn.Tensor(g[f"t{i}"]) for i in range(5)]
+    red = tn.reduce(ts, operator.add, eps=1e-6)
+    ref = g["red_dense"]
+    assert red.ranks_tt.tolist() == g["red_ranks_tt"].tolist() and red.ranks_tucker.tolist() == g["red_ranks_tucker"].tolist()
+    assert (red.torch() - ref).norm() / ref.norm() < 1e-9
+    red3 = tn.reduce(ts, operator.add, rmax=3)
+    ref3 = oracle.tt_to_dense(g["red3_cores"])
+    assert (red3.torch() - ref3).norm() / ref3.norm() < 1e-10
+    # docs/tutorials/arithmetics.ipynb cell 1
+    ones = tn.ones([32] * 4)
+    assert tn.round((ones + ones) * (ones - 2)).ranks_tt.tolist() == load_meta()["known_answers"]["measured_with_reference_here"]["arith_round_ranks"]

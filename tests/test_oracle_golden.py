@@ -191,3 +191,18 @@ def test_cp_als_golden():
     cores, _ = oracle.cp_als(Y, 4, max_iter=6)
     d_o, d_r = oracle.cp_to_dense(cores), oracle.cp_to_dense(g["f32_r4_it6"])
     assert (d_o - d_r).norm() / d_r.norm() < 1e-4
+
+
+# ------------------------------------------------------------------ producers
+def test_producers_golden():
+    g = load_case("producers_f64")
+    prod = oracle.tt_mul(g["a"], g["b"])
+    assert oracle.tt_ranks(prod) == [1, 6, 6, 6, 1] and _max_abs(prod, g["prod"]) == 0
+    ts = [g[f"t{i}"] for i in range(5)]
+    cores, Us = oracle.reduce_sum(ts, eps=1e-6)
+    assert oracle.tt_ranks(cores) == g["red_ranks_tt"].tolist() and [c.shape[1] for c in cores] == g["red_ranks_tucker"].tolist()
+    ref = g["red_dense"]
+    assert (oracle.tucker_to_dense(cores, Us) - ref).norm() / ref.norm() < 1e-9
+    cores3, _ = oracle.reduce_sum(ts, eps=0, rmax=3)
+    ref3 = oracle.tt_to_dense(g["red3_cores"])
+    assert (oracle.tt_to_dense(cores3) - ref3).norm() / ref3.norm() < 1e-10

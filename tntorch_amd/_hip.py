@@ -90,6 +90,7 @@ _SIGNATURES = {
     ),
     "ttr_krp_contract": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_hadamard": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ttr_core_kron": (c_int, [c_int] + [c_int64] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_debug_set_qr_stamps": (c_int, [c_void_p]),
     "ttr_prof_enable": (c_int, [c_int]),
     "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
@@ -425,6 +426,19 @@ def hadamard(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty_like(a)
     _check(L.ttr_hadamard(dt, a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "ttr_hadamard")
+    return out
+
+
+def core_kron(a: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """[B, R1, I, R2] (x) [B, S1, I, S2] -> [B, R1*S1, I, R2*S2] (slice-wise Kronecker product)."""
+    L = lib()
+    dt = dtype_code(a.dtype)
+    assert a.dim() == 4 and c.dim() == 4 and a.dtype == c.dtype and a.shape[0] == c.shape[0] and a.shape[2] == c.shape[2]
+    a, c = a.contiguous(), c.contiguous()
+    B, R1, I, R2 = a.shape
+    _, S1, _, S2 = c.shape
+    out = torch.empty((B, R1 * S1, I, R2 * S2), dtype=a.dtype, device=a.device)
+    _check(L.ttr_core_kron(dt, B, R1, S1, I, R2, S2, a.data_ptr(), c.data_ptr(), out.data_ptr(), _stream()), "ttr_core_kron")
     return out
 
 

@@ -696,3 +696,9 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
         if len(errors) >= 2 and errors[-2] - errors[-1] < tol:  # tensor.py:380-381
             break
     return A, errors
+
+
+# ---------------------------------------------------------------------------------------------- producers
+def core_kron(a4: torch.Tensor, b4: torch.Tensor) -> torch.Tensor:
+    """tensor.py:2309-2320 ``_core_kron`` on [B, r, I, r'] cores."""
+    return _hip.core_kron(a4, b4)

@@ -314,3 +314,10 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
         if len(errors) >= 2 and errors[-2] - errors[-1] < tol:
             break
     return A, errors
+
+
+# ---------------------------------------------------------------------------------------------- producers
+def core_kron(a4: torch.Tensor, b4: torch.Tensor) -> torch.Tensor:
+    """tensor.py:2309-2320 ``_core_kron`` (batch form) on [B, r, I, r'] cores."""
+    c = a4[:, :, None, :, :, None] * b4[:, None, :, :, None, :]
+    return c.reshape([a4.shape[0], a4.shape[1] * b4.shape[1], -1, a4.shape[-1] * b4.shape[-1]])

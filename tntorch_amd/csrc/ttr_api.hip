@@ -130,6 +130,8 @@ int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t
 int krp_contract_dispatch(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* Tn, const void* B,
                           int64_t ldb, void* out, hipStream_t stream);
 int hadamard_dispatch(int dtype, int64_t count, const void* a, const void* b, void* out, hipStream_t stream);
+int core_kron_dispatch(int dtype, int64_t B, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
+                       const void* c, void* out, hipStream_t stream);
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
                        void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
@@ -333,6 +335,15 @@ int ttr_hadamard(int dtype, int64_t count, const void* a, const void* b, void* o
   if (count == 0) return TTR_OK;
   TTR_REQUIRE(a && b && out, TTR_E_INVALID, "ttr_hadamard: null pointer");
   return hadamard_dispatch(dtype, count, a, b, out, (hipStream_t)stream);
+}
+
+int ttr_core_kron(int dtype, int64_t batch, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
+                  const void* c, void* out, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_core_kron: bad dtype %d", dtype);
+  TTR_REQUIRE(batch >= 0 && R1 >= 1 && S1 >= 1 && I >= 1 && R2 >= 1 && S2 >= 1, TTR_E_INVALID, "ttr_core_kron: bad sizes");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(a && c && out, TTR_E_INVALID, "ttr_core_kron: null pointer");
+  return core_kron_dispatch(dtype, batch, R1, S1, I, R2, S2, a, c, out, (hipStream_t)stream);
 }
 
 int ttr_debug_set_qr_stamps(void* device_buffer) {

@@ -1,4 +1,5 @@
-// CP-ALS building blocks (tensor.py:279-394): the Khatri-Rao contraction that turns the
+// CP-ALS building blocks (tensor.py:279-394) and the TT x TT core product: the
+// Khatri-Rao contraction that turns the
 // partially contracted tensor of a fused MTTKRP into the next one, and the Hadamard product of the R x R
 // Gram matrices.  HBM-streaming kernels: T is read exactly once, coalesced; no Khatri-Rao matrix and no
 // permuted unfolding copy is ever materialised.
@@ -49,6 +50,39 @@ __global__ __launch_bounds__(kThreads) void hadamard_kernel(const T* __restrict_
                                                              T* __restrict__ out, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads)
     out[i] = a[i] * b[i];
+}
+
+// out[b, r1*S1 + s1, i, r2*S2 + s2] = a[b, r1, i, r2] * c[b, s1, i, s2]  (slice-wise Kronecker product of two TT cores)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void core_kron_kernel(const T* __restrict__ a, const T* __restrict__ c,
+                                                              T* __restrict__ out, int64_t R1, int64_t S1, int64_t I,
+                                                              int64_t R2, int64_t S2, int64_t total) {
+  const int64_t w = R2 * S2;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+    const int64_t col = idx % w;          // r2 * S2 + s2
+    int64_t t = idx / w;
+    const int64_t i = t % I; t /= I;
+    const int64_t row = t % (R1 * S1);    // r1 * S1 + s1
+    const int64_t b = t / (R1 * S1);
+    const int64_t r1 = row / S1, s1 = row - r1 * S1, r2 = col / S2, s2 = col - r2 * S2;
+    out[idx] = a[((b * R1 + r1) * I + i) * R2 + r2] * c[((b * S1 + s1) * I + i) * S2 + s2];
+  }
+}
+
+int core_kron_dispatch(int dtype, int64_t B, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
+                       const void* c, void* out, hipStream_t stream) {
+  const int64_t total = B * R1 * S1 * I * R2 * S2;
+  int64_t gx = ceil_div(total, kThreads);
+  if (gx > 16384) gx = 16384;
+  ProfScope prof(TTR_PROF_MISC, stream);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(core_kron_kernel<float>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const float*)a,
+                       (const float*)c, (float*)out, R1, S1, I, R2, S2, total);
+  else
+    hipLaunchKernelGGL(core_kron_kernel<double>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const double*)a,
+                       (const double*)c, (double*)out, R1, S1, I, R2, S2, total);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
 }
 
 int krp_contract_dispatch(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* Tn, const void* B,

@@ -340,8 +340,14 @@ class Tensor(object):
         return (self * (-1)) + other
 
     def __mul__(self, other):
-        if isinstance(other, Tensor):
-            _not_in_scope("the Hadamard product of two tensor trains")
+        if isinstance(other, Tensor):  # element-wise product: slice-wise Kronecker product of the cores
+            if self.batch != other.batch:
+                raise ValueError("Tensors with the same batch mode are supported")
+            if self.shape != other.shape:
+                raise ValueError("tntorch_amd: * requires equal shapes (broadcasting is out of scope)")
+            ca, cb = self._absorbed4(), other._absorbed4()
+            ops = ops_for(ca[0])
+            return Tensor(self._denorm([ops.core_kron(a, b) for a, b in zip(ca, cb)]), batch=self.batch)
         cores = [c.clone() for c in self.cores]
         cores[0] = cores[0] * other
         return Tensor(cores, Us=[None if U is None else U.clone() for U in self.Us], batch=self.batch)
