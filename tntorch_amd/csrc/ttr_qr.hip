@@ -205,10 +205,22 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
             const int j = owv * 4 + oc;
             if (j < nsteps) {
               const int jj = j0 + j;
-              T ss = (lane > jj) ? pc[oc][0] * pc[oc][0] : T(0);
+              // ONE reduction round per step: the column norm below the diagonal and the dot products of that
+              // sub-column x with the owner's remaining columns travel together; v^T c = scale * x^T c + c[jj]
+              // (v = scale * x below the diagonal, 1 on it) needs no second round.
+              T x[4];
+              x[0] = (lane > jj) ? pc[oc][0] : T(0);
 #pragma unroll
-              for (int q = 1; q < 4; ++q) ss += pc[oc][q] * pc[oc][q];
-              ss = wave_sum_dpp(ss);
+              for (int q = 1; q < 4; ++q) x[q] = pc[oc][q];
+              T d4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+              for (int cc = oc; cc < 4; ++cc) {
+                d4[cc] = x[0] * pc[cc][0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) d4[cc] += x[q] * pc[cc][q];
+              }
+              wave_sum_dpp4(d4);
+              const T ss = d4[oc];
               const T alpha = lane_get(pc[oc][0], jj);
               T beta, tj, scale;
               if (ss == T(0)) {  // LAPACK larfg: H = I
@@ -217,32 +229,24 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
                 larfg_scalars(alpha, ss, beta, tj, scale);
               }
               T v[4];
-              v[0] = (lane > jj) ? pc[oc][0] * scale : (lane == jj ? T(1) : T(0));
+              v[0] = (lane > jj) ? x[0] * scale : (lane == jj ? T(1) : T(0));
 #pragma unroll
-              for (int q = 1; q < 4; ++q) v[q] = pc[oc][q] * scale;
+              for (int q = 1; q < 4; ++q) v[q] = x[q] * scale;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 Vs[(lane + 64 * q) * VLD + j] = v[q];
                 Vt[(int64_t)jj * BR + lane + 64 * q] = v[q];  // coalesced, fire and forget
               }
-              if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
-              if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
               if constexpr (oc < 3) {  // apply to the owner's remaining columns
-                T d4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
                 for (int cc = oc + 1; cc < 4; ++cc) {
-                  d4[cc] = v[0] * pc[cc][0];
-#pragma unroll
-                  for (int q = 1; q < 4; ++q) d4[cc] += v[q] * pc[cc][q];
-                }
-                wave_sum_dpp4(d4);
-#pragma unroll
-                for (int cc = oc + 1; cc < 4; ++cc) {
-                  const T f = tj * d4[cc];
+                  const T f = tj * (scale * d4[cc] + lane_get(pc[cc][0], jj));
 #pragma unroll
                   for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
                 }
               }
+              if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
+              if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
             }
           };
           local(IC<0>{}); local(IC<1>{}); local(IC<2>{}); local(IC<3>{});
