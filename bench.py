@@ -204,7 +204,11 @@ def main():
             assert all(list(g.ranks_tt) == [1] + [R_OUT] * (N_CORES - 1) + [1] and g.cores[0].shape[0] == B for g in gathered)
             assert torch.isfinite(gathered[-1].cores[3]).all()
 
-    # ---- per-kernel device time over an identical pass (HIP events on the launch stream)
+    # ---- per-kernel device time over an identical pass (HIP events on the launch stream).  The timed region
+    # above runs sub-batches on several streams so that kernels overlap; here every kernel must run alone for
+    # its duration to mean anything, so the same work is issued on ONE stream.
+    from tntorch_amd import _hipops
+    _hipops.STREAM_CHUNKS_ENABLED = False
     _hip.prof_enable(True)
     for _ in range(args.steps):
         t = tn.Tensor(inp, batch=True)
@@ -212,6 +216,7 @@ def main():
     torch.cuda.synchronize()
     prof = _hip.prof_collect()
     _hip.prof_enable(False)
+    _hipops.STREAM_CHUNKS_ENABLED = True
 
     if rank == 0:
         if out is not None:

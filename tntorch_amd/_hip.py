@@ -174,8 +174,10 @@ def gemm(
     rowscale_mode: int = SCALE_NONE,
     colscale: Optional[torch.Tensor] = None,
     colscale_mode: int = SCALE_NONE,
+    out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """C[b] = scale(op(A[b]) @ op(B[b])) for [batch, ., .] tensors; returns a fresh tensor."""
+    """C[b] = scale(op(A[b]) @ op(B[b])) for [batch, ., .] tensors; returns a fresh tensor (or ``out``, a
+    contiguous [batch, M, N] tensor -- e.g. a batch slice of a larger result -- that is overwritten)."""
     L = lib()
     dt = dtype_code(A.dtype)
     assert A.dtype == B.dtype and A.shape[0] == B.shape[0]
@@ -186,7 +188,11 @@ def gemm(
     K2, N = (B.shape[2], B.shape[1]) if transB else (B.shape[1], B.shape[2])
     if K != K2:
         raise ValueError(f"gemm: inner dimensions differ ({K} vs {K2})")
-    C = torch.empty((batch, M, N), dtype=A.dtype, device=A.device)
+    if out is not None:
+        assert tuple(out.shape) == (batch, M, N) and out.is_contiguous() and out.dtype == A.dtype
+        C = out
+    else:
+        C = torch.empty((batch, M, N), dtype=A.dtype, device=A.device)
     if M == 0 or N == 0 or batch == 0:
         return C
     rs_ptr, rs_stride = None, 0
@@ -310,8 +316,10 @@ def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
     return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I))
 
 
-def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None) -> torch.Tensor:
-    """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q)."""
+def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q).
+    ``out``: optional contiguous destination (e.g. a batch slice of a larger result)."""
     L = lib()
     dt = dtype_code(f.dtype)
     if C is not None:
@@ -322,7 +330,11 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
     else:
         kcols = f.k if kcols is None else kcols
         ldc, sC, cptr = 0, 0, None
-    Out = torch.empty((f.batch, f.m, kcols), dtype=f.dtype, device=f.ws.device)
+    if out is not None:
+        assert tuple(out.shape) == (f.batch, f.m, kcols) and out.is_contiguous() and out.dtype == f.dtype
+        Out = out
+    else:
+        Out = torch.empty((f.batch, f.m, kcols), dtype=f.dtype, device=f.ws.device)
     if f.batch == 0:
         return Out
     if f.pushed is not None:

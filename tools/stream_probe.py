@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tntorch_amd as tn
 import bench
-B = 512
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda", 0)
 inp = bench.make_input(B, dev, 1234)
 def run(nchunks, reps=4):
