@@ -345,6 +345,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 
 // ====================================================================================================
 // Tridiagonal QL eigensolver: ONE WAVE per matrix (n <= 64), no workgroup barriers.
+// (Measured alternative: vectors / d / e / rotations in registers with v_readlane broadcasts instead of LDS
+// broadcast reads -- 0.81 -> 1.1 ms per launch of 2048 matrices; the LDS broadcast is the cheaper one.)
 //
 // Householder reduction to tridiagonal form, in-place accumulation of Q, implicit-shift QL with the
 // rotations applied to Q's columns: ~10x fewer flops than cyclic Jacobi (n^3-class constant 4/3+4/3+~3
