@@ -133,6 +133,9 @@ def main():
                     help="tensors per GPU per step (2048 = eight single-wave 64x64 eigenproblems per CU; 13 GB of cores)")
     ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="issue the timed region on one stream too (for rocprofv3 kernel traces: with sub-batch "
+                         "streams the traced kernel durations overlap)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -154,6 +157,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     _hip.lib()  # fail loudly if the kernels are not built
+    from tntorch_amd import _hipops
+    if args.single_stream:
+        _hipops.STREAM_CHUNKS_ENABLED = False
 
     B = args.batch
     inp = make_input(B, dev, seed=1234 + rank)
@@ -207,7 +213,6 @@ def main():
     # ---- per-kernel device time over an identical pass (HIP events on the launch stream).  The timed region
     # above runs sub-batches on several streams so that kernels overlap; here every kernel must run alone for
     # its duration to mean anything, so the same work is issued on ONE stream.
-    from tntorch_amd import _hipops
     _hipops.STREAM_CHUNKS_ENABLED = False
     _hip.prof_enable(True)
     for _ in range(args.steps):
@@ -216,7 +221,7 @@ def main():
     torch.cuda.synchronize()
     prof = _hip.prof_collect()
     _hip.prof_enable(False)
-    _hipops.STREAM_CHUNKS_ENABLED = True
+    _hipops.STREAM_CHUNKS_ENABLED = not args.single_stream
 
     if rank == 0:
         if out is not None:
@@ -264,6 +269,7 @@ def main():
                 "workload": "round_tt(rmax=32) of 64^8 TT tensors, rank 64 (g+g, g randn rank 32), fp32, batch-resident in HBM",
                 "tensors_per_gpu_per_step": B,
                 "algorithm": args.algorithm,
+                "streams_per_gpu": 1 if args.single_stream else 2,
                 "parallelism": f"batch-sharded x{world}, one async RCCL gather of packed cores per step (overlapped with the next step)" if world > 1 else "single GPU",
             },
             "tensors_per_s": tensors / elapsed,
