@@ -173,7 +173,8 @@ def test_eigh_match_diag(dt, n, solver):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("n,B,solver", [(128, 2, 2), (150, 1, 2), (288, 1, 2), (512, 1, 2), (128, 2, 1), (150, 1, 1)])
+@pytest.mark.parametrize("n,B,solver", [(128, 2, 2), (150, 1, 2), (288, 1, 2), (512, 1, 2), (128, 2, 1), (150, 1, 1),
+                                        (127, 2, 2), (211, 1, 2), (122, 1, 1)])  # last three: padded (no block width divides n)
 def test_eigh_block_jacobi(dt, n, B, solver):
     """Large-n driver (_hipops._eigh_any): block Jacobi over pair problems + sorted epilogue.
     solver 2: tridiagonal pair solver, absolute stop test; solver 1: Jacobi pair solver, relative stop test."""

@@ -201,17 +201,40 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
 
 
 def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, cap: int, solver: int):
-    """Dispatch on the problem size: n <= 64 -> requested kernel; n <= LDS limit -> LDS Jacobi; larger ->
-    block Jacobi over the GPU, then one (rotation-free) pass of the Jacobi kernel for its epilogue
-    (clamp, sqrt, sort, rank rule)."""
-    n = G.shape[1]
+    """Dispatch on the problem size: n <= LDS limit -> one workgroup per matrix (tridiagonal QL for n <= 64 when
+    requested, Jacobi otherwise); larger -> block Jacobi over the GPU, then one (rotation-free) pass of the
+    Jacobi kernel for its epilogue (clamp, sqrt, sort, rank rule).  Sizes no block width in 8..32 divides are
+    padded with decoupled rows/columns whose eigenvalue -||G||_F lies below every real one."""
+    Bt, n, _ = G.shape
     lds_limit = _hip.lib().ttr_eigh_max_n_lds(_hip.dtype_code(G.dtype))
-    if n <= lds_limit or _bj_block(n) is None:
+    if n <= lds_limit:
         return _hip.eigh_trunc(G, eig_mode, use_delta, delta2, cap, abs_floor=solver)
-    Vb, d = eigh_block_jacobi(G, relative=(solver != _hip.SOLVER_TRIDIAG))
-    D = torch.diag_embed(d)
-    P, sig, info = _hip.eigh_trunc(D, eig_mode, use_delta, delta2, cap, abs_floor=_hip.SOLVER_JACOBI_ABS)
-    return _hip.gemm(Vb, P), sig, info
+    relative = solver != _hip.SOLVER_TRIDIAG
+    if _bj_block(n) is not None:
+        Vb, d = eigh_block_jacobi(G, relative=relative)
+        P, sig, info = _hip.eigh_trunc(torch.diag_embed(d), eig_mode, use_delta, delta2, cap, abs_floor=_hip.SOLVER_JACOBI_ABS)
+        return _hip.gemm(Vb, P), sig, info
+    nblk = -(-n // 32)
+    b = -(-n // nblk)
+    npad = nblk * b
+    if npad > _hip.max_eigh_n():
+        return _hip.eigh_trunc(G, eig_mode, use_delta, delta2, cap, abs_floor=solver)
+    gn = _hip.norm(G.reshape(Bt, -1))                                     # >= |lambda|_max
+    Gp = G.new_zeros((Bt, npad, npad))
+    Gp[:, :n, :n] = G
+    pad_idx = torch.arange(n, npad, device=G.device)
+    Gp[:, pad_idx, pad_idx] = gn[:, None].neg().expand(Bt, npad - n)      # sentinel eigenvalues (fill: layout)
+    Vb, d = eigh_block_jacobi(Gp, relative=relative)
+    # order by d + ||G|| (pads become exactly the smallest): ttr_gemm_axpby adds the shift, the epilogue sorts
+    shifted = d.reshape(Bt, npad, 1).clone()
+    _hip.gemm_axpby(torch.ones((Bt, npad, 1), dtype=G.dtype, device=G.device), gn.reshape(Bt, 1, 1), shifted, 1.0, 1.0)
+    P1, _, _ = _hip.eigh_trunc(torch.diag_embed(shifted[:, :, 0]), _hip.EIG_RAW, False, 0.0, npad,
+                               abs_floor=_hip.SOLVER_JACOBI_ABS)
+    Vs = _hip.gemm(Vb, P1)[:, :n, :n].contiguous()                        # real eigenvectors, decreasing eigenvalue
+    ds = torch.diagonal(_hip.gemm(P1, _hip.gemm(torch.diag_embed(d), P1), transA=True), dim1=1, dim2=2)[:, :n]
+    P2, sig, info = _hip.eigh_trunc(torch.diag_embed(ds.contiguous()), eig_mode, use_delta, delta2, cap,
+                                    abs_floor=_hip.SOLVER_JACOBI_ABS)
+    return _hip.gemm(Vs, P2), sig, info
 
 
 class Truncation:
