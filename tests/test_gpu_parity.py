@@ -480,6 +480,69 @@ def test_golden_producers():
     assert rel_diff(pb.torch().cpu(), want) <= 2e-6
 
 
+# ------------------------------------------------------------------ randomised shapes (ragged modes, wide cores, ranks 1..80)
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trains_vs_oracle(seed):
+    """Seeded random trains: N in 2..6, ragged mode sizes 1..9 (one mode up to 40), ranks 1..12 (one bond up to 80,
+    i.e. above the 64-column TSQR panel), float64; eps mode and rmax mode, both algorithms, against the oracle:
+    identical ranks in rmax mode, reconstruction within 1e-9, eps bound respected."""
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.randint(2, 7))
+    shape = [int(rng.randint(1, 10)) for _ in range(N)]
+    shape[int(rng.randint(N))] = int(rng.randint(10, 41))
+    rk = [1] + [int(rng.randint(1, 13)) for _ in range(N - 1)] + [1]
+    if N > 2 and seed % 3 == 0:
+        rk[int(rng.randint(1, N))] = int(rng.randint(65, 81))
+    torch.manual_seed(seed)
+    cores = [torch.randn(rk[k], shape[k], rk[k + 1], dtype=torch.float64) for k in range(N)]
+    inp = oracle.tt_add(cores, oracle.tt_scale(cores, 0.5)) if seed % 2 else cores   # redundant ranks every other seed
+    X = dense(inp)
+    for alg in ("svd", "eig"):
+        rmax = int(rng.randint(1, 9))
+        ref = oracle.round_tt([c.clone() for c in inp], rmax=rmax, algorithm=alg)
+        t = gpu_tensor(inp)
+        t.round_tt(rmax=rmax, algorithm=alg)
+        ours = to_list(t.cores)
+        assert ranks(ours) == ranks(ref), (seed, alg, shape, rk, rmax)
+        e_o, e_r = rel_diff(dense(ours), X), rel_diff(dense(ref), X)
+        assert abs(e_o - e_r) <= 1e-9 + 1e-6 * e_r, (seed, alg, shape, rk, rmax, e_o, e_r)
+        eps = float(10.0 ** rng.uniform(-8, -1))
+        t = gpu_tensor(inp)
+        t.round_tt(eps=eps, algorithm=alg)
+        ref = oracle.round_tt([c.clone() for c in inp], eps=eps, algorithm=alg)
+        e_o = rel_diff(dense(to_list(t.cores)), X)
+        assert e_o <= eps * (1 + 1e-6) + 1e-9, (seed, alg, eps, e_o)
+        assert sum(ranks(to_list(t.cores))) <= sum(ranks(ref)) + (0 if alg == "svd" else N), (seed, alg, eps)
+
+
+def test_stream_chunks_identical():
+    """Batches >= 128 run as two sub-batches on separate streams writing into shared result tensors: the result
+    must be bit-identical to the single-stream sweep (odd split 65 / 66, both algorithms, explicit-Q ranks too)."""
+    from tntorch_amd import _hipops
+    torch.manual_seed(41)
+    for shape, r in (([6, 7, 5, 8], 5), ([4, 6, 4], 70)):
+        g = oracle.tt_randn(shape, r, dtype=torch.float32, batch_size=131)
+        inp = [c.cuda() for c in oracle.tt_add(g, g, batch=True)]
+        for alg in ("svd", "eig"):
+            outs = []
+            for enabled in (True, False):
+                _hipops.STREAM_CHUNKS_ENABLED = enabled
+                try:
+                    t = tn.Tensor([c.clone() for c in inp], batch=True)
+                    t.round_tt(rmax=3, algorithm=alg)
+                finally:
+                    _hipops.STREAM_CHUNKS_ENABLED = True
+                torch.cuda.synchronize()
+                outs.append(t)
+            for a, b in zip(outs[0].cores, outs[1].cores):
+                assert a.shape == b.shape and a.is_contiguous() and torch.equal(a, b)
+            X = oracle.tt_to_dense([c.cpu().double() for c in inp], batch=True)
+            ref = oracle.round_tt([c.cpu() for c in inp], rmax=3, algorithm=alg, batch=True)
+            e_o = rel_diff(outs[0].torch().cpu(), X)
+            e_r = rel_diff(oracle.tt_to_dense([c.double() for c in ref], batch=True), X)
+            assert abs(e_o - e_r) <= 2e-5
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""
