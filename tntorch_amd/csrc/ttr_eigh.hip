@@ -357,6 +357,27 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 //   lane = column   for forming Q (each lane reduces its own column: no cross-lane reductions)
 // The matrix is scaled by 1/max|G_ii| on load (fp32 Gram matrices of the metric workload reach 1e24, whose
 // squares overflow) and the eigenvalues are scaled back at the end.
+// r = sqrt(f^2 + g^2) and 1/r for the QL rotations.  The recurrence is computed redundantly by all 64 lanes and
+// is ~60 % of the kernel's VALU instructions (PMC: 254 k VALU instructions per 64 x 64 matrix, the kernel is
+// VALU-issue-bound), so fp32 uses the hardware rsq + one Newton step (full fp32 accuracy, 7 instructions) instead
+// of the IEEE sqrt and divide expansions (~25).
+__device__ __forceinline__ void givens_norm(float f, float g, float& r, float& rinv) {
+  const float x = f * f + g * g;
+  if (x < 1e-36f || x > 1e36f) {  // out of the fast path's range: exact fallback (also x == 0)
+    r = sqrtf(x);
+    rinv = r > 0.f ? 1.0f / r : 0.f;
+    return;
+  }
+  float y = __builtin_amdgcn_rsqf(x);
+  y = y * (1.5f - 0.5f * x * y * y);
+  rinv = y;
+  r = x * y;
+}
+__device__ __forceinline__ void givens_norm(double f, double g, double& r, double& rinv) {
+  r = sqrt(f * f + g * g);
+  rinv = r > 0. ? 1.0 / r : 0.;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -473,7 +494,8 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       int ilast = l;
       for (int i = m - 1; i >= l; --i) {
         const T f = sn * ev[i], b = cs * ev[i];
-        r = sqrt(f * f + g * g);
+        T rinv;
+        givens_norm(f, g, r, rinv);  // r = sqrt(f^2 + g^2), rinv = 1 / r
         if (lane == 0) ev[i + 1] = r;
         if (r == T(0)) {
           if (lane == 0) { dv[i + 1] -= pp; ev[m] = T(0); }
@@ -481,7 +503,6 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
           ilast = i + 1;
           break;
         }
-        const T rinv = T(1) / r;
         sn = f * rinv; cs = g * rinv;
         g = dv[i + 1] - pp;
         r = (dv[i] - g) * sn + T(2) * cs * b;
