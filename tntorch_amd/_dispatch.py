@@ -20,4 +20,7 @@ def ops_for(t: torch.Tensor):
 
     _hip.lib()  # raises RuntimeError if libttround_hip.so has not been built
     _hip.dtype_code(t.dtype)  # raises TypeError for dtypes the kernels do not implement
+    # the sub-batch streams are created on first contact with a device: HIP assigns hardware queues round-robin at
+    # stream creation (4 by default), so early streams are less likely to end up sharing one
+    _hipops._side_streams(t.device, 2)
     return _hipops

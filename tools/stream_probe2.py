@@ -35,13 +35,7 @@ def manual(nchunks):
 
 _hipops.STREAM_CHUNKS_ENABLED = False
 print("product, single stream  :", f"{timeit(product):.2f} ms", flush=True)
-print("manual 2 chunks         :", f"{timeit(manual(2)):.2f} ms", flush=True)
-print("manual 4 chunks         :", f"{timeit(manual(4)):.2f} ms", flush=True)
+for n in (2, 3, 2, 3):
+    print(f"manual {n} chunks         :", f"{timeit(manual(n)):.2f} ms", flush=True)
 _hipops.STREAM_CHUNKS_ENABLED = True
 print("product, internal chunks:", f"{timeit(product):.2f} ms", flush=True)
-_hipops.STREAM_CHUNKS_ENABLED = False
-print("manual 4 chunks again   :", f"{timeit(manual(4)):.2f} ms", flush=True)
-print("product, single stream  :", f"{timeit(product):.2f} ms", flush=True)
-_hipops.STREAM_CHUNKS_ENABLED = True
-_hipops.STREAM_CHUNKS_ENABLED = True
-t0 = time.perf_counter(); product(); print("host issue time of one chunked round_tt:", f"{(time.perf_counter()-t0)*1e3:.2f} ms"); torch.cuda.synchronize()
