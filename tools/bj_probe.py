@@ -4,8 +4,9 @@ sys.path.insert(0, "/root/repo")
 import torch
 from tntorch_amd import _hip as h, _hipops
 
-for dt in (torch.float32, torch.float64):
-    for n, B, solver in [(128, 2, 2), (288, 1, 2), (512, 1, 2), (1024, 1, 2), (128, 2, 1), (256, 8, 2), (256, 64, 2)]:
+for thr in (0,):
+  for dt in (torch.float32, torch.float64):
+    for n, B, solver in [(288, 1, 2), (512, 1, 2), (1024, 1, 2), (256, 8, 2), (256, 64, 2), (128, 2, 1)]:
         g = torch.Generator().manual_seed(n)
         Mx = torch.randn(B, n, 2 * n + 1, generator=g, dtype=torch.float64)
         Mx = Mx * torch.logspace(0, -3, n, dtype=torch.float64)[None, :, None]
