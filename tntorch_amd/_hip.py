@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_int64, c_void_p
 from typing import Optional, Tuple
 
 import torch

@@ -6,12 +6,12 @@ allocates, reshapes, slices and copies.
 
 Algorithms (reference call sites in brackets):
 
-* ``qr``            Householder TSQR                               [tensor.py:1816]
+* ``qr``            Householder TSQR; block Gram-Schmidt around it above 64 columns  [tensor.py:1816]
 * ``truncate``      truncated SVD of ``M`` [round.py:52-187]:
-    - ``algorithm='eig'``: Gram -> Jacobi eigh (with the reference's 1e-8 clamp) ->
+    - ``algorithm='eig'``: Gram -> tridiagonal-QL eigh (with the reference's 1e-8 clamp) ->
       rank rule -> projection; one pass, Gram accuracy (sigma resolved down to
       ~sqrt(eps)*sigma_max), exactly what round.py:101-135 computes.
-    - ``algorithm='svd'``: two Gram/Jacobi passes.  Pass 1 rotates ``M`` into rows
+    - ``algorithm='svd'``: two Gram passes (tridiagonal QL, then Jacobi).  Pass 1 rotates ``M`` into rows
       (columns) that are orthogonal down to the accuracy of a float Gram matrix; pass 2
       re-computes the Gram matrix of the ROTATED matrix, whose small rows are now formed
       from small numbers (no cancellation against sigma_max^2), so every sigma comes out
@@ -22,6 +22,11 @@ Algorithms (reference call sites in brackets):
 * ``dense_tt_svd``  right-to-left TT-SVD on the dense unfoldings; mathematically equal to
                     the reference's identity-padded ``_full_rank_tt`` + ``round_tt``
                     [tensor.py:10-104, 401-408], but feasible at scale.
+* ``eigh_block_jacobi``  eigenproblems above one workgroup (n up to 1024)     [round.py:96, 115]
+* ``round_tucker`` / ``dense_tucker_tt``  Tucker rounding, ST-HOSVD entry   [tensor.py:1911-2006, 401-408]
+* ``cp_als``        CP-ALS with a fused MTTKRP                                [tensor.py:210-400]
+* ``decompress`` / ``dot`` / ``core_kron``  consumers and producers     [tensor.py:1639-1687, metrics.py:28-116,
+                    tensor.py:2309-2320]
 """
 
 from __future__ import annotations

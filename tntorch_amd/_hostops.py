@@ -10,7 +10,7 @@ round-off.  It is selected ONLY for CPU tensors; device tensors never come here
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 

@@ -5,7 +5,6 @@ Mirror of the TT subset of ``tntorch/create.py`` (``rand``, ``randn``, ``ones``,
 in order, so a seeded call reproduces the reference's cores exactly.
 """
 
-from typing import Any, Optional, Sequence, Union
 
 import torch
 
