@@ -52,35 +52,39 @@ __global__ __launch_bounds__(kThreads) void hadamard_kernel(const T* __restrict_
     out[i] = a[i] * b[i];
 }
 
-// out[b, r1*S1 + s1, i, r2*S2 + s2] = a[b, r1, i, r2] * c[b, s1, i, s2]  (slice-wise Kronecker product of two TT cores)
+// out[b, r1*S1 + s1, i, r2*S2 + s2] = a[b, r1, i, r2] * c[b, s1, i, s2]  (slice-wise Kronecker product of two TT cores).
+// One workgroup per output row (b, r1, s1, i): the row index is decoded once per workgroup, the threads walk the
+// contiguous R2*S2 columns (write-coalesced; the a / c rows they read are R2 and S2 elements long and stay in L1).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void core_kron_kernel(const T* __restrict__ a, const T* __restrict__ c,
-                                                              T* __restrict__ out, int64_t R1, int64_t S1, int64_t I,
-                                                              int64_t R2, int64_t S2, int64_t total) {
-  const int64_t w = R2 * S2;
-  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
-    const int64_t col = idx % w;          // r2 * S2 + s2
-    int64_t t = idx / w;
-    const int64_t i = t % I; t /= I;
-    const int64_t row = t % (R1 * S1);    // r1 * S1 + s1
-    const int64_t b = t / (R1 * S1);
-    const int64_t r1 = row / S1, s1 = row - r1 * S1, r2 = col / S2, s2 = col - r2 * S2;
-    out[idx] = a[((b * R1 + r1) * I + i) * R2 + r2] * c[((b * S1 + s1) * I + i) * S2 + s2];
+                                                              T* __restrict__ out, int R1, int S1, int I, int R2,
+                                                              int S2) {
+  int64_t t = blockIdx.x;
+  const int i = (int)(t % I); t /= I;
+  const int s1 = (int)(t % S1); t /= S1;
+  const int r1 = (int)(t % R1);
+  const int64_t b = t / R1;
+  const T* __restrict__ ar = a + ((b * R1 + r1) * I + i) * (int64_t)R2;
+  const T* __restrict__ cr = c + ((b * S1 + s1) * I + i) * (int64_t)S2;
+  T* __restrict__ orow = out + (int64_t)blockIdx.x * R2 * S2;
+  const int w = R2 * S2;
+  for (int col = threadIdx.x; col < w; col += kThreads) {
+    const int r2 = col / S2, s2 = col - r2 * S2;
+    orow[col] = ar[r2] * cr[s2];
   }
 }
 
 int core_kron_dispatch(int dtype, int64_t B, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
                        const void* c, void* out, hipStream_t stream) {
-  const int64_t total = B * R1 * S1 * I * R2 * S2;
-  int64_t gx = ceil_div(total, kThreads);
-  if (gx > 16384) gx = 16384;
+  const int64_t rows = B * R1 * S1 * I;
+  TTR_REQUIRE(rows <= 2147483647LL && R2 * S2 <= 2147483647LL, TTR_E_UNSUPPORTED, "ttr_core_kron: core too large");
   ProfScope prof(TTR_PROF_MISC, stream);
   if (dtype == TTR_F32)
-    hipLaunchKernelGGL(core_kron_kernel<float>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const float*)a,
-                       (const float*)c, (float*)out, R1, S1, I, R2, S2, total);
+    hipLaunchKernelGGL(core_kron_kernel<float>, dim3((unsigned)rows), dim3(kThreads), 0, stream, (const float*)a,
+                       (const float*)c, (float*)out, (int)R1, (int)S1, (int)I, (int)R2, (int)S2);
   else
-    hipLaunchKernelGGL(core_kron_kernel<double>, dim3((unsigned)gx), dim3(kThreads), 0, stream, (const double*)a,
-                       (const double*)c, (double*)out, R1, S1, I, R2, S2, total);
+    hipLaunchKernelGGL(core_kron_kernel<double>, dim3((unsigned)rows), dim3(kThreads), 0, stream, (const double*)a,
+                       (const double*)c, (double*)out, (int)R1, (int)S1, (int)I, (int)R2, (int)S2);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
