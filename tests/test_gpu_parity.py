@@ -536,6 +536,10 @@ def test_stream_chunks_identical():
                 outs.append(t)
             for a, b in zip(outs[0].cores, outs[1].cores):
                 assert a.shape == b.shape and a.is_contiguous() and torch.equal(a, b)
+            # the chunked sweep lays the cores out back to back: the gather's packing step is a view, not a copy
+            flat = tn.dist_batch.pack_cores(outs[0].cores)
+            assert flat.data_ptr() == outs[0].cores[0].data_ptr() and flat.numel() == sum(c.numel() for c in outs[0].cores)
+            assert tn.dist_batch.pack_cores(outs[1].cores).data_ptr() != outs[1].cores[0].data_ptr()
             X = oracle.tt_to_dense([c.cpu().double() for c in inp], batch=True)
             ref = oracle.round_tt([c.cpu() for c in inp], rmax=3, algorithm=alg, batch=True)
             e_o = rel_diff(outs[0].torch().cpu(), X)

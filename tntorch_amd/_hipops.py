@@ -435,18 +435,43 @@ def _side_streams(dev: torch.device, n: int):
 
 
 class _OutArena:
-    """Full-batch result tensors of a chunked sweep; every sub-batch writes its own batch slice."""
+    """Result tensors of a chunked sweep: ONE flat full-batch buffer holding the rounded cores back to back
+    (core-major, each core [B, r, I, r'] contiguous), every sub-batch writes its own batch slice of every core.
+    The layout is exactly what ``dist_batch.pack_cores`` produces, so the multi-GPU gather sends it without a
+    packing copy."""
 
-    def __init__(self, total: int, bounds, main_stream):
-        self.total, self.bounds, self.main = total, bounds, main_stream
-        self.full: dict = {}
+    def __init__(self, total: int, bounds, main_stream, tails, like: torch.Tensor):
+        self.total, self.bounds, self.tails = total, bounds, tails
+        sizes = [total * t[0] * t[1] for t in tails]
+        with torch.cuda.stream(main_stream):  # owned by the caller's stream, like any other result
+            self.flat = torch.empty(sum(sizes), dtype=like.dtype, device=like.device)
+        self.full, off = [], 0
+        for t, sz in zip(tails, sizes):
+            self.full.append(self.flat[off:off + sz].view(total, t[0], t[1]))
+            off += sz
 
-    def slice(self, key, chunk: int, tail, like: torch.Tensor) -> torch.Tensor:
-        if key not in self.full:
-            with torch.cuda.stream(self.main):  # owned by the caller's stream, like any other result
-                self.full[key] = torch.empty((self.total,) + tuple(tail), dtype=like.dtype, device=like.device)
+    def slice(self, key: int, chunk: int, tail) -> torch.Tensor:
+        assert tuple(tail) == tuple(self.tails[key]), (key, tail, self.tails[key])
         lo, hi = self.bounds[chunk]
         return self.full[key][lo:hi]
+
+
+def _rounded_tails(shapes, rmax):
+    """Shapes of the cores round_tt produces in batch mode (no data-dependent ranks, round.py:149-150), as the
+    2-D tails the arena stores: core 0 -> (r0*I, r1), core mu > 0 -> (r, I*r')."""
+    N = len(shapes)
+    lr = [shapes[0][0]]
+    for mu in range(N - 1):
+        lr.append(min(lr[mu] * shapes[mu][1], shapes[mu][2]))
+    out_r = [None] * (N + 1)
+    out_r[N] = shapes[N - 1][2]
+    for mu in range(N - 1, 0, -1):
+        k = min(lr[mu], shapes[mu][1] * out_r[mu + 1])
+        out_r[mu] = _rank_cap(rmax[mu - 1], k)
+    out_r[0] = lr[0]
+    tails = [(out_r[0] * shapes[0][1], out_r[1])]
+    tails += [(out_r[mu], shapes[mu][1] * out_r[mu + 1]) for mu in range(1, N)]
+    return tails, out_r
 
 
 def round_tt(
@@ -485,17 +510,17 @@ def round_tt(
         hi = lo + q + (1 if ci < rem else 0)
         bounds.append((lo, hi))
         lo = hi
-    arena = _OutArena(Bt, bounds, main)
-    shapes = None
+    shapes = [tuple(x.shape[1:]) for x in c]
+    tails, out_r = _rounded_tails(shapes, rmax)
+    arena = _OutArena(Bt, bounds, main, tails, c[0])
     for ci, st in enumerate(streams):
         st.wait_stream(main)
         with torch.cuda.stream(st):
             lo, hi = bounds[ci]
-            out = _round_tt_sweep([x[lo:hi] for x in c], eps, rmax, algorithm, batch, arena, ci)
-            shapes = [tuple(o.shape[1:]) for o in out]
+            _round_tt_sweep([x[lo:hi] for x in c], eps, rmax, algorithm, batch, arena, ci)
     for st in streams:
         main.wait_stream(st)
-    return [arena.full[mu].reshape((Bt,) + shapes[mu]) for mu in range(N)]
+    return [arena.full[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
 
 
 def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.Tensor]:
@@ -538,8 +563,8 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
         Bt, R, I, rn = M4.shape
         alloc = None
         if arena is not None:
-            def alloc(r, mu=mu, n=I * rn, like=M4):
-                return arena.slice(mu, chunk, (r, n), like)
+            def alloc(r, mu=mu, n=I * rn):
+                return arena.slice(mu, chunk, (r, n))
         t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc)
         right = t.right
         if arena is not None:
@@ -552,7 +577,7 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
     f, r0, I = facs[0]
     dst = None
     if arena is not None:
-        dst = arena.slice(0, chunk, (r0 * I, left.shape[2]), left)
+        dst = arena.slice(0, chunk, (r0 * I, left.shape[2]))
     c[0] = _apply_q(f, left, dst).reshape(f.batch, r0, I, left.shape[2])
     return c
 

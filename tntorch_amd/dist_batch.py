@@ -9,7 +9,8 @@ communication, and the rounded cores are collected with ONE gather of a packed b
 (rmax mode => identical core shapes on every rank, so the buffer layout is static).
 
 xGMI is point-to-point: every peer reaches the root over its own link, so the gather is
-bound by one link per peer (0.8 GB per rank for 512 rounded 64^8 trains).  ``gather_batch``
+bound by one link per peer (0.8 GB per rank for 512 rounded 64^8 trains).  The device ``round_tt``
+writes the rounded cores of a large batch back to back into one buffer, so packing is a view.  ``gather_batch``
 can therefore run asynchronously (``async_op=True``): RCCL executes it on its own stream
 while the next batch is already being rounded, and the root receives views into the
 per-rank receive buffers -- no concatenation copy.
@@ -33,7 +34,20 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def pack_cores(cores: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Concatenate batched cores ``[B, r0, I, r1]`` into one flat buffer (core-major)."""
+    """Batched cores ``[B, r0, I, r1]`` as one flat buffer (core-major).  Zero-copy when the cores already lie back
+    to back in one storage -- which is how the device ``round_tt`` lays out the result of a large batch."""
+    c0 = cores[0]
+    off = c0.storage_offset()
+    packed = all(c.is_contiguous() and c.dtype == c0.dtype for c in cores)
+    if packed:
+        for c in cores:
+            if c.untyped_storage().data_ptr() != c0.untyped_storage().data_ptr() or c.storage_offset() != off:
+                packed = False
+                break
+            off += c.numel()
+    if packed:
+        total = off - c0.storage_offset()
+        return torch.empty(0, dtype=c0.dtype, device=c0.device).set_(c0.untyped_storage(), c0.storage_offset(), (total,), (1,))
     return torch.cat([c.reshape(-1) for c in cores])
 
 
