@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
     Vs[i * ld + j] = (i == j) ? T(1) : T(0);
   }
-  if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+  if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
   __syncthreads();
   T floor_abs = Num<T>::tiny();
   if (p.abs_floor) {
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs) {  // no overflow of app*aqq
             jacobi_cs(app, aqq, apq, c, s);
             flags[0] = 1;
+            flags[2 + (r & 1)] = 1;  // this round has work
           }
         }
         // n odd: the player paired with the phantom index sits this round out.  Its pair is stored as
@@ -178,6 +179,11 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
         prow[k] = pp * ld; qrow[k] = qq * ld;
       }
       __syncthreads();
+      // Rounds in which no pair passed the rotation test (the common case once the matrix is nearly diagonal:
+      // pass 2 of the 'svd' algorithm, late block-Jacobi sweeps) skip the two update passes altogether.
+      const bool round_work = flags[2 + (r & 1)] != 0;
+      if (tid == 0) flags[2 + ((r + 1) & 1)] = 0;  // slot of the NEXT round; nobody touches it before the barrier below
+      if (round_work) {
       // ---- phase 2: G <- J^T G J on 2x2 blocks.  Thread item = (row pair kr, column pair kc): the block
       // G[{p,q}][{p',q'}] is read, rotated from both sides and written back by ONE thread, so the two-sided
       // update is a single in-place pass (4 LDS reads, 16 flops, 4 writes) instead of a column pass, a
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           }
         }
       }
+      }  // round_work
       __syncthreads();
     }
     const int rotated = flags[0];
