@@ -139,20 +139,29 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int krs = 4 * (64 / cw);                       // row-pair stride between a thread's blocks
   const int kr0 = (tid >> 6) * (64 / cw) + (tid & 63) / cw;
 
-  // Pre-check (pass 2 of the 'svd' algorithm hands over an already diagonal-to-working-accuracy matrix):
-  // if no off-diagonal entry passes the rotation test, no sweep runs, V stays the identity and the
-  // re-orthogonalisation below is skipped.
-  for (int idx = tid; idx < n * n; idx += kThreads) {
-    const int i = idx / n, j = idx - i * n;
-    if (i < j) {
-      const T aabs = fabs(Gs[i * ld + j]);
-      if (aabs > eps * (sqrt(fabs(Gs[i * ld + i])) * sqrt(fabs(Gs[j * ld + j]))) && aabs > floor_abs) flags[1] = 1;
+  // Convergence scan, before every sweep: does any off-diagonal entry pass the rotation test?  One pass over the
+  // matrix and one barrier -- instead of a whole rotation-free sweep (63 rounds, 126 barriers) to find out.  Pass 2
+  // of the 'svd' algorithm hands over an already diagonal-to-working-accuracy matrix: then no sweep runs at all, V
+  // stays the identity and the re-orthogonalisation below is skipped.
+  auto needs_work = [&]() {
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int i = idx / n, j = idx - i * n;
+      if (i < j) {
+        const T aabs = fabs(Gs[i * ld + j]);
+        if (aabs > eps * (sqrt(fabs(Gs[i * ld + i])) * sqrt(fabs(Gs[j * ld + j]))) && aabs > floor_abs) flags[1] = 1;
+      }
     }
-  }
-  __syncthreads();
-  const bool any_work = flags[1] != 0;
+    __syncthreads();
+    const bool w = flags[1] != 0;
+    __syncthreads();
+    if (tid == 0) flags[1] = 0;
+    return w;  // (the next write to flags[1] happens after at least one more barrier)
+  };
+  bool any_work = false;
   int sweeps_used = 0;
-  for (int sweep = 0; sweep < p.max_sweeps && n > 1 && any_work; ++sweep) {
+  for (int sweep = 0; sweep < p.max_sweeps && n > 1; ++sweep) {
+    if (!needs_work()) break;
+    any_work = true;
     sweeps_used = sweep + 1;
     for (int r = 0; r < m1; ++r) {
       // ---- phase 1: rotations of this round (one thread per pair)
@@ -166,7 +175,6 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
           const T aabs = fabs(apq);
           if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs) {  // no overflow of app*aqq
             jacobi_cs(app, aqq, apq, c, s);
-            flags[0] = 1;
             flags[2 + (r & 1)] = 1;  // this round has work
           }
         }
@@ -268,11 +276,6 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       }  // round_work
       __syncthreads();
     }
-    const int rotated = flags[0];
-    __syncthreads();
-    if (tid == 0) flags[0] = 0;
-    __syncthreads();
-    if (!rotated) break;
   }
 
   // ---- epilogue: clamp / sqrt / sort, Newton-Schulz re-orthogonalisation, permuted write, rank rule
