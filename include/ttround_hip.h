@@ -57,6 +57,7 @@ const char* ttr_last_error(void);
 /* Limits of the LDS/register-resident kernels (queried by the host shim). */
 int ttr_qr_max_cols(int dtype);        /* widest panel ttr_qr factors (columns) */
 int ttr_eigh_max_n_lds(int dtype);     /* largest n solved out of LDS; above it the solver works out of L2/HBM */
+int ttr_eigh_max_n(int dtype);         /* largest n ttr_eigh_trunc accepts (4096 fp32 / 2048 fp64) */
 
 /*
  * C[b] = scale( op(A[b]) * op(B[b]) ),  op(A) is M x K, op(B) is K x N.

@@ -174,7 +174,8 @@ def test_eigh_match_diag(dt, n, solver):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("n,B,solver", [(128, 2, 2), (150, 1, 2), (288, 1, 2), (512, 1, 2), (128, 2, 1), (150, 1, 1),
-                                        (127, 2, 2), (211, 1, 2), (122, 1, 1)])  # last three: padded (no block width divides n)
+                                        (127, 2, 2), (211, 1, 2), (122, 1, 1),   # these three: padded (no block width divides n)
+                                        (2048, 1, 2)])
 def test_eigh_block_jacobi(dt, n, B, solver):
     """Large-n driver (_hipops._eigh_any): block Jacobi over pair problems + sorted epilogue.
     solver 2: tridiagonal pair solver, absolute stop test; solver 1: Jacobi pair solver, relative stop test."""
@@ -189,11 +190,12 @@ def test_eigh_block_jacobi(dt, n, B, solver):
     wref = torch.linalg.eigvalsh(G.double()).flip(-1).clamp_min(0)
     assert (info == n).all()
     assert (sig[:, :-1] >= sig[:, 1:]).all()
-    assert ((sig**2 - wref).abs().max(dim=1).values / wref[:, 0]).max() < tol(dt, 4e-6, 1e-13)
+    grow = max(1.0, (n / 512) ** 0.5)   # rounding of the n-term Rayleigh quotients / residuals grows like sqrt(n)
+    assert ((sig**2 - wref).abs().max(dim=1).values / wref[:, 0]).max() < grow * tol(dt, 4e-6, 1e-13)
     eye = torch.eye(n, dtype=torch.float64)
-    assert (V.transpose(1, 2) @ V - eye).abs().max() < tol(dt, 3e-5, 1e-12)
+    assert (V.transpose(1, 2) @ V - eye).abs().max() < grow * tol(dt, 3e-5, 1e-12)
     resid = (G.double() @ V - V * (sig**2)[:, None, :]).abs().max() / wref.max()
-    assert resid < tol(dt, 3e-5, 1e-12)
+    assert resid < grow * tol(dt, 3e-5, 1e-12)
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "ttr_last_error": (c_char_p, []),
     "ttr_qr_max_cols": (c_int, [c_int]),
     "ttr_eigh_max_n_lds": (c_int, [c_int]),
+    "ttr_eigh_max_n": (c_int, [c_int]),
     "ttr_gemm_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "ttr_gemm": (
         c_int,
@@ -160,8 +161,8 @@ def max_qr_cols(dt: torch.dtype) -> int:
     return lib().ttr_qr_max_cols(dtype_code(dt))
 
 
-def max_eigh_n() -> int:
-    return 1024
+def max_eigh_n(dt: torch.dtype = torch.float32) -> int:
+    return lib().ttr_eigh_max_n(dtype_code(dt))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ Algorithms (reference call sites in brackets):
 * ``dense_tt_svd``  right-to-left TT-SVD on the dense unfoldings; mathematically equal to
                     the reference's identity-padded ``_full_rank_tt`` + ``round_tt``
                     [tensor.py:10-104, 401-408], but feasible at scale.
-* ``eigh_block_jacobi``  eigenproblems above one workgroup (n up to 1024)     [round.py:96, 115]
+* ``eigh_block_jacobi``  eigenproblems above one workgroup (n up to 4096 fp32 / 2048 fp64)  [round.py:96, 115]
 * ``round_tucker`` / ``dense_tucker_tt``  Tucker rounding, ST-HOSVD entry   [tensor.py:1911-2006, 401-408]
 * ``cp_als``        CP-ALS with a fused MTTKRP                                [tensor.py:210-400]
 * ``decompress`` / ``dot`` / ``core_kron``  consumers and producers     [tensor.py:1639-1687, metrics.py:28-116,
@@ -222,7 +222,7 @@ def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, ca
     nblk = -(-n // 32)
     b = -(-n // nblk)
     npad = nblk * b
-    if npad > _hip.max_eigh_n():
+    if npad > _hip.max_eigh_n(G.dtype):
         return _hip.eigh_trunc(G, eig_mode, use_delta, delta2, cap, abs_floor=solver)
     gn = _hip.norm(G.reshape(Bt, -1))                                     # >= |lambda|_max
     Gp = G.new_zeros((Bt, npad, npad))

@@ -151,6 +151,7 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
                   int64_t ws_bytes, hipStream_t stream);
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
+int eigh_max_n(int dtype);
 int eigh_max_n_lds(int dtype);
 
 extern long long* g_qr_dbg;
@@ -169,6 +170,7 @@ const char* ttr_last_error(void) { return g_err.c_str(); }
 
 int ttr_qr_max_cols(int dtype) { return qr_max_cols(dtype); }
 int ttr_eigh_max_n_lds(int dtype) { return eigh_max_n_lds(dtype); }
+int ttr_eigh_max_n(int dtype) { return eigh_max_n(dtype); }
 
 int64_t ttr_gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch) {
   return gemm_workspace_bytes(dtype, M, N, K, batch);

@@ -47,7 +47,8 @@ struct EighArgs {
   int32_t* sweeps;   // optional [batch]: sweeps used (diagnostics / convergence tests)
 };
 
-constexpr int kMaxPairs = 512;  // n <= 1024 in the global-memory variant
+constexpr int kMaxPairs = 2048;  // n <= 4096 (fp32) / 2048 (fp64) in the global-memory variant: its rotation table and
+                                // sort scratch still have to fit the 160 KB LDS
 
 template <typename T>
 __host__ __device__ constexpr size_t rot_table_bytes(int npad) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T floor_abs = Num<T>::tiny();
   if (p.abs_floor) {
     T gmax = 0;
-    for (int i = 0; i < n; ++i) gmax = fmax(gmax, fabs(Gs[i * ld + i]));  // broadcast reads, n <= 1024
+    for (int i = 0; i < n; ++i) gmax = fmax(gmax, fabs(Gs[i * ld + i]));  // broadcast reads
     floor_abs = fmax(floor_abs, Num<T>::eps() * sqrt((T)n) * gmax);
   }
 
@@ -635,6 +636,8 @@ int eigh_max_n_lds(int dtype) {
   return n;
 }
 
+int eigh_max_n(int dtype) { return dtype == TTR_F64 ? kMaxPairs : 2 * kMaxPairs; }
+
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   if (n <= eigh_max_n_lds(dtype)) return 0;
   return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
@@ -645,8 +648,9 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
                       int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                       int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
                       int64_t ws_bytes, hipStream_t stream) {
-  TTR_REQUIRE(n >= 1 && n <= 2 * kMaxPairs, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %d]", (long long)n,
-              2 * kMaxPairs);
+  const int64_t nmax = eigh_max_n(dtype);
+  TTR_REQUIRE(n >= 1 && n <= nmax, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %lld]", (long long)n,
+              (long long)nmax);
   EighArgs<T> p;
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
@@ -681,6 +685,8 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, stream, p);
   } else {
     auto kern = eigh_jacobi_kernel<T, false>;
+    if (lds > 64 * 1024)
+      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, stream, p);
   }
   TTR_HIP_CHECK(hipGetLastError());
