@@ -547,6 +547,38 @@ def test_stream_chunks_identical():
             assert abs(e_o - e_r) <= 2e-5
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_dense_and_tucker_vs_oracle(seed):
+    """Seeded random dense tensors (3..5 modes, ragged sizes 2..14): the TT / Tucker-TT constructors and
+    round_tucker on the device against the oracle -- ranks identical, approximation error within 1e-9 (float64)."""
+    rng = np.random.RandomState(2000 + seed)
+    N = int(rng.randint(3, 6))
+    shape = [int(rng.randint(2, 15)) for _ in range(N)]
+    torch.manual_seed(100 + seed)
+    r = int(rng.randint(2, 5))
+    low = oracle.tt_to_dense(oracle.tt_randn(shape, r, dtype=torch.float64))
+    X = low / low.norm() + 10.0 ** rng.uniform(-6, -2) * torch.randn(shape, dtype=torch.float64) / math.sqrt(low.numel())
+    for alg in ("svd", "eig"):
+        rt = int(rng.randint(1, 6))
+        ref = oracle.dense_to_tt(X, rt, algorithm=alg)
+        t = tn.Tensor(X, ranks_tt=rt, algorithm=alg, device="cuda")
+        assert t.ranks_tt.tolist() == ranks(ref), (seed, alg, shape, rt)
+        e_o, e_r = rel_diff(t.torch().cpu(), X), rel_diff(dense(ref), X)
+        assert abs(e_o - e_r) <= 1e-9 + 1e-6 * e_r, (seed, alg, shape, rt, e_o, e_r)
+        rk = int(rng.randint(1, 5))
+        cores_r, Us_r = oracle.dense_to_tucker_tt(X, ranks_tucker=rk, ranks_tt=rt, algorithm=alg)
+        t2 = tn.Tensor(X, ranks_tucker=rk, ranks_tt=rt, algorithm=alg, device="cuda")
+        assert t2.ranks_tucker.tolist() == [c.shape[1] for c in cores_r] and t2.ranks_tt.tolist() == ranks(cores_r)
+        e_o, e_r = rel_diff(t2.torch().cpu(), X), rel_diff(oracle.tucker_to_dense(cores_r, Us_r), X)
+        assert abs(e_o - e_r) <= 1e-9 + 1e-5 * e_r, (seed, alg, shape, rk, rt, e_o, e_r)
+        eps = float(10.0 ** rng.uniform(-7, -2))
+        c3, U3 = oracle.round_tucker(ref, None, eps=eps, algorithm=alg)
+        t3 = gpu_tensor(ref)
+        t3.round_tucker(eps=eps, algorithm=alg)
+        assert rel_diff(t3.torch().cpu(), dense(ref)) <= eps * (1 + 1e-6) + 1e-9
+        assert sum(t3.ranks_tucker.tolist()) <= sum(c.shape[1] for c in c3) + (0 if alg == "svd" else N)
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""
