@@ -145,11 +145,17 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   // of the 'svd' algorithm hands over an already diagonal-to-working-accuracy matrix: then no sweep runs at all, V
   // stays the identity and the re-orthogonalisation below is skipped.
   auto needs_work = [&]() {
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-      const int i = idx / n, j = idx - i * n;
-      if (i < j) {
-        const T aabs = fabs(Gs[i * ld + j]);
-        if (aabs > eps * (sqrt(fabs(Gs[i * ld + i])) * sqrt(fabs(Gs[j * ld + j]))) && aabs > floor_abs) flags[1] = 1;
+    // exactly the test of phase 1, on exactly the element phase 1 reads (G[p][q] of the schedule's ordered pair:
+    // the two-sided updates leave G symmetric only to rounding, so testing the other triangle could disagree
+    // with phase 1 at the threshold and keep a finished matrix spinning until max_sweeps)
+    for (int idx = tid; idx < m1 * np; idx += kThreads) {
+      const int r = idx / np, k = idx - r * np;
+      int pp, qq;
+      if (k == 0) { pp = ne - 1; qq = r % m1; }
+      else { pp = (r + k) % m1; qq = (r - k + m1) % m1; }
+      if (pp < n && qq < n) {
+        const T aabs = fabs(Gs[pp * ld + qq]);
+        if (aabs > eps * (sqrt(fabs(Gs[pp * ld + pp])) * sqrt(fabs(Gs[qq * ld + qq]))) && aabs > floor_abs) flags[1] = 1;
       }
     }
     __syncthreads();

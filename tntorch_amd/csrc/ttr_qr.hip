@@ -33,7 +33,11 @@
 
 namespace ttr {
 
-constexpr int BR = 256;   // rows per block (= threads: thread t also acts as "row t")
+// rows per block = threads per block = 64 * NW (thread t also acts as "row t"); NW = 4 or 8 waves, chosen per
+// tree level by the host: the sequential Householder steps of a block cost about the same for 256 and for 512
+// rows (they are latency / issue bound, lane = row), so the larger block halves the number of blocks AND of
+// tree nodes -- the smaller one is kept for matrices of <= 256 rows.
+constexpr int BR4 = 256;
 constexpr int PW = 16;    // panel width = MFMA tile edge
 constexpr int VLD = 17;   // leading dimension of 16-column LDS panels (conflict-free column walks)
 template <int I>
@@ -83,16 +87,19 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 }
 
 // ---------------------------------------------------------------- factor
-template <typename T, int NT, bool PUSHED>
-__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
+template <typename T, int NT, bool PUSHED, int NW>
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
   constexpr int NP = PW * NT;  // padded column count
+  constexpr int BR = 64 * NW;  // rows = threads of this block
+  constexpr int NTH = 64 * NW;
+  constexpr int CPW = PW / NW; // panel columns owned by a wave in the column-owning layout (4 or 2)
   __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];       // current panel's reflectors [row][j]
   __shared__ T taus[NP];
   __shared__ T Ts[PW * VLD], Ss[PW * VLD];
   constexpr int WPC = NP > 2 * PW ? NP - PW : PW;               // W only exists for the trailing column tiles (tn >= 1)
-  __shared__ T Wp[4][PW][WPC];                                  // per-wave partial W (also S partials): 4 WGs per CU
+  __shared__ T Wp[NW][PW][WPC];                                 // per-wave partial W (also S partials)
   __shared__ T W2s[PW][NP + 1];
 
   const int tid = threadIdx.x;
@@ -110,12 +117,12 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
 
   Acc acc[4][NT];
   if constexpr (PUSHED) {
-    // acc <- Rm (pk x pRin) * C[:, i, :] (pRin x n) for this wave's mode index i = 4b + wave: the wave's 64
+    // acc <- Rm (pk x pRin) * C[:, i, :] (pRin x n) for this wave's mode index i = NW*b + wave: the wave's 64
     // rows are exactly (kk = 0..63, i).  Rm^T is staged once in LDS (aliasing Vs, conflict-free A-operand
     // reads), the core slice is read from global directly in MFMA B-operand layout.
     T* Rs = Vs;  // [r0][kk], 64 x 64 (Vs holds 256 x 17)
     const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+    for (int idx = tid; idx < 64 * 64; idx += NTH) {
       const int kk = idx >> 6, r0 = idx & 63;
       Rs[r0 * 64 + kk] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
     }
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
-    const int imode = b * 4 + wave;
+    const int imode = b * NW + wave;
     const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
     const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
     const bool ivalid = imode < p.pI;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
     // columns 4w..4w+3 completely -- lane l has rows l, l+64, l+128, l+192.  The column norm and every
     // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
     // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
-    T pc[4][4];  // [column 4w+cc][row lane + 64 q]
+    T pc[CPW][NW];  // [column CPW*w + cc][row lane + 64 q]
     if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
@@ -185,39 +192,39 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
       for (int r = 0; r < 4; ++r) Vs[rowl(tm, r) * VLD + cl] = acc[tm][pnl][r];
     lds_barrier();
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
+    for (int cc = 0; cc < CPW; ++cc)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * 4 + cc];
+      for (int q = 0; q < NW; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * CPW + cc];
     lds_barrier();  // all columns are in registers before reflectors start overwriting Vs
     stamp();
     if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
       for (int j = nsteps; j < PW; ++j) Vs[tid * VLD + j] = T(0);
     }
-    // Steps: a RUNTIME loop over the owner wave (4); the owner factors its FOUR columns locally (build a
-    // reflector, apply it to its remaining columns, ... -- all wave-local, no barrier), publishes the four
-    // reflectors, and after ONE barrier the waves to its right apply them to their own columns.  A panel costs
-    // 4 barrier phases instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
-    for (int owv = 0; owv < 4; ++owv) {
-      if (owv * 4 < nsteps) {  // block-uniform
-        if (wave_id == owv) {  // wave-uniform: local Householder QR of columns 4*owv .. 4*owv+3
+    // Steps: a RUNTIME loop over the owner wave; the owner factors its CPW columns locally (build a reflector,
+    // apply it to its remaining columns, ... -- all wave-local, no barrier), publishes the reflectors, and after
+    // ONE barrier the waves to its right apply them to their own columns.  A panel costs NW barrier phases
+    // instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
+    for (int owv = 0; owv < NW; ++owv) {
+      if (owv * CPW < nsteps) {  // block-uniform
+        if (wave_id == owv) {  // wave-uniform: local Householder QR of columns CPW*owv .. CPW*owv + CPW-1
           auto local = [&](auto OC) {
             constexpr int oc = decltype(OC)::value;
-            const int j = owv * 4 + oc;
+            const int j = owv * CPW + oc;
             if (j < nsteps) {
               const int jj = j0 + j;
               // ONE reduction round per step: the column norm below the diagonal and the dot products of that
               // sub-column x with the owner's remaining columns travel together; v^T c = scale * x^T c + c[jj]
               // (v = scale * x below the diagonal, 1 on it) needs no second round.
-              T x[4];
+              T x[NW];
               x[0] = (lane > jj) ? pc[oc][0] : T(0);
 #pragma unroll
-              for (int q = 1; q < 4; ++q) x[q] = pc[oc][q];
+              for (int q = 1; q < NW; ++q) x[q] = pc[oc][q];
               T d4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-              for (int cc = oc; cc < 4; ++cc) {
+              for (int cc = oc; cc < CPW; ++cc) {
                 d4[cc] = x[0] * pc[cc][0];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) d4[cc] += x[q] * pc[cc][q];
+                for (int q = 1; q < NW; ++q) d4[cc] += x[q] * pc[cc][q];
               }
               wave_sum_dpp4(d4);
               const T ss = d4[oc];
@@ -228,52 +235,53 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
               } else {
                 larfg_scalars(alpha, ss, beta, tj, scale);
               }
-              T v[4];
+              T v[NW];
               v[0] = (lane > jj) ? x[0] * scale : (lane == jj ? T(1) : T(0));
 #pragma unroll
-              for (int q = 1; q < 4; ++q) v[q] = x[q] * scale;
+              for (int q = 1; q < NW; ++q) v[q] = x[q] * scale;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
+              for (int q = 0; q < NW; ++q) {
                 Vs[(lane + 64 * q) * VLD + j] = v[q];
                 Vt[(int64_t)jj * BR + lane + 64 * q] = v[q];  // coalesced, fire and forget
               }
-              if constexpr (oc < 3) {  // apply to the owner's remaining columns
+              if constexpr (oc < CPW - 1) {  // apply to the owner's remaining columns
 #pragma unroll
-                for (int cc = oc + 1; cc < 4; ++cc) {
+                for (int cc = oc + 1; cc < CPW; ++cc) {
                   const T f = tj * (scale * d4[cc] + lane_get(pc[cc][0], jj));
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
+                  for (int q = 0; q < NW; ++q) pc[cc][q] -= f * v[q];
                 }
               }
               if (lane == jj) pc[oc][0] = beta;  // R[jj][jj]
               if (lane == 0) { tau[jj] = tj; taus[jj] = tj; }
             }
           };
-          local(IC<0>{}); local(IC<1>{}); local(IC<2>{}); local(IC<3>{});
+          local(IC<0>{}); local(IC<1>{});
+          if constexpr (CPW > 2) { local(IC<2>{}); local(IC<3>{}); }
         }
-        lds_barrier();  // reflectors 4*owv .. 4*owv+3 (columns of Vs) and their taus are visible
-        if (wave_id > owv && j0 + wave_id * 4 < n) {  // waves right of the owner apply the four reflectors
+        lds_barrier();  // the owner's reflectors (columns of Vs) and their taus are visible
+        if (wave_id > owv && j0 + wave_id * CPW < n) {  // waves right of the owner apply the reflectors
 #pragma unroll
-          for (int rf = 0; rf < 4; ++rf) {
-            const int j = owv * 4 + rf;
+          for (int rf = 0; rf < CPW; ++rf) {
+            const int j = owv * CPW + rf;
             if (j < nsteps) {
-              T v[4];
+              T v[NW];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = Vs[(lane + 64 * q) * VLD + j];
+              for (int q = 0; q < NW; ++q) v[q] = Vs[(lane + 64 * q) * VLD + j];
               const T tj = taus[j0 + j];
-              T d4[4];
+              T d4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-              for (int cc = 0; cc < 4; ++cc) {
+              for (int cc = 0; cc < CPW; ++cc) {
                 d4[cc] = v[0] * pc[cc][0];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) d4[cc] += v[q] * pc[cc][q];
+                for (int q = 1; q < NW; ++q) d4[cc] += v[q] * pc[cc][q];
               }
               wave_sum_dpp4(d4);
 #pragma unroll
-              for (int cc = 0; cc < 4; ++cc) {
+              for (int cc = 0; cc < CPW; ++cc) {
                 const T f = tj * d4[cc];  // columns >= n are all-zero: d = 0, no effect
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pc[cc][q] -= f * v[q];
+                for (int q = 0; q < NW; ++q) pc[cc][q] -= f * v[q];
               }
             }
           }
@@ -286,8 +294,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
       T* __restrict__ Ro = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
       const int rr = p.top ? kb : n;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = j0 + wave_id * 4 + cc;
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int c = j0 + wave_id * CPW + cc;
         if (c < n && lane < rr) Ro[(int64_t)lane * p.ldr + c] = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
       }
     }
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
       if (tid == 0) tau[j0 + j] = T(0);
     }
     lds_barrier();
-    // (5) S = V^T V over the block (MFMA, K = 256 split over the 4 waves), then the triangular factor T
+    // (5) S = V^T V over the block (MFMA, K = BR split over the waves), then the triangular factor T
     {
       Acc s = M::zero();
 #pragma unroll
@@ -308,9 +316,11 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][cl] = s[r];
     }
     lds_barrier();
-    {
+    if (tid < PW * PW) {
       const int i = tid >> 4, k = tid & 15;
-      Ss[i * VLD + k] = (Wp[0][i][k] + Wp[1][i][k]) + (Wp[2][i][k] + Wp[3][i][k]);
+      T acc_s = (Wp[0][i][k] + Wp[1][i][k]) + (Wp[2][i][k] + Wp[3][i][k]);
+      if constexpr (NW == 8) acc_s += (Wp[4][i][k] + Wp[5][i][k]) + (Wp[6][i][k] + Wp[7][i][k]);
+      Ss[i * VLD + k] = acc_s;
     }
     lds_barrier();
     if (tid < PW) {  // larft (forward, columnwise): T[0:j,j] = -tau_j T[0:j,0:j] S[0:j,j], T[j][j] = tau_j
@@ -345,10 +355,13 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_
       // W2 = -T^T (sum of the partials)
       {
         const int jc = tid & 63, i4 = tid >> 6;
-        if (jc < NP && jc >= (pnl + 1) * PW) {
+        if (i4 < 4 && jc < NP && jc >= (pnl + 1) * PW) {
           T ws[PW];
 #pragma unroll
-          for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc - PW] + Wp[1][k][jc - PW]) + (Wp[2][k][jc - PW] + Wp[3][k][jc - PW]);
+          for (int k = 0; k < PW; ++k) {
+            ws[k] = (Wp[0][k][jc - PW] + Wp[1][k][jc - PW]) + (Wp[2][k][jc - PW] + Wp[3][k][jc - PW]);
+            if constexpr (NW == 8) ws[k] += (Wp[4][k][jc - PW] + Wp[5][k][jc - PW]) + (Wp[6][k][jc - PW] + Wp[7][k][jc - PW]);
+          }
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii) {
             const int i = i4 * 4 + ii;
@@ -394,18 +407,20 @@ struct QrApply {
   int64_t ldtop, strideTop;
   T* Out;
   int64_t ldout, strideOut;
-  int pk, pI;    // > 0: level 0 of a PUSHED factorisation, local row (wave, kk) <-> global row kk * pI + 4b + wave
+  int pk, pI;    // > 0: level 0 of a PUSHED factorisation, local row (wave, kk) <-> global row kk * pI + NW*b + wave
 };
 
-template <typename T, int NT, int NTC>
-__global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
+template <typename T, int NT, int NTC, int NW>
+// (second launch bound = minimum waves per SIMD: 4 caps the fp32 kernel at 128 VGPRs, i.e. two 8-wave blocks per CU)
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void qr_apply_kernel(QrApply<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
   constexpr int NP = PW * NT;
   constexpr int NC = PW * NTC;
+  constexpr int BR = 64 * NW;
   __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];
   __shared__ T Ts[PW * VLD];   // compact-WY factor T of the current panel
-  __shared__ T Wp[4][PW][NC];
+  __shared__ T Wp[NW][PW][NC];
   __shared__ T W2s[PW][NC + 1];
 
   const int tid = threadIdx.x;
@@ -445,21 +460,21 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
       }
 
   const int npanels = (kb + PW - 1) / PW;
-  T vreg[PW], treg;
+  T vreg[PW], treg = T(0);
   if (npanels > 0) {
 #pragma unroll
     for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
-    treg = Tg[(npanels - 1) * PW * PW + tid];
+    if (tid < PW * PW) treg = Tg[(npanels - 1) * PW * PW + tid];
   }
   for (int pnl = npanels - 1; pnl >= 0; --pnl) {
     // stage the panel's reflectors ([row][j]) and its T factor; the next panel's loads fly under the MFMAs
 #pragma unroll
     for (int j = 0; j < PW; ++j) Vs[tid * VLD + j] = vreg[j];
-    Ts[(tid >> 4) * VLD + (tid & 15)] = treg;
+    if (tid < PW * PW) Ts[(tid >> 4) * VLD + (tid & 15)] = treg;
     if (pnl > 0) {
 #pragma unroll
       for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((pnl - 1) * PW + j) * BR + tid];
-      treg = Tg[(pnl - 1) * PW * PW + tid];
+      if (tid < PW * PW) treg = Tg[(pnl - 1) * PW * PW + tid];
     }
     lds_barrier();
     // W = V^T C (per-wave partial over its 64 rows)
@@ -477,10 +492,13 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
     // W2 = -T W
     {
       const int jc = tid & 63, i4 = tid >> 6;
-      if (jc < NC) {
+      if (i4 < 4 && jc < NC) {
         T ws[PW];
 #pragma unroll
-        for (int k = 0; k < PW; ++k) ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+        for (int k = 0; k < PW; ++k) {
+          ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+          if constexpr (NW == 8) ws[k] += (Wp[4][k][jc] + Wp[5][k][jc]) + (Wp[6][k][jc] + Wp[7][k][jc]);
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = i4 * 4 + ii;
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void qr_apply_kernel(QrApply<T> p) {
 
   if (p.pI > 0) {
     T* __restrict__ Out = p.Out + bt * p.strideOut;
-    const int imode = b * 4 + wave;
+    const int imode = b * NW + wave;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -536,12 +554,14 @@ struct QrPlan {
   int npad;  // 16 * NT
   int64_t m[16];
   int nb[16];
+  int nw[16];  // waves per block on this level (block rows = 64 * nw)
   // workspace offsets in elements
   int64_t off_vt[16], off_tau[16], off_tg[16], off_x[16], off_out[16];
   int64_t total;  // elements
 };
 
 static int nt_for(int64_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : 4); }
+static int nw_for(int64_t rows) { return rows > BR4 ? 8 : 4; }
 
 static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   QrPlan pl{};
@@ -551,7 +571,8 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   int L = 0;
   for (;;) {
     pl.m[L] = cur;
-    pl.nb[L] = (int)ceil_div(cur, BR);
+    pl.nw[L] = nw_for(cur);
+    pl.nb[L] = (int)ceil_div(cur, 64 * pl.nw[L]);
     ++L;
     if (pl.nb[L - 1] <= 1) break;
     cur = (int64_t)pl.nb[L - 1] * n;
@@ -559,7 +580,7 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   pl.levels = L;
   int64_t off = 0;
   for (int l = 0; l < L; ++l) {
-    pl.off_vt[l] = off; off += batch * pl.nb[l] * pl.npad * BR;
+    pl.off_vt[l] = off; off += batch * pl.nb[l] * pl.npad * 64 * pl.nw[l];
     pl.off_tau[l] = off; off += align_up(batch * pl.nb[l] * pl.npad, 64);
     pl.off_tg[l] = off; off += batch * pl.nb[l] * NT * PW * PW;
     if (l > 0) {
@@ -606,10 +627,14 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-    if (l == 0 && pu.Rm)
-      hipLaunchKernelGGL((qr_factor_kernel<T, NT, true>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
-    else
-      hipLaunchKernelGGL((qr_factor_kernel<T, NT, false>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0, stream, p);
+    const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
+    if (pl.nw[l] == 8) {
+      if (l == 0 && pu.Rm) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8>), grid, dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8>), grid, dim3(512), 0, stream, p);
+    } else {
+      if (l == 0 && pu.Rm) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 4>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 4>), grid, dim3(256), 0, stream, p);
+    }
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
@@ -631,8 +656,9 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     else { p.Out = wsw + pl.off_out[l]; p.ldout = kc; p.strideOut = pl.m[l] * n; }
     p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
-    hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC>), dim3((unsigned)pl.nb[l], (unsigned)batch), dim3(kThreads), 0,
-                       stream, p);
+    const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
+    if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 4>), grid, dim3(256), 0, stream, p);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
@@ -697,9 +723,10 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
   return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, stream);
 }
 
-// Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/4)
-// zero-padded blocks of 256 rows (one mode index per wave), so the plan is that of a (256*ceil(I/4)) x n matrix.
-static int64_t pushed_rows(int64_t I) { return 256 * ceil_div(I, 4); }
+// Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/NW)
+// zero-padded blocks of 64*NW rows (one mode index per wave), so the plan is that of a (64*NW*ceil(I/NW)) x n
+// matrix -- NW = 8 as soon as there are more than four mode indices (consistent with nw_for).
+static int64_t pushed_rows(int64_t I) { return I > 4 ? 512 * ceil_div(I, 8) : 256; }
 
 int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {
   return qr_workspace_bytes(dtype, pushed_rows(I), n, batch);
