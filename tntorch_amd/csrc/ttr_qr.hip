@@ -8,13 +8,13 @@
 // conventions), organised as a communication-avoiding TSQR whose blocks are factored with the
 // blocked compact-WY algorithm on the matrix cores:
 //
-//   block    256 rows x (16*NT) columns, one workgroup (4 wave64).  The block lives in REGISTERS as
-//            MFMA accumulator tiles: wave w owns rows 64w..64w+63 = 4 row tiles x NT column tiles of
-//            16x16 (v_mfma_*_16x16x4 C/D layout), 64 VGPRs for fp32.
-//   panel    16 columns at a time.  Inside a panel the 16 Householder steps are sequential but
-//            light: thread (segment, c) holds 16 rows of column c, so v^T a_c and the rank-1 update
-//            are 16 FMAs; the column norm is one redundant wave reduction; LDS carries the current
-//            column / reflector (256 values) and 16x16 partial dots.
+//   block    64*NW rows x (16*NT) columns, one workgroup of NW wave64 (NW = 8 above 256 rows, else 4).  The
+//            block lives in REGISTERS as MFMA accumulator tiles: wave w owns rows 64w..64w+63 = 4 row
+//            tiles x NT column tiles of 16x16 (v_mfma_*_16x16x4 C/D layout), 64 VGPRs for fp32.
+//   panel    16 columns at a time, factored in a COLUMN-OWNING layout: the panel is transposed through
+//            LDS so that wave w holds 16/NW whole columns (lane = row); the owner factors its columns
+//            locally (norm and dot products are wave-local DPP reductions, one round per step),
+//            publishes the reflectors, one LDS-only barrier, the waves to its right apply them.
 //   block    after a panel: S = V^T V (MFMA), the 16x16 triangular factor T (larft recurrence), then
 //   update   the trailing tiles get  A2 <- (I - V T^T V^T) A2  as three MFMA GEMMs
 //            W = V^T A2 (the accumulator registers ARE the B operand: K-step s of a row tile is
