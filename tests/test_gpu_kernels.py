@@ -319,6 +319,24 @@ def test_core_kron(dt):
         assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_qr_blocked_exact_dependence(dt):
+    """Exactly zero and exactly repeated column blocks (what block-diagonal TT sums produce): the panels' zero
+    remainders must not be completed with colliding unit vectors.  Square, wide and all-zero inputs."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(12)
+    base = torch.randn(1, 136, 40, generator=g, dtype=torch.float64)
+    A = torch.cat([base, torch.zeros(1, 136, 30, dtype=torch.float64), 0.5 * base, torch.zeros(1, 136, 26, dtype=torch.float64)], dim=2)
+    for X in (A, torch.cat([A, base[:, :, :14]], dim=2), torch.zeros(1, 136, 136, dtype=torch.float64), A[:, :100]):
+        X = X.to(dt)
+        Q, R = _hipops.qr(X.cuda())
+        Q, R = Q.cpu().double(), R.cpu().double()
+        k = min(X.shape[1], X.shape[2])
+        assert (Q.transpose(1, 2) @ Q - torch.eye(k, dtype=torch.float64)).abs().max() < tol(dt, 5e-5, 1e-11)
+        # (an all-zero input comes back with R at the perturbation floor, ~1e-15 in fp32, instead of exact zeros)
+        assert (Q @ R - X.double()).abs().max() <= tol(dt, 2e-5, 1e-12) * float(X.abs().max()) + 1e-13
+
+
 def test_unsupported_shapes_raise():
     h = _hip()
     with pytest.raises(NotImplementedError):

@@ -67,9 +67,23 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     pw = _hip.max_qr_cols(A.dtype)
     R = torch.zeros((Bt, n, n), dtype=A.dtype, device=A.device)
     Q = torch.empty((Bt, m, n), dtype=A.dtype, device=A.device)
+    # Exactly dependent / exactly zero columns (block-structured sums such as t + t have them) leave an exactly
+    # zero remainder after the projection; the Householder kernel then completes the panel with unit vectors
+    # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  Every panel therefore gets
+    # a perturbation at the rounding level of A (8 eps * rms(A), seeded, deterministic): zero remainders become
+    # generic directions, which the two projection passes make orthogonal to the finished Q; A = Q R still holds
+    # to O(eps ||A||).
+    rms = float(_hip.norm(A.reshape(1, -1))[0].item()) / math.sqrt(max(1, Bt * m * n))
+    delta = 8.0 * torch.finfo(A.dtype).eps * rms + 1e4 * math.sqrt(torch.finfo(A.dtype).tiny)  # (squares must not underflow)
+    gen = torch.Generator(device=A.device)
     for j0 in range(0, n, pw):
         j1 = min(j0 + pw, n)
+        w = j1 - j0
         W = A[:, :, j0:j1].contiguous()
+        gen.manual_seed(0x5EED + j0)
+        noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
+        eye = torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous()
+        _hip.gemm_axpby(noise, eye, W, delta, 1.0)             # W += delta * noise
         if j0 == 0:
             Qj, Rjj = _hip.qr(W)
         else:
