@@ -94,9 +94,51 @@ def stress_truncated_svd(seed):
                 assert (G - torch.eye(G.shape[0], dtype=torch.float64)).abs().max() < (1e-3 if dt == torch.float32 else 1e-8), (seed, alg, lo, m, n)
 
 
+def stress_cp(seed):
+    rng = np.random.RandomState(8000 + seed)
+    N = int(rng.randint(2, 6))
+    shape = [int(rng.randint(3, 12)) for _ in range(N)]
+    R = int(rng.randint(1, 6))
+    torch.manual_seed(seed)
+    fac = [torch.randn(i, R, dtype=torch.float64) for i in shape]
+    X = oracle.cp_to_dense(fac)
+    X = X / X.norm() + 10.0 ** rng.uniform(-4, -1) * torch.randn(shape, dtype=torch.float64) / math.sqrt(X.numel())
+    K = int(rng.randint(1, 8))
+    Rfit = max(1, min(R + int(rng.randint(-1, 2)), min(shape)))   # (R > I_n would draw random completion columns)
+    t = tn.Tensor(X, ranks_cp=Rfit, max_iter=K, tol=-1.0, device="cuda")
+    ref, errs = oracle.cp_als(X, Rfit, max_iter=K, tol=-1.0)
+    e_o = rel_diff(oracle.cp_to_dense([c.cpu() for c in t.cores]), X)
+    e_r = rel_diff(oracle.cp_to_dense(ref), X)
+    assert abs(e_o - e_r) <= 1e-6 + 1e-3 * e_r, (seed, shape, R, Rfit, K, e_o, e_r)
+    assert abs(t.cp_errors[-1] - e_o) <= 1e-6, (seed, "error estimate", t.cp_errors[-1], e_o)
+
+
+def stress_dense_batch(seed):
+    rng = np.random.RandomState(9000 + seed)
+    N = int(rng.randint(3, 6))
+    shape = [int(rng.randint(2, 10)) for _ in range(N)]
+    B = int(rng.choice([1, 2, 5, 130]))
+    dt = torch.float32 if seed % 2 else torch.float64
+    torch.manual_seed(seed)
+    X = torch.randn([B] + shape, dtype=torch.float64).to(dt)
+    r = int(rng.randint(1, 6))
+    t = tn.Tensor(X, ranks_tt=r, batch=True, device="cuda")
+    ref = oracle.dense_to_tt(X, r, batch=True)
+    assert ranks([c[0] for c in to_list(t.cores)]) == ranks([c[0] for c in ref]), (seed, "ranks")
+    for b in range(0, B, max(1, B // 4)):
+        e_o = rel_diff(oracle.tt_to_dense([c[b].cpu().double() for c in t.cores]), X[b])
+        e_r = rel_diff(oracle.tt_to_dense([c[b].double() for c in ref]), X[b])
+        assert abs(e_o - e_r) <= (3e-5 if dt == torch.float32 else 1e-9), (seed, B, b, e_o, e_r)
+    # Tucker rounding of the batch (rmax mode; small modes: the reference itself only supports I <= R R' here)
+    rk = int(rng.randint(1, 4))
+    t.round_tucker(rmax=rk)
+    assert max(t.ranks_tucker.tolist()) <= rk and torch.isfinite(t.torch()).all()
+
+
 fails = 0
 for name, fn, seeds in (("fp32 batch", stress_fp32_batch, range(40)), ("product", stress_product, range(40)),
-                        ("truncated_svd", stress_truncated_svd, range(60))):
+                        ("truncated_svd", stress_truncated_svd, range(60)),
+                        ("cp_als", stress_cp, range(40)), ("dense batch", stress_dense_batch, range(40))):
     for seed in seeds:
         try:
             fn(seed)
