@@ -135,10 +135,47 @@ def stress_dense_batch(seed):
     assert max(t.ranks_tucker.tolist()) <= rk and torch.isfinite(t.torch()).all()
 
 
+def stress_orthogonalize(seed):
+    rng = np.random.RandomState(10000 + seed)
+    N = int(rng.randint(2, 7))
+    shape = [int(rng.randint(1, 12)) for _ in range(N)]
+    rk = [1] + [int(rng.randint(1, 10)) for _ in range(N - 1)] + [1]
+    if N > 2 and seed % 4 == 0:
+        rk[int(rng.randint(1, N))] = int(rng.randint(65, 100))
+    dt = torch.float32 if seed % 2 else torch.float64
+    torch.manual_seed(seed)
+    cores = [torch.randn(rk[k], shape[k], rk[k + 1], dtype=torch.float64).to(dt) for k in range(N)]
+    X = dense(cores)
+    mu = int(rng.randint(0, N))
+    t = gpu(cores)
+    t.orthogonalize(mu)
+    tol_o = 1e-4 if dt == torch.float32 else 1e-10
+    assert rel_diff(t.torch().cpu(), X) <= (2e-5 if dt == torch.float32 else 1e-11), (seed, "tensor changed")
+    for k in range(N):
+        c = t.cores[k].cpu().double()
+        if k < mu:
+            M = c.reshape(-1, c.shape[-1]); G = M.T @ M
+        elif k > mu:
+            M = c.reshape(c.shape[0], -1); G = M @ M.T
+        else:
+            continue
+        assert (G - torch.eye(G.shape[0], dtype=torch.float64)).abs().max() < tol_o, (seed, N, shape, rk, mu, k)
+    # batched truncated_svd, both orientations
+    B, m, n = int(rng.randint(1, 6)), int(rng.randint(1, 90)), int(rng.randint(1, 120))
+    M = torch.randn(B, m, n, dtype=torch.float64).to(dt)
+    r = int(rng.randint(1, min(m, n) + 1))
+    for lo in (True, False):
+        L, R = tn.truncated_svd(M.cuda(), rmax=r, left_ortho=lo, batch=True)
+        Lr, Rr = oracle.truncated_svd(M, rmax=r, left_ortho=lo, batch=True)
+        e_o = rel_diff((L @ R).cpu(), M); e_r = rel_diff(Lr @ Rr, M)
+        assert L.shape == Lr.shape and abs(e_o - e_r) <= (3e-5 if dt == torch.float32 else 1e-10), (seed, lo, B, m, n, r, e_o, e_r)
+
+
 fails = 0
 for name, fn, seeds in (("fp32 batch", stress_fp32_batch, range(40)), ("product", stress_product, range(40)),
                         ("truncated_svd", stress_truncated_svd, range(60)),
-                        ("cp_als", stress_cp, range(40)), ("dense batch", stress_dense_batch, range(40))):
+                        ("cp_als", stress_cp, range(40)), ("dense batch", stress_dense_batch, range(40)),
+                        ("orthogonalize / batched truncated_svd", stress_orthogonalize, range(60))):
     for seed in seeds:
         try:
             fn(seed)
