@@ -21,7 +21,8 @@
 namespace ttr {
 
 constexpr int BK = 16;  // K step; 32 measured slower on every shape of the path (metric GEMMs 12.8 -> 17.1 ms/step); two LDS
-                        // stages with one barrier per step: 12.6 -> 13.2 ms/step (also measured, not kept)
+                        // stages with one barrier per step: 12.6 -> 13.2 ms/step; a K <= 64 variant staging the whole K extent at once
+                        // (one barrier, all loads in flight): 12.7 -> 17.5 ms/step -- occupancy matters more (all measured, not kept)
 constexpr int BKL = 4;  // log2(BK)
 // Tile shapes: every wave always owns a 32 x 32 block of C (2 x 2 MFMA tiles); the four waves are laid out
 // 2 x 2 (64 x 64 tile), 4 x 1 (128 x 32: products with <= 32 columns, e.g. X[I^3, I] @ A[I, R] of the MTTKRP or
