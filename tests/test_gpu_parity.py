@@ -584,6 +584,23 @@ def test_random_dense_and_tucker_vs_oracle(seed):
         assert sum(t3.ranks_tucker.tolist()) <= sum(c.shape[1] for c in c3) + (0 if alg == "svd" else N)
 
 
+def test_high_order_fp32_no_overflow():
+    """A 14-core fp32 train with ||X|| = 6e19: squared norms / Gram entries would overflow fp32 (the reference's LAPACK
+    rescales internally and stays finite); the device sweep takes exact powers of two out of the R factors."""
+    torch.manual_seed(0)
+    g = oracle.tt_randn([32] * 14, 24, dtype=torch.float32)
+    inp = oracle.tt_add(g, g)
+    t = gpu_tensor(inp)
+    t.round_tt(rmax=24)
+    assert all(torch.isfinite(c).all() for c in t.cores) and t.ranks_tt.tolist() == [1] + [24] * 13 + [1]
+    assert tt_rel_err(to_list(t.cores), inp) <= 6e-5
+    tb = gpu_tensor([torch.stack([c, 3 * c]) for c in inp], batch=True)     # per-item exponents in batch mode
+    tb.round_tt(rmax=24)
+    assert all(torch.isfinite(c).all() for c in tb.cores)
+    assert tt_rel_err([c[0] for c in to_list(tb.cores)], inp) <= 6e-5
+    assert tt_rel_err([c[1] for c in to_list(tb.cores)], [3 * c for c in inp]) <= 6e-5
+
+
 # ------------------------------------------------------------------ BASELINE-size configs
 def _metric_input(B, seed=0):
     """g+g with g = randn TT, shape [64]*8, rank 32, float32 (the metric's workload)."""

@@ -542,6 +542,7 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
     N = len(c)
     facs = []
     Rprev = None  # R factor still to be pushed into the current core
+    expo = None   # fp32: accumulated binary exponent taken out of the R factors (per batch item)
     for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
         Bt, r0, I, r1 = c[mu].shape
         rows_k = r0 if Rprev is None else Rprev.shape[1]
@@ -558,6 +559,15 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
             f = _hip.qr_factor(pushed.reshape(Bt, Rprev.shape[1] * I, r1))
         facs.append((f, rows_k, I))
         Rprev = f.R
+        if Rprev.dtype == torch.float32:
+            # ||R_mu|| is the norm of the partially contracted tensor and grows like (I r)^(mu/2): the squared
+            # column norms / Gram entries of a high-order train overflow fp32 (LAPACK rescales internally).  Every R
+            # is therefore brought back to O(1) by an exact power of two per batch item; the exponents are summed
+            # and returned to core 0 at the end, so the result is bit-identical whenever nothing overflowed.
+            e = torch.frexp(_hip.norm(Rprev.reshape(Bt, -1)))[1]
+            expo = e if expo is None else expo + e
+            s2 = torch.ldexp(torch.ones(Bt, dtype=Rprev.dtype, device=Rprev.device), -e)
+            Rprev = _hip.scale_cols(Rprev, s2[:, None].expand(Bt, Rprev.shape[2]).contiguous(), _hip.SCALE_MUL)
         c[mu] = None
     last = c[N - 1]
     c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
@@ -589,6 +599,9 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
         c[mu] = right.reshape(Bt, t.rank, I, rn)
         left = t.left_scaled()
     f, r0, I = facs[0]
+    if expo is not None:  # give the exponents back (exact); a norm beyond the fp32 range overflows here, as it must
+        back = torch.ldexp(torch.ones(left.shape[0], dtype=left.dtype, device=left.device), expo)
+        left = _hip.scale_cols(left, back[:, None].expand(left.shape[0], left.shape[2]).contiguous(), _hip.SCALE_MUL)
     dst = None
     if arena is not None:
         dst = arena.slice(0, chunk, (r0 * I, left.shape[2]))
