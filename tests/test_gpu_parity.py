@@ -584,6 +584,26 @@ def test_random_dense_and_tucker_vs_oracle(seed):
         assert sum(t3.ranks_tucker.tolist()) <= sum(c.shape[1] for c in c3) + (0 if alg == "svd" else N)
 
 
+@pytest.mark.parametrize("scales", [[1e15, 1e-15, 1e12, 1e-12, 1.0], [1.0, 1e-15, 1.0, 1.0, 1.0], [1e-15, 1.0, 1.0, 1.0, 1.0],
+                                    [1.0, 1.0, 1.0, 1.0, 1e-15], [1e15, 1.0, 1.0, 1.0, 1.0]])
+def test_fp32_badly_scaled_cores(scales):
+    """fp32 cores scaled by 1e+-15 (legitimate fp32 data): squares of their entries leave the fp32 range.  The QR
+    blocks are factored at the exponent of their largest entry and the sweep carries the R factors' exponents
+    separately; the reference (LAPACK) is fine here too."""
+    torch.manual_seed(0)
+    g = oracle.tt_randn([8, 9, 7, 8, 6], 5, dtype=torch.float32)
+    inp = [c * s for c, s in zip(oracle.tt_add(g, g), scales)]
+    X = dense(inp)
+    t = gpu_tensor(inp)
+    t.round_tt(rmax=5)
+    assert t.ranks_tt.tolist() == [1, 5, 5, 5, 5, 1]
+    e_r = rel_diff(dense(oracle.round_tt([c.clone() for c in inp], rmax=5)), X)
+    assert rel_diff(dense(to_list(t.cores)), X) <= max(5e-6, 3 * e_r)
+    u = gpu_tensor(inp)
+    u.orthogonalize(2)
+    assert rel_diff(dense(to_list(u.cores)), X) <= 5e-6
+
+
 def test_high_order_fp32_no_overflow():
     """A 14-core fp32 train with ||X|| = 6e19: squared norms / Gram entries would overflow fp32 (the reference's LAPACK
     rescales internally and stays finite); the device sweep takes exact powers of two out of the R factors."""

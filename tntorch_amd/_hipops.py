@@ -572,6 +572,13 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
     last = c[N - 1]
     c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
+    if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
+        Bt = c[N - 1].shape[0]
+        flat = c[N - 1].reshape(Bt, 1, -1)
+        e = torch.frexp(_hip.norm(flat.reshape(Bt, -1)))[1]
+        expo = expo + e
+        s2 = torch.ldexp(torch.ones(Bt, dtype=flat.dtype, device=flat.device), -e)
+        c[N - 1] = _hip.scale_cols(flat, s2[:, None].expand(Bt, flat.shape[2]).contiguous(), _hip.SCALE_MUL).reshape(c[N - 1].shape)
     if batch:  # tensor.py:2036-2037
         delta = None
     else:  # tensor.py:2039-2051

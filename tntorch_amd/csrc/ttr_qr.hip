@@ -164,6 +164,41 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
         }
   }
+  // fp32 range guard: the Householder steps square the entries (column norms, alpha^2 + ss); for blocks whose
+  // entries are near 1e19 or near 1e-19 -- legitimate fp32 data, e.g. one core of a train scaled by 1e-15 -- those
+  // squares overflow or fall into the denormal range (the fast sqrt / rcp then return 0 / inf: NaN).  The block is
+  // therefore scaled by the exact power of two of its largest entry for the factorisation and R is scaled back
+  // on output; reflectors and T factors are scale invariant, so nothing else changes (bit-identical in range).
+  int bexp = 0;
+  if constexpr (sizeof(T) == 4) {
+    T mx = T(0);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(acc[tm][tn][r]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) Ss[wave] = mx;
+    lds_barrier();
+    T bm = Ss[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bm = fmax(bm, Ss[w]);
+    lds_barrier();  // Ss is reused by the panels
+    if (bm > T(0) && bm < T(3e38)) {
+      (void)frexpf((float)bm, &bexp);
+      if (bexp > -8 && bexp < 8) bexp = 0;  // already O(1): leave the data alone
+    }
+    if (bexp != 0) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[tm][tn][r] = ldexpf((float)acc[tm][tn][r], -bexp);
+    }
+  }
   int dbgi = 0;
   auto stamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
   stamp();
@@ -296,7 +331,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
       for (int cc = 0; cc < CPW; ++cc) {
         const int c = j0 + wave_id * CPW + cc;
-        if (c < n && lane < rr) Ro[(int64_t)lane * p.ldr + c] = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
+        if (c < n && lane < rr) {
+          T rv = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
+          if constexpr (sizeof(T) == 4) { if (bexp != 0) rv = ldexpf((float)rv, bexp); }
+          Ro[(int64_t)lane * p.ldr + c] = rv;
+        }
       }
     }
     for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
