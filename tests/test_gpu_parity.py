@@ -604,6 +604,32 @@ def test_fp32_badly_scaled_cores(scales):
     assert rel_diff(dense(to_list(u.cores)), X) <= 5e-6
 
 
+@pytest.mark.parametrize("scale", [1e18, 1e-18])
+def test_fp32_out_of_range_inputs(scale):
+    """Dense tensors / matrices whose Gram matrices leave the fp32 range: dense -> TT, truncated_svd and
+    round_tucker take the binary exponent out first (the reference's LAPACK calls are scale safe)."""
+    torch.manual_seed(4)
+    low = oracle.tt_to_dense(oracle.tt_randn([10, 9, 8, 7], 3, dtype=torch.float64))
+    X = ((low / low.norm() + 1e-4 * torch.randn(low.shape, dtype=torch.float64) / math.sqrt(low.numel())) * scale).float()
+    # (references are run on the UNSCALED data: at 1e-18 the reference's absolute zero guard, round.py:137-145,
+    # returns zeros, and at 1e18 its float32 'svd' is simply scale safe)
+    Xu = (X.double() / scale).float()
+    t = tn.Tensor(X, ranks_tt=3, device="cuda")
+    ref = oracle.dense_to_tt(Xu, 3)
+    e_o, e_r = rel_diff(t.torch().cpu(), X), rel_diff(dense(ref), Xu)
+    assert math.isfinite(e_o) and abs(e_o - e_r) <= 1e-5
+    M = X.reshape(90, 56)
+    for lo in (True, False):
+        L, R = tn.truncated_svd(M.cuda(), eps=1e-3, left_ortho=lo)
+        Lr, Rr = oracle.truncated_svd(Xu.reshape(90, 56), eps=1e-3, left_ortho=lo)
+        assert L.shape == Lr.shape and rel_diff((L @ R).cpu(), M) <= 1e-3 * (1 + 1e-3)
+    # (reference on the UNSCALED train: at 1e-18 its absolute zero guard, round.py:137-145, would return zeros)
+    cr, Ur = oracle.round_tucker([c / (scale if k == 0 else 1.0) for k, c in enumerate(to_list(t.cores))], None, rmax=3)
+    t.round_tucker(rmax=3)
+    e_o, e_r = rel_diff(t.torch().cpu(), X), rel_diff(oracle.tucker_to_dense(cr, Ur), X / scale)
+    assert math.isfinite(e_o) and abs(e_o - e_r) <= 1e-4
+
+
 def test_high_order_fp32_no_overflow():
     """A 14-core fp32 train with ||X|| = 6e19: squared norms / Gram entries would overflow fp32 (the reference's LAPACK
     rescales internally and stays finite); the device sweep takes exact powers of two out of the R factors."""

@@ -354,8 +354,33 @@ def truncate(
     return Truncation(left, None, right, r)
 
 
+def _scale_batch(X: torch.Tensor, e: torch.Tensor, sign: int) -> torch.Tensor:
+    """X[b] * 2^(sign * e[b]) (exact) for a [B, ...] tensor."""
+    Bt = X.shape[0]
+    flat = X.reshape(Bt, 1, -1)
+    s2 = torch.ldexp(torch.ones(Bt, dtype=X.dtype, device=X.device), sign * e)
+    return _hip.scale_cols(flat, s2[:, None].expand(Bt, flat.shape[2]).contiguous(), _hip.SCALE_MUL).reshape(X.shape)
+
+
+def _range_guard(X: torch.Tensor):
+    """fp32 only: binary exponents (per batch item) to take out of ``X`` before Gram matrices are formed from it,
+    or None when every item lies within 2^+-40 (squares far from the fp32 range limits).  The rounding sweep
+    normalises its own operands; this is for the entries that receive user data directly."""
+    if X.dtype != torch.float32:
+        return None
+    e = torch.frexp(_hip.norm(X.reshape(X.shape[0], -1)))[1]
+    if int(e.abs().max().item()) < 40:
+        return None
+    return e
+
+
 def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
     """round.py:52-187 on a [B, m, n] device tensor -> (left [B, m, r], M2 [B, r, n])."""
+    e = _range_guard(M3)
+    if e is not None:  # out-of-range fp32 scale: work on M 2^-e, give the exponent back to the non-orthonormal factor
+        M3 = _scale_batch(M3, e, -1)
+        if delta is not None:
+            delta = delta * 2.0 ** (-int(e.max().item()))  # (absolute bound: only meaningful for a single matrix)
     if delta is None and eps is not None:  # round.py:79-80
         delta = eps * float(_hip.norm(M3.reshape(1, -1))[0].item())
     if delta is None:
@@ -364,7 +389,13 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
     left = t.left_scaled()
     if not left.is_contiguous():
         left = left.contiguous()
-    return left, t.right
+    right = t.right
+    if e is not None:
+        if left_ortho:
+            right = _scale_batch(right, e, +1)
+        else:
+            left = _scale_batch(left, e, +1)
+    return left, right
 
 
 # ----------------------------------------------------------------------------------------------
@@ -697,6 +728,11 @@ def dense_tt_svd(
     else:
         nrm = float(_hip.norm(X.reshape(1, -1))[0].item())
         delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
+    e = _range_guard(X)
+    if e is not None:  # ||X|| outside 2^+-40 in fp32: every bond's Gram matrix would leave the range
+        X = _scale_batch(X, e, -1)
+        if delta is not None:
+            delta = delta * 2.0 ** (-int(e[0].item()))
     cores: List[Optional[torch.Tensor]] = [None] * N
     C = X.reshape(Bt, -1, shape[-1])
     rn = 1
@@ -706,6 +742,8 @@ def dense_tt_svd(
         cores[kdim] = t.right.reshape(Bt, t.rank, shape[kdim], rn)
         C = t.left_scaled()
         rn = t.rank
+    if e is not None:
+        C = _scale_batch(C, e, +1)
     cores[0] = C.reshape(Bt, 1, shape[0], rn).contiguous()
     return cores  # type: ignore[return-value]
 
