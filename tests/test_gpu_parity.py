@@ -281,6 +281,9 @@ def test_quirks():
     # rmax list length is checked (tensor.py:2029)
     with pytest.raises(AssertionError):
         tn.Tensor(held).round_tt(rmax=[2, 2])
+    # the kernels are not differentiable: refuse instead of silently cutting the graph
+    with pytest.raises(NotImplementedError):
+        tn.Tensor([c.clone().requires_grad_() for c in held]).round_tt(rmax=2)
 
 
 # ------------------------------------------------------------------ consumers on the device

@@ -183,6 +183,10 @@ class Tensor(object):
     def _norm4(self) -> List[torch.Tensor]:
         """Cores as [B, r0, I, r1] views (B = 1 for non-batch tensors); CP factors [I, R] become TT cores whose
         slices are diagonal (tensor.py:1717-1769: first [1, I, R], last [R, I, 1], middle [R, I, R])."""
+        if any(c.is_cuda and c.requires_grad for c in self.cores):
+            raise NotImplementedError(
+                "tntorch_amd: the HIP kernels are not differentiable (autograd would silently see constants); "
+                "detach the cores or run the rounding on CPU tensors")
         cs = list(self.cores) if self.batch else [c[None] for c in self.cores]
         N = len(cs)
         out = []
