@@ -16,6 +16,8 @@ def ops_for(t: torch.Tensor):
         return _hostops
     if t.device.type != "cuda":
         raise RuntimeError(f"tntorch_amd: unsupported device {t.device}")
+    if t.requires_grad:
+        raise NotImplementedError("tntorch_amd: the HIP kernels are not differentiable; detach the tensor or use CPU tensors")
     from . import _hip, _hipops
 
     _hip.lib()  # raises RuntimeError if libttround_hip.so has not been built
