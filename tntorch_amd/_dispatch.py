@@ -16,7 +16,7 @@ def ops_for(t: torch.Tensor):
         return _hostops
     if t.device.type != "cuda":
         raise RuntimeError(f"tntorch_amd: unsupported device {t.device}")
-    if t.requires_grad:
+    if getattr(t, "requires_grad", False):
         raise NotImplementedError("tntorch_amd: the HIP kernels are not differentiable; detach the tensor or use CPU tensors")
     from . import _hip, _hipops
 
