@@ -83,3 +83,22 @@ def test_pack_unpack_roundtrip():
     flat = pack_cores(cores)
     back = unpack_cores(flat, [c.shape for c in cores])
     assert all(torch.equal(a, b) for a, b in zip(cores, back))
+
+
+def test_pack_cores_zero_copy_when_back_to_back():
+    """Cores that already lie back to back in one storage (how the device round_tt lays out a large batch) are
+    packed as a view; anything else is concatenated."""
+    from tntorch_amd.dist_batch import pack_cores
+
+    flat = torch.arange(100.0)
+    cores = [flat[0:24].view(2, 3, 2, 2), flat[24:60].view(2, 2, 3, 3), flat[60:100].view(2, 5, 2, 2)]
+    p = pack_cores(cores)
+    assert p.data_ptr() == flat.data_ptr() and torch.equal(p, flat)
+    off = torch.arange(120.0)
+    cores = [off[10:34].view(2, 3, 2, 2), off[34:70].view(2, 2, 3, 3)]
+    p = pack_cores(cores)
+    assert p.data_ptr() == off[10:].data_ptr() and torch.equal(p, off[10:70])
+    q = pack_cores([c.clone() for c in cores])                  # separate storages: copy
+    assert q.data_ptr() != off[10:].data_ptr() and torch.equal(q, off[10:70])
+    gap = [off[10:34].view(2, 3, 2, 2), off[40:76].view(2, 2, 3, 3)]  # same storage, not adjacent: copy
+    assert torch.equal(pack_cores(gap), torch.cat([off[10:34], off[40:76]]))
