@@ -911,3 +911,10 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
 def core_kron(a4: torch.Tensor, b4: torch.Tensor) -> torch.Tensor:
     """tensor.py:2309-2320 ``_core_kron`` on [B, r, I, r'] cores."""
     return _hip.core_kron(a4, b4)
+
+
+def scale(x: torch.Tensor, value: float) -> torch.Tensor:
+    """x * value for a device tensor of any shape (ttr_scale_cols with a constant column scale)."""
+    flat = x.reshape(1, 1, -1)
+    sv = torch.full((1, flat.shape[2]), float(value), dtype=x.dtype, device=x.device)
+    return _hip.scale_cols(flat.contiguous(), sv, _hip.SCALE_MUL).reshape(x.shape)

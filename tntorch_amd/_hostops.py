@@ -321,3 +321,7 @@ def core_kron(a4: torch.Tensor, b4: torch.Tensor) -> torch.Tensor:
     """tensor.py:2309-2320 ``_core_kron`` (batch form) on [B, r, I, r'] cores."""
     c = a4[:, :, None, :, :, None] * b4[:, None, :, :, None, :]
     return c.reshape([a4.shape[0], a4.shape[1] * b4.shape[1], -1, a4.shape[-1] * b4.shape[-1]])
+
+
+def scale(x: torch.Tensor, value) -> torch.Tensor:
+    return x * value

@@ -8,6 +8,7 @@ in order, so a seeded call reproduces the reference's cores exactly.
 
 import torch
 
+from ._dispatch import ops_for
 from .tensor import Tensor
 
 __all__ = ["rand", "randn", "rand_like", "randn_like", "ones", "zeros", "full"]
@@ -60,7 +61,7 @@ def full(shape, fill_value, device=None, batch=False, dtype=None):
     spatial = shape[1:] if batch else shape
     lead = [shape[0]] if batch else []
     cores = [torch.ones(lead + [1, s, 1], device=device, dtype=dtype) for s in spatial]
-    cores[0] = cores[0] * fill_value
+    cores[0] = ops_for(cores[0]).scale(cores[0], fill_value)
     return Tensor(cores, batch=batch)
 
 

@@ -301,7 +301,7 @@ class Tensor(object):
         c0 = self.cores[0]
         lead = (c0.shape[0],) if self.batch else ()
         cores = [torch.ones(lead + (1, c.shape[-2], 1), dtype=c0.dtype, device=c0.device) for c in self.cores]
-        cores[0] = cores[0] * value
+        cores[0] = ops_for(cores[0]).scale(cores[0], value)
         return Tensor(cores, batch=self.batch)
 
     def __add__(self, other):
@@ -353,7 +353,7 @@ class Tensor(object):
             ops = ops_for(ca[0])
             return Tensor(self._denorm([ops.core_kron(a, b) for a, b in zip(ca, cb)]), batch=self.batch)
         cores = [c.clone() for c in self.cores]
-        cores[0] = cores[0] * other
+        cores[0] = ops_for(cores[0]).scale(cores[0], other)
         return Tensor(cores, Us=[None if U is None else U.clone() for U in self.Us], batch=self.batch)
 
     def __rmul__(self, other):
