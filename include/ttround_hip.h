@@ -162,12 +162,21 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
  * accurate to eps*||G||).  abs_floor = 2 selects, for n <= 64, the tridiagonal solver instead (Householder
  * reduction + implicit-shift QL, one wave per matrix, absolute accuracy O(eps*||G||) like LAPACK steqr):
  * ~10x fewer flops, used for the first pass / 'eig'; larger n falls back to Jacobi with abs_floor = 1.
+ * abs_floor = TTR_SOLVER_JACOBI_LIVE (pass 2 of the two-pass 'svd' truncation): purely relative rotation test among
+ * the LIVE indices; indices with G_ii <= (n eps)^2 max G_ii (the numerical null space of the input) are frozen.  Every
+ * live direction gets the accuracy of a backward-stable SVD (LAPACK gesdd class, round.py:96) whatever its sigma.
  * `sweeps` (optional, [batch]) receives the number of sweeps (Jacobi) / QL iterations used.
  * eig_mode = TTR_EIG_MATCH_DIAG: see above (sigma[b] then follows V's column order; info as usual).
+ * The input may be given as `gparts` partial matrices (split-K partials of a Gram kernel, `stride_gpart` elements
+ * apart): G[b] = sum_p G[b * strideG + p * stride_gpart + ...]; gparts = 1 for a plain matrix.
  */
+#define TTR_SOLVER_JACOBI_REL 0
+#define TTR_SOLVER_JACOBI_ABS 1
+#define TTR_SOLVER_TRIDIAG 2
+#define TTR_SOLVER_JACOBI_LIVE 3
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
-                   const void* G, int64_t ldg, int64_t strideG,
+                   const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
                    void* V, int64_t ldv, int64_t strideV,
                    void* sigma, int64_t stride_sigma,
                    int32_t* info,
@@ -213,6 +222,37 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
                    const void* s, int64_t stride_s, int mode,
                    void* out, int64_t ldo, int64_t stride_out, void* stream);
 
+/*
+ * Exact power-of-two normalisation, one launch: e[b] = binary exponent of ||x[b]|| (0 for a zero / non-finite norm),
+ * out[b] = x[b] * 2^-e[b], and, when `expo_acc` is given, expo_acc[b] += e[b].  (`out` may alias `x`; out = NULL:
+ * exponents only.)
+ * Replaces the LAPACK-internal rescaling the reference relies on (torch.linalg.qr / svd are scale safe,
+ * tensor.py:1816, round.py:96): the fp32 sweep keeps every R factor at O(1) and returns the summed exponent to core 0.
+ */
+int ttr_pow2_normalize(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x,
+                       void* out, int64_t stride_out, int32_t* e_out, int32_t* expo_acc, void* stream);
+
+/*
+ * out[b][i] = x[b][i] * scale[b * stride_scale] * 2^(expo_sign * expo[b])   (scale and/or expo may be NULL;
+ * stride_scale = 0 broadcasts one scalar).  Replaces scalar multiplications of cores (tensor.py:687-773 with a
+ * scalar operand) and gives the exponents of ttr_pow2_normalize back.
+ */
+int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x,
+                    const void* scale, int64_t stride_scale, const int32_t* expo, int expo_sign,
+                    void* out, int64_t stride_out, void* stream);
+
+/*
+ * Orthonormal completion of the numerically null directions a truncation keeps.  X[b] holds `r` vectors of length `n`
+ * (vector i, element k at X[b * strideX + i * vec_stride + k * elem_stride]); sigma[b] are the singular values,
+ * decreasing.  Vectors i < r with sigma_i <= dead_rel * sigma_0 carry rounding noise only (their sigma is below the
+ * resolution of the input): they are re-orthogonalised against all previous vectors (modified Gram-Schmidt, twice;
+ * a vector that vanishes is replaced by a hashed pseudo-random one) and normalised, so that the factor is orthonormal
+ * to working accuracy like the V of a LAPACK SVD (round.py:96), while the product left * right changes by
+ * O(dead_rel * sigma_0) only.  Items without such vectors exit immediately (the normal case).
+ */
+int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
+                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, void* stream);
+
 /* Per-kernel device timing (HIP events on `stream`), used by bench.py for the roofline line. */
 #define TTR_PROF_GEMM 0
 #define TTR_PROF_QR_FACTOR 1
@@ -223,6 +263,11 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
 /* Diagnostics: when set to a device buffer of >= 64 int64, block (0,0) of every level-0 QR factor launch writes
  * its s_memtime stamps at phase boundaries there.  NULL disables. */
 int ttr_debug_set_qr_stamps(void* device_buffer);
+/* Diagnostics / A-B measurements: select kernel variants at run time (process-wide, not thread safe).
+ *   TTR_KNOB_QR_PANEL  0 = panels factored in the column-owning layout (round 1), 1 = row-layout panels with
+ *                      ds_bpermute shuffles, 2 = row-layout panels with DPP row_newbcast / v_permlane swaps (default). */
+#define TTR_KNOB_QR_PANEL 0
+int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */
 int ttr_prof_collect(double* ms, int64_t* launches);

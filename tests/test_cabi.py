@@ -47,7 +47,9 @@ def test_host_only_entry_points(lib):
     lib.ttr_qr_workspace_bytes.restype = ctypes.c_int64
     lib.ttr_qr_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     w1 = lib.ttr_qr_workspace_bytes(0, 4096, 64, 1)
-    assert w1 >= 4096 * 64 * 4 and lib.ttr_qr_workspace_bytes(0, 4096, 64, 8) == 8 * w1 or True
+    assert w1 >= 4096 * 64 * 4
+    w8 = lib.ttr_qr_workspace_bytes(0, 4096, 64, 8)
+    assert 8 * w1 - 8 * 64 * 4 * 4 <= w8 <= 8 * w1  # per-level tau arrays are padded to 64 elements per level, not per item
     assert lib.ttr_qr_workspace_bytes(1, 4096, 64, 1) == 2 * w1
     # argument validation happens before any HIP call
     lib.ttr_qr.restype = ctypes.c_int

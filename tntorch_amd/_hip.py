@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libttround_hip.so")
 F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
-SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG = 0, 1, 2  # `abs_floor` argument of ttr_eigh_trunc
+SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
 PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc")
 
 _lib = None
@@ -80,8 +80,17 @@ _SIGNATURES = {
     "ttr_eigh_trunc": (
         c_int,
         [c_int, c_int64, c_int64,
-         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
          c_int, c_int, c_double, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_pow2_normalize": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ttr_scale_batch": (
+        c_int,
+        [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_orth_fixup": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p],
     ),
     "ttr_norm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_scale_cols": (
@@ -93,6 +102,7 @@ _SIGNATURES = {
     "ttr_hadamard": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_core_kron": (c_int, [c_int] + [c_int64] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_debug_set_qr_stamps": (c_int, [c_void_p]),
+    "ttr_debug_set_knob": (c_int, [c_int, c_int]),
     "ttr_prof_enable": (c_int, [c_int]),
     "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
 }
@@ -145,6 +155,35 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _first_cuda_tensor(args, kwargs):
+    for a in args:
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a
+        if isinstance(a, QrFactors):
+            return a.ws
+    for a in kwargs.values():
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a
+    return None
+
+
+def _on_device(fn):
+    """Run a binding with the device of its first device operand current: workspaces / results are allocated there
+    and ``_stream()`` is that device's current stream (a tensor on cuda:1 while cuda:0 is current would otherwise be
+    processed on cuda:0's stream -- a cross-device launch, unordered against torch's work on cuda:1)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        t = _first_cuda_tensor(args, kwargs)
+        if t is None or t.device.index is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+
+    return wrapped
+
+
 def _mat(t: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
     """Return (tensor, ld, batch_stride) of a [B, r, c] tensor whose rows are contiguous."""
     assert t.dim() == 3 and t.is_cuda
@@ -166,6 +205,7 @@ def max_eigh_n(dt: torch.dtype = torch.float32) -> int:
 
 
 # ----------------------------------------------------------------------------------------------
+@_on_device
 def gemm(
     A: torch.Tensor,
     B: torch.Tensor,
@@ -217,6 +257,7 @@ def gemm(
     return C
 
 
+@_on_device
 def gemm_axpby(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, alpha: float, beta: float,
                transA: bool = False, transB: bool = False) -> torch.Tensor:
     """In place: C[b] <- beta * C[b] + alpha * op(A[b]) @ op(B[b]); C must be contiguous [batch, M, N]."""
@@ -244,6 +285,7 @@ def gemm_axpby(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, alpha: float, 
     return C
 
 
+@_on_device
 def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Reduced Householder QR of [batch, m, n] -> Q [batch, m, k], R [batch, k, n]."""
     L = lib()
@@ -277,6 +319,7 @@ class QrFactors:
         return min(self.m, self.n)
 
 
+@_on_device
 def qr_factor(A: torch.Tensor) -> QrFactors:
     """Factor [batch, m, n]; returns a handle holding R [batch, k, n] and the implicit Q."""
     L = lib()
@@ -297,6 +340,7 @@ def pushed_supported(k: int, Rin: int, I: int, n: int, dt: torch.dtype) -> bool:
     return k <= 64 and Rin <= 64 and n <= max_qr_cols(dt) and k * I >= n
 
 
+@_on_device
 def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
     """Factor the left unfolding of ``Rm @ core`` (Rm [batch, k, Rin], core [batch, Rin, I, n]) without forming it."""
     L = lib()
@@ -317,6 +361,7 @@ def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
     return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I))
 
 
+@_on_device
 def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q).
@@ -350,16 +395,24 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
     return Out
 
 
+@_on_device
 def eigh_trunc(
     G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: int = 1,
     sweeps: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
-    decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard)."""
+    decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard).
+    ``G`` may also be [batch, parts, n, n] (contiguous): split-K partials of a Gram kernel, summed on load."""
     L = lib()
     dt = dtype_code(G.dtype)
-    G, ldg, sG = _mat(G)
-    batch, n, _ = G.shape
+    gparts, sGp = 1, 0
+    if G.dim() == 4:
+        G = G.contiguous()
+        batch, gparts, n, _ = G.shape
+        ldg, sG, sGp = n, gparts * n * n, n * n
+    else:
+        G, ldg, sG = _mat(G)
+        batch, n, _ = G.shape
     V = torch.empty((batch, n, n), dtype=G.dtype, device=G.device)
     sigma = torch.empty((batch, n), dtype=G.dtype, device=G.device)
     info = torch.empty((batch,), dtype=torch.int32, device=G.device)
@@ -369,7 +422,7 @@ def eigh_trunc(
     ws = torch.empty(wsb, dtype=torch.uint8, device=G.device) if wsb > 0 else None
     rmax = int(min(max(int(rmax), 1), 2**31 - 1))
     code = L.ttr_eigh_trunc(
-        dt, n, batch, G.data_ptr(), ldg, sG, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
+        dt, n, batch, G.data_ptr(), ldg, sG, gparts, sGp, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
         eig_mode, int(bool(use_delta)), float(delta2), rmax, int(abs_floor),
         sweeps.data_ptr() if sweeps is not None else None,
         ws.data_ptr() if ws is not None else None, wsb, _stream(),
@@ -378,6 +431,7 @@ def eigh_trunc(
     return V, sigma, info
 
 
+@_on_device
 def norm(x: torch.Tensor) -> torch.Tensor:
     """Frobenius norm per batch item of a [batch, ...] tensor -> [batch]."""
     L = lib()
@@ -401,6 +455,7 @@ def norm(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
     """out[b, i, j] = X[b, i, j] * s[b, j] (SCALE_MUL) or / s[b, j] (SCALE_DIV)."""
     L = lib()
@@ -417,6 +472,73 @@ def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
     return out
 
 
+@_on_device
+def pow2_normalize(x: torch.Tensor, expo_acc: Optional[torch.Tensor] = None, exponent_only: bool = False):
+    """[batch, ...] -> (x * 2^-e per batch item, e int32 [batch]) with e the binary exponent of ||x[b]||;
+    ``expo_acc`` (int32 [batch]) is incremented by e in place.  ``exponent_only``: returns (None, e), x is only read."""
+    L = lib()
+    dt = dtype_code(x.dtype)
+    x = x.contiguous()
+    batch = x.shape[0]
+    count = x[0].numel() if batch > 0 else 0
+    out = None if exponent_only else torch.empty_like(x)
+    e = torch.zeros((batch,), dtype=torch.int32, device=x.device)
+    if batch == 0:
+        return out, e
+    _check(L.ttr_pow2_normalize(dt, count, batch, x.data_ptr(), count, out.data_ptr() if out is not None else None, count,
+                                e.data_ptr(), expo_acc.data_ptr() if expo_acc is not None else None, _stream()),
+           "ttr_pow2_normalize")
+    return out, e
+
+
+@_on_device
+def scale_batch(x: torch.Tensor, scale=None, expo: Optional[torch.Tensor] = None, expo_sign: int = 1) -> torch.Tensor:
+    """out[b] = x[b] * scale[b] * 2^(expo_sign * expo[b]) for a [batch, ...] tensor.  ``scale``: None, a python
+    number (one scalar for the whole batch) or a [batch] tensor; ``expo``: None or int32 [batch]."""
+    L = lib()
+    dt = dtype_code(x.dtype)
+    x = x.contiguous()
+    batch = x.shape[0]
+    count = x[0].numel() if batch > 0 else 0
+    out = torch.empty_like(x)
+    if batch == 0 or count == 0:
+        return out
+    sp, ss = None, 0
+    if scale is not None:
+        if not isinstance(scale, torch.Tensor):
+            scale = torch.full((1,), float(scale), dtype=x.dtype, device=x.device)  # (a fill, not arithmetic)
+            ss = 0
+        else:
+            scale = scale.to(x.dtype).contiguous()
+            ss = 1
+        sp = scale.data_ptr()
+    _check(L.ttr_scale_batch(dt, count, batch, x.data_ptr(), count, sp, ss,
+                             expo.data_ptr() if expo is not None else None, int(expo_sign),
+                             out.data_ptr(), count, _stream()), "ttr_scale_batch")
+    return out
+
+
+@_on_device
+def orth_fixup(X: torch.Tensor, sigma: torch.Tensor, r: int, dead_rel: float, columns: bool = False) -> None:
+    """In place: orthonormal completion of the kept vectors whose sigma <= dead_rel * sigma_max (ttr_orth_fixup).
+    ``X``: contiguous [batch, r, n] (rows are the vectors) or, with ``columns=True``, [batch, n, r]."""
+    L = lib()
+    dt = dtype_code(X.dtype)
+    assert X.is_contiguous() and X.dim() == 3 and sigma.is_contiguous()
+    batch = X.shape[0]
+    if columns:
+        n, vs, es = X.shape[1], 1, X.shape[2]
+        assert X.shape[2] == r
+    else:
+        n, vs, es = X.shape[2], X.shape[2], 1
+        assert X.shape[1] == r
+    if batch == 0 or r == 0 or n == 0:
+        return
+    _check(L.ttr_orth_fixup(dt, r, n, batch, X.data_ptr(), vs, es, X.shape[1] * X.shape[2], sigma.data_ptr(),
+                            sigma.shape[-1], float(dead_rel), _stream()), "ttr_orth_fixup")
+
+
+@_on_device
 def krp_contract(T: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """out[p, q, r] = sum_j T[p, j, q, r] * B[j, r] for contiguous T [P, J, Q, R], B [J, R]."""
     L = lib()
@@ -432,6 +554,7 @@ def krp_contract(T: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def hadamard(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     L = lib()
     dt = dtype_code(a.dtype)
@@ -442,6 +565,7 @@ def hadamard(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def core_kron(a: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     """[B, R1, I, R2] (x) [B, S1, I, S2] -> [B, R1*S1, I, R2*S2] (slice-wise Kronecker product)."""
     L = lib()
@@ -453,6 +577,14 @@ def core_kron(a: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     out = torch.empty((B, R1 * S1, I, R2 * S2), dtype=a.dtype, device=a.device)
     _check(L.ttr_core_kron(dt, B, R1, S1, I, R2, S2, a.data_ptr(), c.data_ptr(), out.data_ptr(), _stream()), "ttr_core_kron")
     return out
+
+
+KNOB_QR_PANEL = 0
+
+
+def set_knob(knob: int, value: int):
+    """Diagnostics: select a kernel variant (see ttr_debug_set_knob in the header)."""
+    _check(lib().ttr_debug_set_knob(int(knob), int(value)), "ttr_debug_set_knob")
 
 
 def prof_enable(on: bool):

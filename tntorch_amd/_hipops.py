@@ -1,8 +1,9 @@
 """Device-side (HIP) implementation of the TT sweeps: orchestration of the C-ABI kernels.
 
 Everything here works on batch-normalised tensors (``[B, ...]``; the non-batch API adds
-a leading 1).  Arithmetic is done exclusively by ``libttround_hip.so``; torch only
-allocates, reshapes, slices and copies.
+a leading 1).  Arithmetic on tensor data is done by ``libttround_hip.so``; torch allocates, reshapes,
+slices, copies and fills (identity / zero blocks, seeded noise for the blocked QR), and reads back the
+few scalars that steer control flow (ranks in eps mode, convergence flags of the block-Jacobi driver).
 
 Algorithms (reference call sites in brackets):
 
@@ -70,11 +71,13 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     # Exactly dependent / exactly zero columns (block-structured sums such as t + t have them) leave an exactly
     # zero remainder after the projection; the Householder kernel then completes the panel with unit vectors
     # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  Every panel therefore gets
-    # a perturbation at the rounding level of A (8 eps * rms(A), seeded, deterministic): zero remainders become
-    # generic directions, which the two projection passes make orthogonal to the finished Q; A = Q R still holds
-    # to O(eps ||A||).
-    rms = float(_hip.norm(A.reshape(1, -1))[0].item()) / math.sqrt(max(1, Bt * m * n))
-    delta = 8.0 * torch.finfo(A.dtype).eps * rms + 1e4 * math.sqrt(torch.finfo(A.dtype).tiny)  # (squares must not underflow)
+    # a perturbation at the rounding level of its OWN batch item (8 eps * rms(A[b]), seeded, deterministic): zero
+    # remainders become generic directions, which the two projection passes make orthogonal to the finished Q;
+    # A = Q R still holds to O(eps ||A[b]||).  Per item: every item is first brought to ||A[b]|| in [0.5, 1) by an
+    # exact power of two (ttr_pow2_normalize; given back to R at the end), so one delta serves the whole batch and
+    # an item 1e-6 times smaller than its neighbours is not swamped by their noise level.
+    A, a_exp = _hip.pow2_normalize(A)
+    delta = 8.0 * torch.finfo(A.dtype).eps / math.sqrt(max(1, m * n))
     gen = torch.Generator(device=A.device)
     for j0 in range(0, n, pw):
         j1 = min(j0 + pw, n)
@@ -99,7 +102,7 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
             R[:, :j0, j0:j1] = C1
         Q[:, :, j0:j1] = Qj
         R[:, j0:j1, j0:j1] = Rjj
-    return Q, R
+    return Q, _hip.scale_batch(R, expo=a_exp, expo_sign=+1)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -321,7 +324,11 @@ def truncate(
     # pass 2 of 'svd': graded, accurately formed Gram matrix -> Jacobi (relative accuracy of the small sigmas)
     # (problems above the LDS limit go through the block-Jacobi driver in either pass: absolute accuracy)
     V, sig, info = _eigh_any(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
-                             _hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_ABS)
+                             _hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_LIVE)
+    # 'svd': kept directions whose sigma lies below the resolution of the input (k eps sigma_max) carry rounding
+    # noise only; LAPACK's V is orthonormal there too (round.py:96), so they get an orthonormal completion
+    # (ttr_orth_fixup; a per-item early exit when there are none -- the normal case)
+    dead_rel = k * torch.finfo(M.dtype).eps if algorithm == "svd" else None
     r = _select_rank(info, batch, rmax, k)
     if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
         z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)
@@ -336,11 +343,15 @@ def truncate(
             right = _hip.gemm(Vr, Mw, transA=True, out=dst)
         else:
             right = _hip.gemm(Vr, Mw, transA=True, rowscale=sig, rowscale_mode=_hip.SCALE_DIV, out=dst)
+            if dead_rel is not None:
+                _hip.orth_fixup(right, sig, r, dead_rel)
         U = _hip.gemm(V1, Vr) if V1 is not None else Vr
         return Truncation(U, None if left_ortho else sig, right, r)
     # right side: left = Mw Vr (= U sigma); right = (V1 Vr)^T
     if left_ortho:
         left = _hip.gemm(Mw, Vr, colscale=sig, colscale_mode=_hip.SCALE_DIV)
+        if dead_rel is not None:
+            _hip.orth_fixup(left, sig, r, dead_rel, columns=True)
         if V1 is not None:
             right = _hip.gemm(Vr, V1, transA=True, transB=True, rowscale=sig, rowscale_mode=_hip.SCALE_MUL)
         else:
@@ -355,11 +366,8 @@ def truncate(
 
 
 def _scale_batch(X: torch.Tensor, e: torch.Tensor, sign: int) -> torch.Tensor:
-    """X[b] * 2^(sign * e[b]) (exact) for a [B, ...] tensor."""
-    Bt = X.shape[0]
-    flat = X.reshape(Bt, 1, -1)
-    s2 = torch.ldexp(torch.ones(Bt, dtype=X.dtype, device=X.device), sign * e)
-    return _hip.scale_cols(flat, s2[:, None].expand(Bt, flat.shape[2]).contiguous(), _hip.SCALE_MUL).reshape(X.shape)
+    """X[b] * 2^(sign * e[b]) (exact) for a [B, ...] tensor (ttr_scale_batch)."""
+    return _hip.scale_batch(X, expo=e, expo_sign=sign)
 
 
 def _range_guard(X: torch.Tensor):
@@ -368,8 +376,8 @@ def _range_guard(X: torch.Tensor):
     normalises its own operands; this is for the entries that receive user data directly."""
     if X.dtype != torch.float32:
         return None
-    e = torch.frexp(_hip.norm(X.reshape(X.shape[0], -1)))[1]
-    if int(e.abs().max().item()) < 40:
+    _, e = _hip.pow2_normalize(X, exponent_only=True)
+    if int(e.abs().max().item()) < 40:  # (readback: control flow only)
         return None
     return e
 
@@ -593,23 +601,18 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
         if Rprev.dtype == torch.float32:
             # ||R_mu|| is the norm of the partially contracted tensor and grows like (I r)^(mu/2): the squared
             # column norms / Gram entries of a high-order train overflow fp32 (LAPACK rescales internally).  Every R
-            # is therefore brought back to O(1) by an exact power of two per batch item; the exponents are summed
-            # and returned to core 0 at the end, so the result is bit-identical whenever nothing overflowed.
-            e = torch.frexp(_hip.norm(Rprev.reshape(Bt, -1)))[1]
-            expo = e if expo is None else expo + e
-            s2 = torch.ldexp(torch.ones(Bt, dtype=Rprev.dtype, device=Rprev.device), -e)
-            Rprev = _hip.scale_cols(Rprev, s2[:, None].expand(Bt, Rprev.shape[2]).contiguous(), _hip.SCALE_MUL)
+            # is therefore brought back to O(1) by an exact power of two per batch item (one ttr_pow2_normalize
+            # launch); the exponents are summed on the device and returned to core 0 at the end, so the result is
+            # bit-identical whenever nothing overflowed.
+            if expo is None:
+                expo = torch.zeros(Bt, dtype=torch.int32, device=Rprev.device)
+            Rprev, _ = _hip.pow2_normalize(Rprev, expo_acc=expo)
         c[mu] = None
     last = c[N - 1]
     c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
     if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
-        Bt = c[N - 1].shape[0]
-        flat = c[N - 1].reshape(Bt, 1, -1)
-        e = torch.frexp(_hip.norm(flat.reshape(Bt, -1)))[1]
-        expo = expo + e
-        s2 = torch.ldexp(torch.ones(Bt, dtype=flat.dtype, device=flat.device), -e)
-        c[N - 1] = _hip.scale_cols(flat, s2[:, None].expand(Bt, flat.shape[2]).contiguous(), _hip.SCALE_MUL).reshape(c[N - 1].shape)
+        c[N - 1], _ = _hip.pow2_normalize(c[N - 1], expo_acc=expo)
     if batch:  # tensor.py:2036-2037
         delta = None
     else:  # tensor.py:2039-2051
@@ -638,8 +641,7 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
         left = t.left_scaled()
     f, r0, I = facs[0]
     if expo is not None:  # give the exponents back (exact); a norm beyond the fp32 range overflows here, as it must
-        back = torch.ldexp(torch.ones(left.shape[0], dtype=left.dtype, device=left.device), expo)
-        left = _hip.scale_cols(left, back[:, None].expand(left.shape[0], left.shape[2]).contiguous(), _hip.SCALE_MUL)
+        left = _hip.scale_batch(left, expo=expo, expo_sign=+1)
     dst = None
     if arena is not None:
         dst = arena.slice(0, chunk, (r0 * I, left.shape[2]))
@@ -914,7 +916,5 @@ def core_kron(a4: torch.Tensor, b4: torch.Tensor) -> torch.Tensor:
 
 
 def scale(x: torch.Tensor, value: float) -> torch.Tensor:
-    """x * value for a device tensor of any shape (ttr_scale_cols with a constant column scale)."""
-    flat = x.reshape(1, 1, -1)
-    sv = torch.full((1, flat.shape[2]), float(value), dtype=x.dtype, device=x.device)
-    return _hip.scale_cols(flat.contiguous(), sv, _hip.SCALE_MUL).reshape(x.shape)
+    """x * value for a device tensor of any shape (ttr_scale_batch with one broadcast scalar)."""
+    return _hip.scale_batch(x.reshape(1, -1), scale=float(value)).reshape(x.shape)

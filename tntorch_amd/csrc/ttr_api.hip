@@ -120,6 +120,110 @@ __global__ __launch_bounds__(kThreads) void scale_cols_kernel(int64_t rows, int6
   }
 }
 
+// Block-wide sum of doubles (256 threads), result in every thread.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();  // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int w = 0; w < kThreads / kWave; ++w) s += red[w];
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pow2_normalize_kernel(const T* __restrict__ x, int64_t count, int64_t stride_x,
+                                                                  T* __restrict__ out, int64_t stride_out,
+                                                                  int32_t* __restrict__ e_out, int32_t* __restrict__ expo_acc) {
+  __shared__ double red[kThreads / kWave];
+  const int64_t b = blockIdx.x;
+  const T* __restrict__ xb = x + b * stride_x;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < count; i += kThreads) {
+    const double v = (double)xb[i];
+    acc += v * v;
+  }
+  const double nrm = sqrt(block_sum(acc, red));
+  int e = 0;
+  if (nrm > 0.0 && nrm < 1e300) (void)frexp(nrm, &e);
+  if (out) {
+    T* __restrict__ ob = out + b * stride_out;
+    for (int64_t i = threadIdx.x; i < count; i += kThreads) ob[i] = (T)ldexp((double)xb[i], -e);  // exact
+  }
+  if (threadIdx.x == 0) {
+    if (e_out) e_out[b] = e;
+    if (expo_acc) expo_acc[b] += e;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scale_batch_kernel(const T* __restrict__ x, int64_t count, int64_t stride_x,
+                                                               const T* __restrict__ scale, int64_t stride_scale,
+                                                               const int32_t* __restrict__ expo, int expo_sign,
+                                                               T* __restrict__ out, int64_t stride_out) {
+  const int64_t b = blockIdx.y;
+  const T sc = scale ? scale[b * stride_scale] : T(1);
+  const int e = expo ? expo_sign * expo[b] : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads) {
+    T v = x[b * stride_x + i] * sc;
+    if (e != 0) v = (T)ldexp((double)v, e);
+    out[b * stride_out + i] = v;
+  }
+}
+
+// One workgroup per batch item; see ttr_orth_fixup in the header.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void orth_fixup_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t es,
+                                                              int64_t strideX, const T* __restrict__ sigma,
+                                                              int64_t stride_sigma, double dead_rel) {
+  __shared__ double red[kThreads / kWave];
+  const int64_t b = blockIdx.x;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const double s0 = (double)sg[0];
+  int first = r;
+  for (int i = 0; i < r; ++i)
+    if (!((double)sg[i] > dead_rel * s0)) { first = i; break; }  // (also catches NaN / zero sigma_0)
+  if (first >= r) return;
+  T* __restrict__ Xb = X + b * strideX;
+  const int tid = threadIdx.x;
+  for (int i = first; i < r; ++i) {
+    T* __restrict__ xi = Xb + (int64_t)i * vs;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      double n0 = 0.0;
+      for (int64_t k = tid; k < n; k += kThreads) { const double v = (double)xi[k * es]; n0 += v * v; }
+      n0 = block_sum(n0, red);
+      bool regenerate = !(n0 > 0.0) || !(n0 < 1e300);
+      if (!regenerate) {
+        for (int pass = 0; pass < 2; ++pass)
+          for (int j = 0; j < i; ++j) {  // modified Gram-Schmidt against every finished vector
+            const T* __restrict__ xj = Xb + (int64_t)j * vs;
+            double d = 0.0;
+            for (int64_t k = tid; k < n; k += kThreads) d += (double)xj[k * es] * (double)xi[k * es];
+            d = block_sum(d, red);
+            for (int64_t k = tid; k < n; k += kThreads) xi[k * es] = (T)((double)xi[k * es] - d * (double)xj[k * es]);
+          }
+        double n1 = 0.0;
+        for (int64_t k = tid; k < n; k += kThreads) { const double v = (double)xi[k * es]; n1 += v * v; }
+        n1 = block_sum(n1, red);
+        if (n1 > 1e-6 * n0) {  // a genuine remainder: normalise and go on
+          const double inv = 1.0 / sqrt(n1);
+          for (int64_t k = tid; k < n; k += kThreads) xi[k * es] = (T)((double)xi[k * es] * inv);
+          break;
+        }
+        regenerate = true;  // the vector lay in the span of the previous ones
+      }
+      if (regenerate) {  // hashed pseudo-random replacement (deterministic), orthogonalised by the next attempt
+        for (int64_t k = tid; k < n; k += kThreads) {
+          uint32_t h = (uint32_t)(k * 2654435761u) ^ (uint32_t)((i + 1) * 40503u) ^ (uint32_t)((attempt + 1) * 97u);
+          h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+          xi[k * es] = (T)((double)(h >> 8) * (1.0 / 8388608.0) - 1.0);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // implemented in the other translation units
 int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
@@ -146,8 +250,8 @@ int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
                              int64_t strideO, hipStream_t stream);
 int qr_max_cols(int dtype);
-int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
-                  int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
+int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
+                  int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
                   int64_t ws_bytes, hipStream_t stream);
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
@@ -155,6 +259,7 @@ int eigh_max_n(int dtype);
 int eigh_max_n_lds(int dtype);
 
 extern long long* g_qr_dbg;
+extern int g_qr_variant;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -268,18 +373,21 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
 
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return eigh_workspace_bytes(dtype, n, batch); }
 
-int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
-                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
-                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* workspace,
-                   int64_t workspace_bytes, void* stream) {
+int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
+                   int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma,
+                   int32_t* info, int eig_mode, int use_delta, double delta2, int64_t rmax, int abs_floor,
+                   int32_t* sweeps, void* workspace, int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_trunc: bad dtype %d", dtype);
-  TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
+  TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1 && gparts >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
+  TTR_REQUIRE(abs_floor >= TTR_SOLVER_JACOBI_REL && abs_floor <= TTR_SOLVER_JACOBI_LIVE, TTR_E_INVALID,
+              "ttr_eigh_trunc: bad solver %d", abs_floor);
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(G && V && sigma && info, TTR_E_INVALID, "ttr_eigh_trunc: null pointer");
   TTR_REQUIRE(eig_mode >= TTR_EIG_RAW && eig_mode <= TTR_EIG_MATCH_DIAG, TTR_E_INVALID, "ttr_eigh_trunc: bad eig_mode %d",
               eig_mode);
-  return eigh_dispatch(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                       use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes, (hipStream_t)stream);
+  return eigh_dispatch(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info,
+                       eig_mode, use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes,
+                       (hipStream_t)stream);
 }
 
 int ttr_norm(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out, void* stream) {
@@ -322,6 +430,73 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
   return TTR_OK;
 }
 
+int ttr_pow2_normalize(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out,
+                       int64_t stride_out, int32_t* e_out, int32_t* expo_acc, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_pow2_normalize: bad dtype %d", dtype);
+  TTR_REQUIRE(count >= 0 && batch >= 0, TTR_E_INVALID, "ttr_pow2_normalize: negative size");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(x && (out || e_out), TTR_E_INVALID, "ttr_pow2_normalize: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(pow2_normalize_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (const float*)x, count,
+                       stride_x, (float*)out, stride_out, e_out, expo_acc);
+  else
+    hipLaunchKernelGGL(pow2_normalize_kernel<double>, dim3((unsigned)batch), dim3(kThreads), 0, s, (const double*)x,
+                       count, stride_x, (double*)out, stride_out, e_out, expo_acc);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, const void* scale,
+                    int64_t stride_scale, const int32_t* expo, int expo_sign, void* out, int64_t stride_out,
+                    void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_scale_batch: bad dtype %d", dtype);
+  TTR_REQUIRE(count >= 0 && batch >= 0, TTR_E_INVALID, "ttr_scale_batch: negative size");
+  if (batch == 0 || count == 0) return TTR_OK;
+  TTR_REQUIRE(x && out, TTR_E_INVALID, "ttr_scale_batch: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t gx = ceil_div(count, kThreads * 4);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  ProfScope prof(TTR_PROF_MISC, s);
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y limit
+    const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    const int64_t so = dtype == TTR_F32 ? 4 : 8;
+    const char* xs = (const char*)x + b0 * stride_x * so;
+    char* os = (char*)out + b0 * stride_out * so;
+    const char* ss = scale ? (const char*)scale + b0 * stride_scale * so : nullptr;
+    const int32_t* es = expo ? expo + b0 : nullptr;
+    if (dtype == TTR_F32)
+      hipLaunchKernelGGL(scale_batch_kernel<float>, dim3((unsigned)gx, (unsigned)nb), dim3(kThreads), 0, s, (const float*)xs,
+                         count, stride_x, (const float*)ss, stride_scale, es, expo_sign, (float*)os, stride_out);
+    else
+      hipLaunchKernelGGL(scale_batch_kernel<double>, dim3((unsigned)gx, (unsigned)nb), dim3(kThreads), 0, s,
+                         (const double*)xs, count, stride_x, (const double*)ss, stride_scale, es, expo_sign, (double*)os,
+                         stride_out);
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
+                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_orth_fixup: bad dtype %d", dtype);
+  TTR_REQUIRE(r >= 0 && n >= 0 && batch >= 0 && r <= 2147483647LL, TTR_E_INVALID, "ttr_orth_fixup: bad sizes");
+  if (batch == 0 || r == 0 || n == 0) return TTR_OK;
+  TTR_REQUIRE(X && sigma, TTR_E_INVALID, "ttr_orth_fixup: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(orth_fixup_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (float*)X,
+                       vec_stride, elem_stride, strideX, (const float*)sigma, stride_sigma, dead_rel);
+  else
+    hipLaunchKernelGGL(orth_fixup_kernel<double>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (double*)X,
+                       vec_stride, elem_stride, strideX, (const double*)sigma, stride_sigma, dead_rel);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
 int ttr_krp_contract(int dtype, int64_t P, int64_t J, int64_t Q, int64_t R, const void* T, const void* B, int64_t ldb,
                      void* out, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_krp_contract: bad dtype %d", dtype);
@@ -351,6 +526,17 @@ int ttr_core_kron(int dtype, int64_t batch, int64_t R1, int64_t S1, int64_t I, i
 int ttr_debug_set_qr_stamps(void* device_buffer) {
   g_qr_dbg = (long long*)device_buffer;
   return TTR_OK;
+}
+
+int ttr_debug_set_knob(int knob, int value) {
+  switch (knob) {
+    case TTR_KNOB_QR_PANEL:
+      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: QR panel variant %d outside [0, 2]", value);
+      g_qr_variant = value;
+      return TTR_OK;
+    default:
+      TTR_REQUIRE(false, TTR_E_INVALID, "ttr_debug_set_knob: unknown knob %d", knob);
+  }
 }
 
 int ttr_prof_enable(int on) {

@@ -133,6 +133,42 @@ __device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
   for (int c = 0; c < 4; ++c) v[c] = (lane_get(v[c], 0) + lane_get(v[c], 16)) + (lane_get(v[c], 32) + lane_get(v[c], 48));
 }
 
+// ------------------------------------------------------------------ 16-lane-row primitives (MFMA C/D layout helpers)
+// In the 16x16 accumulator layout lane = (g = lane >> 4, cl = lane & 15) holds rows {4g..4g+3} (f32) of column cl.
+// row_bcast<J>(v): every lane receives v of lane (g, J) of its own 16-lane row (DPP row_newbcast: VALU only).
+template <int J>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xF, 0xF, false));
+}
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + J, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// Sum over the four lanes {cl, cl+16, cl+32, cl+48}; result in all four.  gfx950 v_permlane16_swap / v_permlane32_swap
+// exchange whole 16-lane rows between two registers (VALU only); `safe` uses ds_bpermute shuffles instead.
+__device__ __forceinline__ float xrow_sum(float v, bool safe) {
+  if (safe) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned a = __builtin_bit_cast(unsigned, v);
+  u32x2 s = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+  v = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  a = __builtin_bit_cast(unsigned, v);
+  s = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+__device__ __forceinline__ double xrow_sum(double v, bool) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 template <typename T>
 struct Num;
 template <>

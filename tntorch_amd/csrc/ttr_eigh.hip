@@ -31,6 +31,8 @@ struct EighArgs {
   int n;
   const T* G;
   int64_t ldg, strideG;
+  int gparts;            // G[b] = sum of `gparts` partial matrices spaced stride_gpart apart (split-K partials of a Gram kernel)
+  int64_t stride_gpart;
   T* V;
   int64_t ldv, strideV;
   T* sigma;
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T* st = ct + npad;
   unsigned char* after = smem_raw + rot_table_bytes<T>(npad);
   int* flags = reinterpret_cast<int*>(after);              // [0]: rotated-this-sweep
-  T* sg = reinterpret_cast<T*>(flags + 16);                // sigma / ordering scratch [2 * n]
+  int* deadv = flags + 16;                                 // [n4] 1 = numerically null index, never rotated (TTR_SOLVER_JACOBI_LIVE)
+  const int n4 = (n + 4) & ~3;
+  T* sg = reinterpret_cast<T*>(deadv + n4);                // sigma / ordering scratch [2 * n]
   T* Gs;
   T* Vs;
   if (LDSRES) {
@@ -116,7 +120,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const T* __restrict__ G = p.G + bt * p.strideG;
   for (int idx = tid; idx < n * n; idx += kThreads) {
     const int i = idx / n, j = idx % n;
-    Gs[i * ld + j] = G[(int64_t)i * p.ldg + j];
+    T gv = G[(int64_t)i * p.ldg + j];
+    for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
+    Gs[i * ld + j] = gv;
     Vs[i * ld + j] = (i == j) ? T(1) : T(0);
   }
   if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
@@ -125,8 +131,22 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   if (p.abs_floor) {
     T gmax = 0;
     for (int i = 0; i < n; ++i) gmax = fmax(gmax, fabs(Gs[i * ld + i]));  // broadcast reads
-    floor_abs = fmax(floor_abs, Num<T>::eps() * sqrt((T)n) * gmax);
+    if (p.abs_floor == TTR_SOLVER_JACOBI_LIVE) {
+      // Pass 2 of the 'svd' truncation: G is the Gram matrix of ROTATED rows, i.e. graded and nearly diagonal, and
+      // every entry is accurate relative to sqrt(G_pp G_qq).  The purely relative (cosine) rotation test then gives
+      // every live direction the accuracy class of a backward-stable SVD, however small its sigma.  Indices whose
+      // G_ii <= (n eps)^2 max G_ii are the numerical null space of the input (their rows are rounding noise of the
+      // pass-1 rotation): rotating them never terminates (the noise is regenerated by every update) and changes
+      // nothing above the noise level, so they are frozen.
+      const T thr = (T)n * Num<T>::eps();
+      const T dead_below = thr * thr * gmax;
+      for (int i = tid; i < n; i += kThreads) deadv[i] = (Gs[i * ld + i] <= dead_below) ? 1 : 0;
+      __syncthreads();
+    } else {
+      floor_abs = fmax(floor_abs, Num<T>::eps() * sqrt((T)n) * gmax);
+    }
   }
+  const bool live_mode = p.abs_floor == TTR_SOLVER_JACOBI_LIVE;
 
   // LAPACK xGESVJ-style tolerance sqrt(n)*eps: with a bare eps the rounding noise of the updates keeps
   // regenerating off-diagonals at the eps level and the sweep loop never terminates.
@@ -155,7 +175,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       else { pp = (r + k) % m1; qq = (r - k + m1) % m1; }
       if (pp < n && qq < n) {
         const T aabs = fabs(Gs[pp * ld + qq]);
-        if (aabs > eps * (sqrt(fabs(Gs[pp * ld + pp])) * sqrt(fabs(Gs[qq * ld + qq]))) && aabs > floor_abs) flags[1] = 1;
+        if (aabs > eps * (sqrt(fabs(Gs[pp * ld + pp])) * sqrt(fabs(Gs[qq * ld + qq]))) && aabs > floor_abs &&
+            !(live_mode && (deadv[pp] | deadv[qq])))
+          flags[1] = 1;
       }
     }
     __syncthreads();
@@ -180,7 +202,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
         if (pp < n && qq < n) {
           const T app = Gs[pp * ld + pp], aqq = Gs[qq * ld + qq], apq = Gs[pp * ld + qq];
           const T aabs = fabs(apq);
-          if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs) {  // no overflow of app*aqq
+          if (aabs > eps * (sqrt(fabs(app)) * sqrt(fabs(aqq))) && aabs > floor_abs &&  // no overflow of app*aqq
+              !(live_mode && (deadv[pp] | deadv[qq]))) {
             jacobi_cs(app, aqq, apq, c, s);
             flags[2 + (r & 1)] = 1;  // this round has work
           }
@@ -414,7 +437,14 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale
-  const T gdiag = (lane < n) ? G[(int64_t)lane * p.ldg + lane] : T(0);
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int i = idx / n, j = idx - i * n;
+    T gv = G[(int64_t)i * p.ldg + j];
+    for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
+    A[i * ld + j] = gv;
+  }
+  __syncthreads();
+  const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);
   T gd = fabs(gdiag);
   T gmax = gd;
 #pragma unroll
@@ -422,7 +452,7 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   const T ginv = gmax > T(0) ? T(1) / gmax : T(0);
   for (int idx = lane; idx < n * n; idx += kWave) {
     const int i = idx / n, j = idx - i * n;
-    A[i * ld + j] = G[(int64_t)i * p.ldg + j] * ginv;
+    A[i * ld + j] *= ginv;
   }
   __syncthreads();
 
@@ -629,6 +659,7 @@ static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
   const int np = (int)((n + 1) / 2), npad = (np + 7) & ~7;
   const size_t tab = (size_t)npad * (2 * sizeof(double) + 4 * sizeof(int) + 2 * elem);
   size_t bytes = tab + 16 * sizeof(int);
+  bytes += (size_t)((n + 4) & ~3) * sizeof(int);  // dead-index flags
   bytes += (2 * ((n + 1) & ~1) + 2) * elem;
   if (ldsres) bytes += 2 * (size_t)n * (n + 1) * elem;  // G and V
   return (bytes + 15) & ~size_t(15);
@@ -650,7 +681,8 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
 }
 
 template <typename T>
-static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
+                      int64_t stride_gpart, void* V,
                       int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                       int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
                       int64_t ws_bytes, hipStream_t stream) {
@@ -660,6 +692,7 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   EighArgs<T> p;
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
+  p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
   p.V = (T*)V; p.ldv = ldv; p.strideV = strideV;
   p.sigma = (T*)sigma; p.stride_sigma = stride_sigma;
   p.info = info;
@@ -668,14 +701,14 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
   p.abs_floor = abs_floor;
   p.sweeps = sweeps;
-  if (abs_floor == 2 && n <= 64) {  // tridiagonal QL, one wave per matrix
+  if (abs_floor == TTR_SOLVER_TRIDIAG && n <= 64) {  // tridiagonal QL, one wave per matrix
     const size_t lds = eigh_tridiag_lds_bytes(sizeof(T), n);
     ProfScope prof(TTR_PROF_EIGH, stream);
     hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(kWave), lds, stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     return TTR_OK;
   }
-  if (abs_floor == 2) p.abs_floor = 1;  // larger problems: Jacobi with the absolute floor
+  if (abs_floor == TTR_SOLVER_TRIDIAG) p.abs_floor = TTR_SOLVER_JACOBI_ABS;  // larger problems: Jacobi with the absolute floor
   const bool ldsres = n <= eigh_max_n_lds(dtype);
   if (!ldsres) {
     const int64_t need = eigh_workspace_bytes(dtype, n, batch);
@@ -699,14 +732,15 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   return TTR_OK;
 }
 
-int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, void* V,
+int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
+                  int64_t stride_gpart, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
                   int64_t ws_bytes, hipStream_t stream) {
   if (dtype == TTR_F32)
-    return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
+    return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
                              use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
-  return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
+  return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
 }
 

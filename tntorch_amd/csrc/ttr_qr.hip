@@ -64,6 +64,7 @@ struct QrLevel {
   int64_t strideCn;
   int pk, pRin, pI;
   long long* dbg;      // optional: cycle stamps of block (0,0) at phase boundaries (diagnostics)
+  int safe_xlane;      // ROWP: 1 = ds_bpermute shuffles instead of DPP row_newbcast / v_permlane swaps (diagnostics)
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -87,7 +88,36 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 }
 
 // ---------------------------------------------------------------- factor
-template <typename T, int NT, bool PUSHED, int NW>
+// Panel step helper (ROWP): dst[i] = src[i] of lane (g, j) of the caller's 16-lane row, j a runtime value.
+template <typename T>
+__device__ __forceinline__ void bcast_col16(int j, const T (&src)[16], T (&dst)[16], bool safe, int lane) {
+  if (safe) {
+    const int from = (lane & 48) | j;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = __shfl(src[i], from, 64);
+    return;
+  }
+#define TTR_BC(J)                                               \
+  case J:                                                       \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) dst[i] = row_bcast<J>(src[i]); \
+    break;
+  switch (j) {
+    TTR_BC(0) TTR_BC(1) TTR_BC(2) TTR_BC(3) TTR_BC(4) TTR_BC(5) TTR_BC(6) TTR_BC(7)
+    TTR_BC(8) TTR_BC(9) TTR_BC(10) TTR_BC(11) TTR_BC(12) TTR_BC(13) TTR_BC(14)
+    default:
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) dst[i] = row_bcast<15>(src[i]);
+      break;
+  }
+#undef TTR_BC
+}
+
+// ROWP = false: panels factored in the column-owning layout (round 1).  ROWP = true: panels factored in place in the
+// accumulator (row) layout -- every wave works on every step, one LDS-only barrier per Householder step:
+//   lane (g, cl) holds 16 rows of panel column cl.  Step j: the sub-column x_j is broadcast inside the 16-lane rows
+//   (DPP row_newbcast), every lane forms the partial dot product x_j . (its own column), the four lane rows are summed
+//   with v_permlane swaps, the NW wave partials meet in LDS (16 x NW floats, double buffered), and each lane applies
+//   H_j to its own 16 elements.  No transposition of the panel, no idle waves.
+template <typename T, int NT, bool PUSHED, int NW, bool ROWP>
 __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
@@ -101,6 +131,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   constexpr int WPC = NP > 2 * PW ? NP - PW : PW;               // W only exists for the trailing column tiles (tn >= 1)
   __shared__ T Wp[NW][PW][WPC];                                 // per-wave partial W (also S partials)
   __shared__ T W2s[PW][NP + 1];
+  __shared__ __attribute__((aligned(16))) T part[ROWP ? 2 : 1][PW][NW];  // ROWP: per-wave partial dot products of a step
+  __shared__ T prowv[ROWP ? 2 : 1][PW];                                  // ROWP: the pivot row of a step
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -120,11 +152,14 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // acc <- Rm (pk x pRin) * C[:, i, :] (pRin x n) for this wave's mode index i = NW*b + wave: the wave's 64
     // rows are exactly (kk = 0..63, i).  Rm^T is staged once in LDS (aliasing Vs, conflict-free A-operand
     // reads), the core slice is read from global directly in MFMA B-operand layout.
-    T* Rs = Vs;  // [r0][kk], 64 x 64 (Vs holds 256 x 17)
+    // Rs[kk][r0], leading dimension 66: the coalesced global read is stored without bank conflicts (consecutive
+    // r0) and the A-operand reads below (16 kk x 2 r0 per 32-lane group: words 66 cl + g) touch 32 distinct banks.
+    constexpr int RLD = 66;
+    T* Rs = Vs;  // 64 x 66 <= 256 x 17
     const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
     for (int idx = tid; idx < 64 * 64; idx += NTH) {
       const int kk = idx >> 6, r0 = idx & 63;
-      Rs[r0 * 64 + kk] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
+      Rs[kk * RLD + r0] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
     }
     lds_barrier();
 #pragma unroll
@@ -145,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         bv[tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
       }
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[r0 * 64 + tm * 16 + cl];
+      for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -219,6 +254,104 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // columns 4w..4w+3 completely -- lane l has rows l, l+64, l+128, l+192.  The column norm and every
     // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
     // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
+    if constexpr (ROWP) {
+      if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs / W2s
+      stamp();
+      const bool safe = p.safe_xlane != 0;
+      for (int j = 0; j < nsteps; ++j) {
+        const int pr = j0 + j;  // pivot row (block-local; always inside wave 0)
+        const int buf = j & 1;
+        T src[16], xb[16];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) src[tm * 4 + r] = acc[tm][pnl][r];
+        bcast_col16<T>(j, src, xb, safe, lane);
+        if (wave_id == 0) {  // only wave 0 holds rows <= pr: x is the part of column j strictly below the pivot
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (tm < pnl) xb[tm * 4 + r] = T(0);
+              else if (tm == pnl) xb[tm * 4 + r] = (M::row(lane, r) > j) ? xb[tm * 4 + r] : T(0);
+            }
+          // publish the pivot row (all 16 panel columns): element (row j of tile pnl, column cl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (M::row(lane, r) == j) prowv[buf][cl] = acc[pnl][pnl][r];
+        }
+        T d0 = xb[0] * src[0], d1 = xb[1] * src[1], d2 = xb[2] * src[2], d3 = xb[3] * src[3];
+#pragma unroll
+        for (int i = 4; i < 16; i += 4) {
+          d0 += xb[i] * src[i]; d1 += xb[i + 1] * src[i + 1]; d2 += xb[i + 2] * src[i + 2]; d3 += xb[i + 3] * src[i + 3];
+        }
+        T d = xrow_sum((d0 + d1) + (d2 + d3), safe);
+        if (g == 0) part[buf][cl][wave] = d;
+        lds_barrier();
+        T my, ss;
+        {
+          T a[NW], c2[NW];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) { a[w] = part[buf][cl][w]; c2[w] = part[buf][j][w]; }
+          if constexpr (NW == 8) {
+            my = ((a[0] + a[4]) + (a[1] + a[5])) + ((a[2] + a[6]) + (a[3] + a[7]));
+            ss = ((c2[0] + c2[4]) + (c2[1] + c2[5])) + ((c2[2] + c2[6]) + (c2[3] + c2[7]));
+          } else {
+            my = (a[0] + a[2]) + (a[1] + a[3]);
+            ss = (c2[0] + c2[2]) + (c2[1] + c2[3]);
+          }
+        }
+        const T alpha = prowv[buf][j], pcl = prowv[buf][cl];
+        T beta, tj, scale;
+        if (ss == T(0)) {  // LAPACK larfg: H = I
+          beta = alpha; tj = T(0); scale = T(0);
+        } else {
+          larfg_scalars(alpha, ss, beta, tj, scale);
+        }
+        const bool isj = (cl == j);
+        const T f = (cl > j) ? tj * (scale * my + pcl) : T(0);  // tau * (v^T c) for the columns right of j
+        // Below the pivot row:  column j <- v = scale * x (there x IS the lane's own element),  column c > j <- c - f v,
+        // finished columns unchanged -- one branch-free form  P <- ca * P + cb * x  with per-lane coefficients.
+        const T ca = isj ? scale : T(1), cb = isj ? T(0) : -(f * scale);
+        if (wave_id == 0) {
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (tm < pnl) continue;  // rows above the panel's diagonal block: finished R entries
+              T cur = acc[tm][pnl][r];
+              if (tm == pnl) {
+                const int re = M::row(lane, r);
+                if (re > j) cur = ca * cur + cb * xb[tm * 4 + r];
+                else if (re == j) cur = isj ? beta : cur - f;  // v = 1 on the pivot row
+              } else {
+                cur = ca * cur + cb * xb[tm * 4 + r];
+              }
+              acc[tm][pnl][r] = cur;
+            }
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][pnl][r] = ca * acc[tm][pnl][r] + cb * xb[tm * 4 + r];
+        }
+        if (tid == 0) { tau[pr] = tj; taus[pr] = tj; }
+      }
+      stamp();
+      // the finished panel -> Vs[row][c] with explicit unit diagonal / zeros above (identity reflectors: all zero)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = rowl(tm, r), dg = j0 + cl;
+          Vs[lr * VLD + cl] = (cl < nsteps) ? (lr > dg ? acc[tm][pnl][r] : (lr == dg ? T(1) : T(0))) : T(0);
+        }
+      lds_barrier();
+      // reflectors to the workspace, transposed (thread = row: each store instruction writes 256 contiguous bytes per wave)
+#pragma unroll
+      for (int c = 0; c < PW; ++c) Vt[(int64_t)(j0 + c) * BR + tid] = Vs[tid * VLD + c];
+      if (tid < PW && tid >= nsteps) tau[j0 + tid] = T(0);
+    } else {
     T pc[CPW][NW];  // [column CPW*w + cc][row lane + 64 q]
     if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
@@ -343,6 +476,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       if (tid == 0) tau[j0 + j] = T(0);
     }
     lds_barrier();
+    }
     // (5) S = V^T V over the block (MFMA, K = BR split over the waves), then the triangular factor T
     {
       Acc s = M::zero();
@@ -376,10 +510,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         Tg[pnl * PW * PW + i * PW + jc] = trow[jc];
       }
     }
-    lds_barrier();
-    stamp();
-    if (pnl < NT - 1 && (pnl + 1) * PW < n) {
-      // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand
+    // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand.  W does not
+    // depend on T: it is formed in the same barrier interval as the (serial, 16-lane) larft recurrence above, so
+    // the other waves' MFMAs run under wave 0's recurrence instead of waiting for it.
+    const bool trailing = pnl < NT - 1 && (pnl + 1) * PW < n;
+    if (trailing) {
 #pragma unroll
       for (int tn = pnl + 1; tn < NT; ++tn) {
         Acc wa = M::zero();
@@ -390,7 +525,10 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
         for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][(tn - 1) * PW + cl] = wa[r];
       }
-      lds_barrier();
+    }
+    lds_barrier();
+    stamp();
+    if (trailing) {
       // W2 = -T^T (sum of the partials)
       {
         const int jc = tid & 63, i4 = tid >> 6;
@@ -429,6 +567,26 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   if constexpr (NT > 1) panel(IC<1>{});
   if constexpr (NT > 2) panel(IC<2>{});
   if constexpr (NT > 3) panel(IC<3>{});
+  if constexpr (ROWP) {
+    // R = the upper triangle of the block's first min(rows, n) rows: they live in wave 0's tiles
+    if (wave_id == 0) {
+      T* __restrict__ Ro = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
+      const int rr = p.top ? kb : n;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tm * 16 + M::row(lane, r), col = tn * PW + cl;
+            if (col < n && row < rr) {
+              T rv = (row <= col && row < kb) ? acc[tm][tn][r] : T(0);
+              if constexpr (sizeof(T) == 4) { if (bexp != 0) rv = ldexpf((float)rv, bexp); }
+              Ro[(int64_t)row * p.ldr + col] = rv;
+            }
+          }
+    }
+  }
   lds_barrier();
 }
 
@@ -637,6 +795,8 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 }
 
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
+int g_qr_variant = 2;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 0 column-owning panels (round 1), 1 row-layout panels
+                                // with ds_bpermute shuffles, 2 row-layout panels with DPP / v_permlane (default)
 
 struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
   const void* Rm = nullptr;
@@ -667,13 +827,18 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
     const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
-    if (pl.nw[l] == 8) {
-      if (l == 0 && pu.Rm) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8>), grid, dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8>), grid, dim3(512), 0, stream, p);
+    const bool pushed = (l == 0 && pu.Rm);
+    p.safe_xlane = (g_qr_variant == 1);
+#define TTR_QR_LAUNCH(PU, NWV, RP) \
+  hipLaunchKernelGGL((qr_factor_kernel<T, NT, PU, NWV, RP>), grid, dim3(64 * NWV), 0, stream, p)
+    if (g_qr_variant == 0) {
+      if (pl.nw[l] == 8) { if (pushed) TTR_QR_LAUNCH(true, 8, false); else TTR_QR_LAUNCH(false, 8, false); }
+      else { if (pushed) TTR_QR_LAUNCH(true, 4, false); else TTR_QR_LAUNCH(false, 4, false); }
     } else {
-      if (l == 0 && pu.Rm) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 4>), grid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 4>), grid, dim3(256), 0, stream, p);
+      if (pl.nw[l] == 8) { if (pushed) TTR_QR_LAUNCH(true, 8, true); else TTR_QR_LAUNCH(false, 8, true); }
+      else { if (pushed) TTR_QR_LAUNCH(true, 4, true); else TTR_QR_LAUNCH(false, 4, true); }
     }
+#undef TTR_QR_LAUNCH
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
