@@ -69,9 +69,18 @@ QR_SHAPES = [(64, 64), (4096, 64), (300, 17), (16, 16), (10, 40), (256, 16), (25
              (1, 1), (1, 7), (7, 1), (513, 32), (70000, 8)]
 
 
+@pytest.fixture(params=[2, 1, 0], ids=["panel-row-dpp", "panel-row-shfl", "panel-colown"])
+def qr_variant(request):
+    """TTR_KNOB_QR_PANEL: every QR test runs under the default panel kernel (2) and the two A/B variants."""
+    h = _hip()
+    h.set_knob(h.KNOB_QR_PANEL, request.param)
+    yield request.param
+    h.set_knob(h.KNOB_QR_PANEL, 2)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("m,n", QR_SHAPES)
-def test_qr(dt, m, n):
+def test_qr(dt, m, n, qr_variant):
     h = _hip()
     g = torch.Generator().manual_seed(m * 31 + n)
     B = 2 if m * n < 400000 else 1
@@ -91,7 +100,7 @@ def test_qr(dt, m, n):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("k,Rin,I,n", [(64, 64, 64, 64), (10, 7, 9, 12), (64, 64, 5, 33), (33, 64, 130, 64), (1, 1, 40, 8)])
-def test_qr_pushed(dt, k, Rin, I, n):
+def test_qr_pushed(dt, k, Rin, I, n, qr_variant):
     """Fused push + QR: factor the left unfolding of Rm @ core without forming it; apply gives Q [C; 0]."""
     h = _hip()
     g = torch.Generator().manual_seed(k * 1000 + Rin * 100 + I * 10 + n)
@@ -114,7 +123,7 @@ def test_qr_pushed(dt, k, Rin, I, n):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_qr_rank_deficient(dt):
+def test_qr_rank_deficient(dt, qr_variant):
     """Left unfolding of g+g: exactly rank-deficient; Q must still be orthonormal."""
     h = _hip()
     g = torch.Generator().manual_seed(3)
@@ -343,3 +352,131 @@ def test_unsupported_shapes_raise():
         h.qr(torch.randn(1, 300, h.max_qr_cols(torch.float32) + 1).cuda())
     with pytest.raises(TypeError):
         h.qr(torch.randn(1, 8, 4).cuda().half())
+
+
+# ------------------------------------------------------------------ round 2 additions
+def test_xlane_primitives():
+    """DPP row_newbcast / v_permlane swaps (row-layout QR panels) against their ds_bpermute stand-ins: the two panel
+    variants must produce the SAME factorisation up to rounding-order differences of the four-lane sums."""
+    h = _hip()
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(4, 4096, 64, generator=g, dtype=torch.float32).cuda()
+    out = {}
+    for v in (1, 2):
+        h.set_knob(h.KNOB_QR_PANEL, v)
+        try:
+            f = h.qr_factor(A)
+            out[v] = (f.R.clone(), h.qr_apply(f))
+        finally:
+            h.set_knob(h.KNOB_QR_PANEL, 2)
+    assert (out[1][0] - out[2][0]).abs().max() / out[1][0].abs().max() < 1e-5
+    assert (out[1][1] - out[2][1]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pow2_normalize_and_scale_batch(dt):
+    h = _hip()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 7, 33, generator=g, dtype=torch.float64).to(dt)
+    x[1] *= 1e20 if dt == torch.float64 else 1e15
+    x[2] *= 1e-20 if dt == torch.float64 else 1e-15
+    x[3] = 0
+    acc = torch.full((5,), 3, dtype=torch.int32).cuda()
+    y, e = h.pow2_normalize(x.cuda(), expo_acc=acc)
+    y, e = y.cpu(), e.cpu()
+    nrm = x.double().reshape(5, -1).norm(dim=1)
+    want_e = torch.frexp(nrm)[1].to(torch.int32)
+    want_e[3] = 0
+    assert torch.equal(e, want_e) and torch.equal(acc.cpu(), want_e + 3)
+    assert torch.equal(y, torch.ldexp(x, -e[:, None, None].to(torch.int32)))          # exact power-of-two scaling
+    yn = y.double().reshape(5, -1).norm(dim=1)
+    assert ((yn >= 0.5 - 1e-6) & (yn < 1.0 + 1e-6))[[0, 1, 2, 4]].all() and yn[3] == 0
+    _, e2 = h.pow2_normalize(x.cuda(), exponent_only=True)
+    assert torch.equal(e2.cpu(), want_e)
+    back = h.scale_batch(y.cuda(), expo=e.cuda(), expo_sign=+1).cpu()
+    assert torch.equal(back, x)
+    s = torch.tensor([2.0, -1.0, 0.5, 3.0, 1.0], dtype=dt)
+    z = h.scale_batch(x.cuda(), scale=s.cuda()).cpu()
+    assert torch.allclose(z, x * s[:, None, None], rtol=1e-6 if dt == torch.float32 else 1e-14, atol=0)
+    z = h.scale_batch(x.cuda(), scale=-2.5).cpu()
+    assert torch.allclose(z, x * -2.5, rtol=1e-6 if dt == torch.float32 else 1e-14, atol=0)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_eigh_split_k_partials(dt, solver):
+    """G given as split-K partial sums (what a fused Gram kernel leaves behind): summed on load."""
+    h = _hip()
+    g = torch.Generator().manual_seed(17)
+    B, parts, n = 3, 5, 48
+    Mx = torch.randn(B, parts, n, 40, generator=g, dtype=torch.float64)
+    Gp = (Mx @ Mx.transpose(2, 3)).to(dt)
+    G = Gp.double().sum(dim=1)
+    V, sig, info = h.eigh_trunc(Gp.cuda(), h.EIG_RAW, False, 0.0, n, abs_floor=solver)
+    V, sig = V.cpu().double(), sig.cpu().double()
+    wref = torch.linalg.eigvalsh(G).flip(-1)
+    assert ((sig**2 - wref).abs().max(dim=1).values / wref[:, 0]).max() < tol(dt, 2e-6, 1e-13)
+    assert (G @ V - V * (sig**2)[:, None, :]).abs().max() / wref.max() < tol(dt, 2e-5, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_eigh_live_graded(dt):
+    """TTR_SOLVER_JACOBI_LIVE on an accurately formed graded Gram matrix (pass 2 of 'svd'): every eigenvalue above the
+    dead threshold (n eps)^2 lambda_max comes out with RELATIVE accuracy; the absolute-floor solver only resolves
+    them to eps * lambda_max."""
+    h = _hip()
+    g = torch.Generator().manual_seed(23)
+    n = 64
+    eps = torch.finfo(dt).eps
+    decay = 0.5 if dt == torch.float32 else 1.2          # sigma_63 / sigma_0 = 3e-10 (fp32) / 2e-23 (fp64)
+    s = 2.0 ** (-decay * torch.arange(n, dtype=torch.float64))
+    Q, _ = torch.linalg.qr(torch.randn(3, 512, n, generator=g, dtype=torch.float64))
+    W = torch.linalg.qr(torch.randn(3, n, n, generator=g, dtype=torch.float64))[0]
+    W = torch.eye(n, dtype=torch.float64) + 1e-3 * (W - torch.eye(n, dtype=torch.float64))   # nearly diagonal after "pass 1"
+    rows = (W * s[None, None, :]).transpose(1, 2) @ Q.transpose(1, 2)                        # graded rows, mildly coupled
+    G = (rows @ rows.transpose(1, 2))
+    Gd = G.to(dt)
+    V, sig, info = h.eigh_trunc(Gd.cuda(), h.EIG_RAW, False, 0.0, n, abs_floor=h.SOLVER_JACOBI_LIVE)
+    V, sig = V.cpu().double(), sig.cpu().double()
+    wref = torch.linalg.eigvalsh(Gd.double()).flip(-1).clamp_min(0)
+    sref = wref.sqrt()
+    live = sref[0] > 4 * n * eps * sref[0, 0]
+    rel = ((sig[0] - sref[0]).abs() / sref[0])[live]
+    assert rel.max() < tol(dt, 2e-4, 1e-10), rel.max()
+    assert (V.transpose(1, 2) @ V - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
+    # rotated rows of the LIVE directions are orthogonal relative to their own norms (what the projection needs)
+    Rw = V[0].T @ rows[0]
+    Rn = Rw[live] / Rw[live].norm(dim=1, keepdim=True)
+    assert (Rn @ Rn.T - torch.eye(int(live.sum()), dtype=torch.float64)).abs().max() < tol(dt, 5e-4, 1e-9)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("columns", [False, True])
+def test_orth_fixup(dt, columns):
+    h = _hip()
+    g = torch.Generator().manual_seed(29)
+    B, r, n = 4, 12, 300
+    Q = torch.linalg.qr(torch.randn(B, n, r, generator=g, dtype=torch.float64))[0].transpose(1, 2).contiguous()  # [B, r, n]
+    sig = torch.ones(B, r, dtype=torch.float64) * torch.linspace(1, 0.5, r, dtype=torch.float64)
+    X = Q.clone()
+    # item 0: untouched.  item 1: last 3 vectors dead and noisy.  item 2: a dead vector inside the span, a zero one, a NaN one
+    sig[1, 9:] = 1e-12
+    X[1, 9:] = X[1, 9:] * 3.0 + 0.3 * X[1, :3] + 0.2 * torch.randn(3, n, generator=g, dtype=torch.float64)
+    sig[2, 8:] = 0.0
+    X[2, 8] = X[2, 0] - 2 * X[2, 3]
+    X[2, 9] = 0
+    X[2, 10] = float("nan")
+    X[2, 11] = 5 * X[2, 11]
+    sig[3, 11] = 1e-9
+    Xd = (X.transpose(1, 2).contiguous() if columns else X).to(dt).cuda()
+    before = Xd.clone()
+    h.orth_fixup(Xd, sig.to(dt).cuda(), r, 1e-6, columns=columns)
+    out = Xd.cpu().double()
+    out = out.transpose(1, 2) if columns else out
+    eye = torch.eye(r, dtype=torch.float64)
+    t = tol(dt, 2e-6, 1e-13)
+    for b in range(B):
+        assert (out[b] @ out[b].T - eye).abs().max() < t, b
+    assert torch.equal(Xd[0], before[0])                                   # nothing dead: untouched, bit for bit
+    live = out[1, :9] if True else None
+    assert (live - X[1, :9]).abs().max() < t                               # live vectors are never modified

@@ -1,0 +1,119 @@
+// Instruction-rate microbenchmarks for gfx950 (round 2): how many cycles does one wave64 VALU instruction occupy its
+// SIMD, alone and with four waves per SIMD?  Built and run by tools/r2_probe.py on the GPU box; not part of the library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+__global__ void rate_kernel(float* out, long long* cyc, int iters) {
+  float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+  const float m = 1.0000001f, c = 1e-9f;
+  f32x2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+  const f32x2 pm = {m, m}, pc = {c, c};
+  __syncthreads();
+  const long long t0 = clock64();
+  for (int i = 0; i < iters; ++i) {
+    if (KIND == 0) {  // 8 independent v_fma_f32
+      a0 = fmaf(a0, m, c); a1 = fmaf(a1, m, c); a2 = fmaf(a2, m, c); a3 = fmaf(a3, m, c);
+      a4 = fmaf(a4, m, c); a5 = fmaf(a5, m, c); a6 = fmaf(a6, m, c); a7 = fmaf(a7, m, c);
+    } else if (KIND == 1) {  // 4 independent v_pk_fma_f32 (8 flops-lanes)
+      p0 = __builtin_elementwise_fma(p0, pm, pc); p1 = __builtin_elementwise_fma(p1, pm, pc);
+      p2 = __builtin_elementwise_fma(p2, pm, pc); p3 = __builtin_elementwise_fma(p3, pm, pc);
+    } else if (KIND == 2) {  // 8 DPP row broadcasts
+      a0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x153, 0xF, 0xF, false));
+      a1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x154, 0xF, 0xF, false));
+      a2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a2), 0x155, 0xF, 0xF, false));
+      a3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a3), 0x156, 0xF, 0xF, false));
+      a4 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a4), 0x157, 0xF, 0xF, false));
+      a5 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a5), 0x158, 0xF, 0xF, false));
+      a6 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a6), 0x159, 0xF, 0xF, false));
+      a7 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a7), 0x15A, 0xF, 0xF, false));
+    } else if (KIND == 3) {  // dependent v_fma chain (latency)
+      a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c);
+      a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c); a0 = fmaf(a0, m, c);
+    } else if (KIND == 4) {  // 8 ds_bpermute
+      const int idx = ((threadIdx.x & 48) | 5) * 4;
+      a0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a0)));
+      a1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a1)));
+      a2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a2)));
+      a3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a3)));
+      a4 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a4)));
+      a5 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a5)));
+      a6 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a6)));
+      a7 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, a7)));
+    } else if (KIND == 5) {  // 8 independent v_mul + v_cndmask pairs (16 instructions)
+      const bool s = (threadIdx.x & 1) != 0;
+      a0 = s ? a0 * m : a0; a1 = s ? a1 * m : a1; a2 = s ? a2 * m : a2; a3 = s ? a3 * m : a3;
+      a4 = s ? a4 * m : a4; a5 = s ? a5 * m : a5; a6 = s ? a6 * m : a6; a7 = s ? a7 * m : a7;
+    }
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+  }
+  const long long t1 = clock64();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1];
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// lane-exchange semantics: out[0][l] = row_newbcast<5>, out[1][l] = permlane16-swap sum, out[2][l] = permlane32-swap sum
+__global__ void xlane_kernel(float* out) {
+  const float v = (float)threadIdx.x;
+  out[threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x155, 0xF, 0xF, false));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned a = __builtin_bit_cast(unsigned, v);
+  u32x2 s = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+  out[64 + threadIdx.x] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  s = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  out[128 + threadIdx.x] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+
+template <int KIND>
+static void run(const char* name, int insts_per_iter) {
+  const int iters = 20000;
+  float* out; long long* cyc;
+  hipMalloc(&out, sizeof(float) * 256 * 4096);
+  hipMalloc(&cyc, sizeof(long long) * 4096);
+  long long h[4096];
+  // one wave alone on a CU
+  hipLaunchKernelGGL(rate_kernel<KIND>, dim3(1), dim3(64), 0, 0, out, cyc, iters);
+  hipMemcpy(h, cyc, sizeof(long long), hipMemcpyDeviceToHost);
+  const double alone = (double)h[0] / ((double)iters * insts_per_iter);
+  // four waves per SIMD on every CU: 256 CUs x 4 blocks x 256 threads
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(rate_kernel<KIND>, dim3(1024), dim3(256), 0, 0, out, cyc, iters);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(rate_kernel<KIND>, dim3(1024), dim3(256), 0, 0, out, cyc, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(h, cyc, sizeof(long long) * 1024, hipMemcpyDeviceToHost);
+  double avg = 0; for (int i = 0; i < 1024; ++i) avg += (double)h[i]; avg /= 1024;
+  // per SIMD: 4 waves x iters x insts instructions in `avg` cycles
+  const double loaded = avg / ((double)iters * insts_per_iter * 4);
+  printf("{\"microbench\": \"%s\", \"cycles_per_wave_inst_alone\": %.3f, \"simd_cycles_per_wave_inst_4waves\": %.3f, \"ms_full_chip\": %.3f, \"ghz_equiv\": %.3f}\n",
+         name, alone, loaded, ms, avg / (ms * 1e6));
+  hipFree(out); hipFree(cyc);
+}
+
+int main() {
+  run<0>("v_fma_f32 x8 independent", 8);
+  run<1>("v_pk_fma_f32 x4 independent", 4);
+  run<2>("v_mov_dpp row_newbcast x8", 8);
+  run<3>("v_fma_f32 x8 dependent chain", 8);
+  run<4>("ds_bpermute_b32 x8", 8);
+  run<5>("v_mul + v_cndmask x8 pairs", 16);
+  float* o; hipMalloc(&o, sizeof(float) * 192);
+  hipLaunchKernelGGL(xlane_kernel, dim3(1), dim3(64), 0, 0, o);
+  float h[192]; hipMemcpy(h, o, sizeof(h), hipMemcpyDeviceToHost);
+  int ok_b = 1, ok_16 = 1, ok_32 = 1;
+  for (int l = 0; l < 64; ++l) {
+    if (h[l] != (float)((l & 48) | 5)) ok_b = 0;
+    const int g = l >> 4, cl = l & 15;
+    if (h[64 + l] != (float)((((g & 2) | 0) * 16 + cl) + (((g & 2) | 1) * 16 + cl))) ok_16 = 0;
+    if (h[128 + l] != (float)((l & 31) + ((l & 31) + 32))) ok_32 = 0;
+  }
+  printf("{\"xlane\": {\"row_newbcast\": %d, \"permlane16_swap_sum\": %d, \"permlane32_swap_sum\": %d, \"sample16\": [%g, %g, %g, %g], \"sample32\": [%g, %g]}}\n",
+         ok_b, ok_16, ok_32, h[64], h[64 + 16], h[64 + 32], h[64 + 48], h[128], h[128 + 32]);
+  return 0;
+}
