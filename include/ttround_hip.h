@@ -223,6 +223,31 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
                    void* out, int64_t ldo, int64_t stride_out, void* stream);
 
 /*
+ * Fused kernels of the right-to-left truncation sweep: the (R <= 64) x n right unfolding M of a core is streamed once,
+ * 16 columns per wave and step, every intermediate stays in MFMA accumulator registers.
+ *   ttr_rowgram   G = M M^T                                           replaces `M @ M^T` round.py:104-109
+ *   ttr_rotgram   G = (V1^T M)(V1^T M)^T  (V1: R x R)                 pass 2 of the two-pass 'svd' truncation (round.py:96):
+ *                 the Gram matrix of the rows ROTATED by the pass-1 eigenvectors, formed from the rotated data (small
+ *                 rows from small numbers) without ever writing the rotated matrix
+ *   ttr_project   right = diag(1/sigma) U^T M (ro x n),  left = U diag(sigma) (R x ro, optional),  U = V1 V2[:, :ro]
+ *                 (V1 = NULL: U = V2[:, :ro]); scale_right = 0: right = U^T M, left = U        replaces round.py:163-172
+ * G is written as `nparts` split-K partial matrices per item ([batch][nparts][R][R], contiguous; nparts from
+ * ttr_sweep_gram_parts); ttr_eigh_trunc sums them on load.
+ */
+int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch);
+int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                void* G, int64_t nparts, void* stream);
+int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, void* stream);
+int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
+                const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1,
+                const void* V2, int64_t ldv2, int64_t strideV2,
+                const void* sigma, int64_t stride_sigma, int scale_right,
+                void* right, int64_t ldr, int64_t strideR,
+                void* left, int64_t ldl, int64_t strideL, void* stream);
+
+/*
  * Exact power-of-two normalisation, one launch: e[b] = binary exponent of ||x[b]|| (0 for a zero / non-finite norm),
  * out[b] = x[b] * 2^-e[b], and, when `expo_acc` is given, expo_acc[b] += e[b].  (`out` may alias `x`; out = NULL:
  * exponents only.)
@@ -259,13 +284,15 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
 #define TTR_PROF_QR_APPLY 2
 #define TTR_PROF_EIGH 3
 #define TTR_PROF_MISC 4
-#define TTR_PROF_NKINDS 5
+#define TTR_PROF_ROTGRAM 5
+#define TTR_PROF_PROJECT 6
+#define TTR_PROF_NKINDS 7
 /* Diagnostics: when set to a device buffer of >= 64 int64, block (0,0) of every level-0 QR factor launch writes
  * its s_memtime stamps at phase boundaries there.  NULL disables. */
 int ttr_debug_set_qr_stamps(void* device_buffer);
 /* Diagnostics / A-B measurements: select kernel variants at run time (process-wide, not thread safe).
- *   TTR_KNOB_QR_PANEL  0 = panels factored in the column-owning layout (round 1), 1 = row-layout panels with
- *                      ds_bpermute shuffles, 2 = row-layout panels with DPP row_newbcast / v_permlane swaps (default). */
+ *   TTR_KNOB_QR_PANEL  1 = the 8-wave QR blocks factor / apply their panel columns in pairs (two reflectors per step,
+ *                      v_permlane-swap reductions; default), 0 = one reflector at a time (round-1 kernel). */
 #define TTR_KNOB_QR_PANEL 0
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);

@@ -69,13 +69,13 @@ QR_SHAPES = [(64, 64), (4096, 64), (300, 17), (16, 16), (10, 40), (256, 16), (25
              (1, 1), (1, 7), (7, 1), (513, 32), (70000, 8)]
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["panel-row-dpp", "panel-row-shfl", "panel-colown"])
+@pytest.fixture(params=[1, 0], ids=["pair-steps", "single-steps"])
 def qr_variant(request):
-    """TTR_KNOB_QR_PANEL: every QR test runs under the default panel kernel (2) and the two A/B variants."""
+    """TTR_KNOB_QR_PANEL: every QR test runs under the default panel kernel (pair steps) and the round-1 variant."""
     h = _hip()
     h.set_knob(h.KNOB_QR_PANEL, request.param)
     yield request.param
-    h.set_knob(h.KNOB_QR_PANEL, 2)
+    h.set_knob(h.KNOB_QR_PANEL, 1)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -355,22 +355,67 @@ def test_unsupported_shapes_raise():
 
 
 # ------------------------------------------------------------------ round 2 additions
-def test_xlane_primitives():
-    """DPP row_newbcast / v_permlane swaps (row-layout QR panels) against their ds_bpermute stand-ins: the two panel
-    variants must produce the SAME factorisation up to rounding-order differences of the four-lane sums."""
+def test_qr_pair_steps_match_single_steps():
+    """The pair-step panel kernel (v_permlane-swap reductions, two reflectors per step) against the one-reflector
+    kernel: the same Householder factorisation up to summation order."""
     h = _hip()
     g = torch.Generator().manual_seed(5)
-    A = torch.randn(4, 4096, 64, generator=g, dtype=torch.float32).cuda()
+    A = torch.randn(4, 4096, 64, generator=g, dtype=torch.float32)
+    A[1, :, 20:40] = A[1, :, :20]            # exactly dependent columns
+    A[2, :, 7] = 0
+    A = A.cuda()
     out = {}
-    for v in (1, 2):
+    for v in (0, 1):
         h.set_knob(h.KNOB_QR_PANEL, v)
         try:
             f = h.qr_factor(A)
             out[v] = (f.R.clone(), h.qr_apply(f))
         finally:
-            h.set_knob(h.KNOB_QR_PANEL, 2)
-    assert (out[1][0] - out[2][0]).abs().max() / out[1][0].abs().max() < 1e-5
-    assert (out[1][1] - out[2][1]).abs().max() < 1e-5
+            h.set_knob(h.KNOB_QR_PANEL, 1)
+    assert (out[0][0][0] - out[1][0][0]).abs().max() / out[0][0][0].abs().max() < 1e-5   # generic item: same R
+    for b in range(4):
+        Q = out[1][1][b].double()
+        assert (Q.T @ Q - torch.eye(64, dtype=torch.float64, device="cuda")).abs().max() < 3e-5
+        assert (Q @ out[1][0][b].double() - A[b].double()).abs().max() / A[b].abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("R,n,B", [(64, 2048, 3), (64, 4096, 1), (37, 1000, 2), (5, 33, 2), (1, 7, 1), (64, 70000, 1), (48, 16, 300)])
+def test_sweep_gram_rotgram_project(dt, R, n, B):
+    """ttr_rowgram / ttr_rotgram / ttr_project against float64 torch."""
+    h = _hip()
+    g = torch.Generator().manual_seed(R * 7 + n)
+    M = torch.randn(B, R, n, generator=g, dtype=torch.float64).to(dt)
+    V1 = torch.linalg.qr(torch.randn(B, R, R, generator=g, dtype=torch.float64))[0].to(dt)
+    V2 = torch.linalg.qr(torch.randn(B, R, R, generator=g, dtype=torch.float64))[0].to(dt)
+    sig = (torch.rand(B, R, generator=g, dtype=torch.float64) + 0.5).to(dt)
+    Md, V1d, V2d = M.double(), V1.double(), V2.double()
+    t = tol(dt, 2e-5, 1e-12)
+    G = h.rowgram(M.cuda()).cpu().double().sum(dim=1)
+    Gr = Md @ Md.transpose(1, 2)
+    assert (G - Gr).abs().max() / Gr.abs().max() < t
+    G2 = h.rowgram(M.cuda(), V1.cuda()).cpu().double().sum(dim=1)
+    Mw = V1d.transpose(1, 2) @ Md
+    G2r = Mw @ Mw.transpose(1, 2)
+    assert (G2 - G2r).abs().max() / G2r.abs().max() < t
+    assert (G2 - G2.transpose(1, 2)).abs().max() == 0                       # both triangles written from one value
+    ro = max(1, R // 2)
+    U = V1d @ V2d[:, :, :ro]
+    right, left = h.project(M.cuda(), V1.cuda(), V2.cuda(), sig.cuda(), ro, scale_right=True)
+    assert (right.cpu().double() - (U.transpose(1, 2) @ Md) / sig.double()[:, :ro, None]).abs().max() / Md.abs().max() < 4 * t
+    assert (left.cpu().double() - U * sig.double()[:, None, :ro]).abs().max() < t
+    right, left = h.project(M.cuda(), None, V2.cuda(), sig.cuda(), ro, scale_right=False)
+    assert (right.cpu().double() - V2d[:, :, :ro].transpose(1, 2) @ Md).abs().max() / Md.abs().max() < 4 * t
+    assert (left.cpu().double() - V2d[:, :, :ro]).abs().max() < t
+    # a strided view of a larger tensor (leading dimension > n), and a zero sigma (TTR_SCALE_DIV: 0, not inf)
+    big = torch.randn(B, R, n + 5, generator=g, dtype=torch.float64).to(dt).cuda()
+    Gv = h.rowgram(big[:, :, 2:2 + n]).cpu().double().sum(dim=1)
+    ref = big[:, :, 2:2 + n].cpu().double()
+    assert (Gv - ref @ ref.transpose(1, 2)).abs().max() / Gr.abs().max() < t
+    sig0 = sig.clone()
+    sig0[:, 0] = 0
+    right, _ = h.project(M.cuda(), None, V2.cuda(), sig0.cuda(), ro, scale_right=True)
+    assert (right[:, 0] == 0).all() and torch.isfinite(right).all()
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
-PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc")
+PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc", "rotgram", "project")
 
 _lib = None
 
@@ -82,6 +82,17 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
          c_int, c_int, c_double, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_sweep_gram_parts": (c_int64, [c_int64, c_int64]),
+    "ttr_rowgram": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "ttr_rotgram": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_project": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
     ),
     "ttr_pow2_normalize": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ttr_scale_batch": (
@@ -470,6 +481,65 @@ def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
                             out.data_ptr(), cols, rows * cols, _stream())
     _check(code, "ttr_scale_cols")
     return out
+
+
+def sweep_fused_ok(M: torch.Tensor) -> bool:
+    """The fused row-Gram / rotate-Gram / projection kernels hold up to 64 rows."""
+    return M.shape[1] <= 64
+
+
+@_on_device
+def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-K partials [batch, parts, R, R] of M M^T (V1 None) or of (V1^T M)(V1^T M)^T for M [batch, R, n], R <= 64
+    (ttr_rowgram / ttr_rotgram); ``eigh_trunc`` sums the parts on load."""
+    L = lib()
+    dt = dtype_code(M.dtype)
+    M, ldm, sM = _mat(M)
+    batch, R, n = M.shape
+    parts = int(L.ttr_sweep_gram_parts(n, max(batch, 1)))
+    G = torch.empty((batch, parts, R, R), dtype=M.dtype, device=M.device)
+    if batch == 0:
+        return G
+    if V1 is None:
+        _check(L.ttr_rowgram(dt, R, n, batch, M.data_ptr(), ldm, sM, G.data_ptr(), parts, _stream()), "ttr_rowgram")
+    else:
+        V1, ldv, sV = _mat(V1)
+        assert V1.shape == (batch, R, R)
+        _check(L.ttr_rotgram(dt, R, n, batch, M.data_ptr(), ldm, sM, V1.data_ptr(), ldv, sV, G.data_ptr(), parts, _stream()),
+               "ttr_rotgram")
+    return G
+
+
+@_on_device
+def project(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma: Optional[torch.Tensor], ro: int,
+            scale_right: bool, out: Optional[torch.Tensor] = None, want_left: bool = True):
+    """right [batch, ro, n] = diag(1/sigma) U^T M and left [batch, R, ro] = U diag(sigma) with U = V1 V2[:, :ro]
+    (ttr_project; ``scale_right=False``: right = U^T M, left = U).  ``out``: optional contiguous destination of right."""
+    L = lib()
+    dt = dtype_code(M.dtype)
+    M, ldm, sM = _mat(M)
+    batch, R, n = M.shape
+    V2, ldv2, sV2 = _mat(V2)
+    v1p, ldv1, sV1 = None, 0, 0
+    if V1 is not None:
+        V1, ldv1, sV1 = _mat(V1)
+        v1p = V1.data_ptr()
+    if out is not None:
+        assert tuple(out.shape) == (batch, ro, n) and out.is_contiguous() and out.dtype == M.dtype
+        right = out
+    else:
+        right = torch.empty((batch, ro, n), dtype=M.dtype, device=M.device)
+    left = torch.empty((batch, R, ro), dtype=M.dtype, device=M.device) if want_left else None
+    if batch == 0:
+        return right, left
+    sp, ss = None, 0
+    if sigma is not None:
+        sigma = sigma.contiguous()
+        sp, ss = sigma.data_ptr(), sigma.shape[-1]
+    _check(L.ttr_project(dt, R, n, ro, batch, M.data_ptr(), ldm, sM, v1p, ldv1, sV1, V2.data_ptr(), ldv2, sV2, sp, ss,
+                         int(bool(scale_right)), right.data_ptr(), n, ro * n,
+                         left.data_ptr() if left is not None else None, ro, R * ro, _stream()), "ttr_project")
+    return right, left
 
 
 @_on_device

@@ -303,6 +303,29 @@ def truncate(
     left_side = m <= n  # round.py:104-109; the 'svd' path is orientation-free
     ref_clamp = algorithm == "eig"
 
+    if left_side and _hip.sweep_fused_ok(M):
+        # Up to 64 rows (every bond of a train with TT ranks <= 64): the fused sweep kernels.  M is streamed three
+        # times ('eig': twice) and nothing of its size is written except the result: row Gram -> pass-1 eigenvectors V1
+        # -> Gram of the ROTATED rows (ttr_rotgram: the rotated matrix only exists 16 columns at a time in registers)
+        # -> Jacobi -> projection with U = V1 V2 formed in the kernel's prologue, which also emits left = U sigma.
+        V1 = None
+        if algorithm == "svd":
+            V1, _, _ = _hip.eigh_trunc(_hip.rowgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_JACOBI_LIVE)
+        else:
+            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M), _hip.EIG_REF, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_TRIDIAG)
+        r = _select_rank(info, batch, rmax, k)
+        if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
+            return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
+                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True)
+        dst = right_alloc(r) if right_alloc is not None else None
+        right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst)
+        if algorithm == "svd" and not left_ortho:
+            _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
+        return Truncation(left, None, right, r)
+
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         if left_side:

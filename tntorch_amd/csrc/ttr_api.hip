@@ -258,6 +258,14 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int eigh_max_n(int dtype);
 int eigh_max_n_lds(int dtype);
 
+int sweep_gram_parts(int64_t n, int64_t batch);
+int sweep_gram_dispatch(int dtype, int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
+                        const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream);
+int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
+                           int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
+                           int64_t strideV2, const void* sigma, int64_t stride_sigma, int scale_right, void* right,
+                           int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream);
+
 extern long long* g_qr_dbg;
 extern int g_qr_variant;
 
@@ -430,6 +438,42 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
   return TTR_OK;
 }
 
+int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch) {
+  if (n <= 0 || batch <= 0) return 1;
+  return sweep_gram_parts(n, batch);
+}
+
+int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM, void* G,
+                int64_t nparts, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_rowgram: bad dtype %d", dtype);
+  TTR_REQUIRE(R >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_rowgram: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(M && G, TTR_E_INVALID, "ttr_rowgram: null pointer");
+  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, nullptr, 0, 0, G, nparts, (hipStream_t)stream);
+}
+
+int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_rotgram: bad dtype %d", dtype);
+  TTR_REQUIRE(R >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_rotgram: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(M && G && V1, TTR_E_INVALID, "ttr_rotgram: null pointer");
+  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream);
+}
+
+int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2, int64_t strideV2,
+                const void* sigma, int64_t stride_sigma, int scale_right, void* right, int64_t ldr, int64_t strideR,
+                void* left, int64_t ldl, int64_t strideL, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_project: bad dtype %d", dtype);
+  TTR_REQUIRE(R >= 1 && n >= 1 && ro >= 1 && batch >= 0, TTR_E_INVALID, "ttr_project: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(M && V2 && right, TTR_E_INVALID, "ttr_project: null pointer");
+  TTR_REQUIRE(!scale_right || sigma, TTR_E_INVALID, "ttr_project: scale_right needs sigma");
+  return sweep_project_dispatch(dtype, R, n, ro, batch, M, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
+                                stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, (hipStream_t)stream);
+}
+
 int ttr_pow2_normalize(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out,
                        int64_t stride_out, int32_t* e_out, int32_t* expo_acc, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_pow2_normalize: bad dtype %d", dtype);
@@ -531,7 +575,7 @@ int ttr_debug_set_qr_stamps(void* device_buffer) {
 int ttr_debug_set_knob(int knob, int value) {
   switch (knob) {
     case TTR_KNOB_QR_PANEL:
-      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: QR panel variant %d outside [0, 2]", value);
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: QR panel variant %d outside [0, 1]", value);
       g_qr_variant = value;
       return TTR_OK;
     default:

@@ -133,41 +133,55 @@ __device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
   for (int c = 0; c < 4; ++c) v[c] = (lane_get(v[c], 0) + lane_get(v[c], 16)) + (lane_get(v[c], 32) + lane_get(v[c], 48));
 }
 
-// ------------------------------------------------------------------ 16-lane-row primitives (MFMA C/D layout helpers)
-// In the 16x16 accumulator layout lane = (g = lane >> 4, cl = lane & 15) holds rows {4g..4g+3} (f32) of column cl.
-// row_bcast<J>(v): every lane receives v of lane (g, J) of its own 16-lane row (DPP row_newbcast: VALU only).
-template <int J>
-__device__ __forceinline__ float row_bcast(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xF, 0xF, false));
+// ------------------------------------------------------------------ multi-value wave reductions (v_permlane swaps)
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange 32- / 16-lane blocks BETWEEN TWO REGISTERS (VALU only): one
+// swap + one add folds TWO values by half each, so four values are folded into the four 16-lane rows of ONE register
+// with 3 swaps + 3 adds, one DPP row reduction (4 steps) finishes all four, and four v_readlane broadcast them:
+// 14 instructions instead of the 44 of four interleaved DPP reductions.  That matters because a wave issues at most one
+// VALU instruction per ~8 cycles (measured: 8.0 cycles per independent v_fma for a wave alone on its SIMD, DPP 17.5), so
+// on the sequential Householder chain the instruction COUNT is the latency.
+// (Inline asm: the __builtin_amdgcn_permlane{16,32}_swap builtins of ROCm 7.2's clang return the same register for both
+// results -- verified in the ISA and on the device.)
+__device__ __forceinline__ void permswap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-template <int J>
-__device__ __forceinline__ double row_bcast(double v) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + J, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xF, 0xF, false);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+__device__ __forceinline__ void permswap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-// Sum over the four lanes {cl, cl+16, cl+32, cl+48}; result in all four.  gfx950 v_permlane16_swap / v_permlane32_swap
-// exchange whole 16-lane rows between two registers (VALU only); `safe` uses ds_bpermute shuffles instead.
-__device__ __forceinline__ float xrow_sum(float v, bool safe) {
-  if (safe) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-  }
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  unsigned a = __builtin_bit_cast(unsigned, v);
-  u32x2 s = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-  v = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-  a = __builtin_bit_cast(unsigned, v);
-  s = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-}
-__device__ __forceinline__ double xrow_sum(double v, bool) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+template <typename T>
+__device__ __forceinline__ T row_sum_dpp(T v) {  // sum over the 16 lanes of each row, result in every lane of the row
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
   return v;
 }
+// a, b <- their sums over the 64 lanes (wave-uniform)
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  permswap32(a, b);            // a = [a.r0 a.r1 b.r0 b.r1], b = [a.r2 a.r3 b.r2 b.r3]
+  float s = a + b, t = s;      // s = [a02 a13 b02 b13]
+  permswap16(s, t);            // s = [a02 a02 b02 b02], t = [a13 a13 b13 b13]
+  const float q = row_sum_dpp(s + t);
+  a = lane_get(q, 0);
+  b = lane_get(q, 32);
+}
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+  a = wave_sum_dpp(a);
+  b = wave_sum_dpp(b);
+}
+// v[0..3] <- their sums over the 64 lanes (wave-uniform)
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+  permswap32(v[0], v[1]);
+  permswap32(v[2], v[3]);
+  float ab = v[0] + v[1], cd = v[2] + v[3];  // ab = [A02 A13 B02 B13], cd = [C02 C13 D02 D13]
+  permswap16(ab, cd);                        // ab = [A02 C02 B02 D02], cd = [A13 C13 B13 D13]
+  const float q = row_sum_dpp(ab + cd);      // rows: A, C, B, D
+  v[0] = lane_get(q, 0);
+  v[1] = lane_get(q, 32);
+  v[2] = lane_get(q, 16);
+  v[3] = lane_get(q, 48);
+}
+__device__ __forceinline__ void wave_sum4(double (&v)[4]) { wave_sum_dpp4(v); }
 
 template <typename T>
 struct Num;

@@ -64,7 +64,6 @@ struct QrLevel {
   int64_t strideCn;
   int pk, pRin, pI;
   long long* dbg;      // optional: cycle stamps of block (0,0) at phase boundaries (diagnostics)
-  int safe_xlane;      // ROWP: 1 = ds_bpermute shuffles instead of DPP row_newbcast / v_permlane swaps (diagnostics)
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -88,36 +87,11 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 }
 
 // ---------------------------------------------------------------- factor
-// Panel step helper (ROWP): dst[i] = src[i] of lane (g, j) of the caller's 16-lane row, j a runtime value.
-template <typename T>
-__device__ __forceinline__ void bcast_col16(int j, const T (&src)[16], T (&dst)[16], bool safe, int lane) {
-  if (safe) {
-    const int from = (lane & 48) | j;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = __shfl(src[i], from, 64);
-    return;
-  }
-#define TTR_BC(J)                                               \
-  case J:                                                       \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) dst[i] = row_bcast<J>(src[i]); \
-    break;
-  switch (j) {
-    TTR_BC(0) TTR_BC(1) TTR_BC(2) TTR_BC(3) TTR_BC(4) TTR_BC(5) TTR_BC(6) TTR_BC(7)
-    TTR_BC(8) TTR_BC(9) TTR_BC(10) TTR_BC(11) TTR_BC(12) TTR_BC(13) TTR_BC(14)
-    default:
-      _Pragma("unroll") for (int i = 0; i < 16; ++i) dst[i] = row_bcast<15>(src[i]);
-      break;
-  }
-#undef TTR_BC
-}
-
-// ROWP = false: panels factored in the column-owning layout (round 1).  ROWP = true: panels factored in place in the
-// accumulator (row) layout -- every wave works on every step, one LDS-only barrier per Householder step:
-//   lane (g, cl) holds 16 rows of panel column cl.  Step j: the sub-column x_j is broadcast inside the 16-lane rows
-//   (DPP row_newbcast), every lane forms the partial dot product x_j . (its own column), the four lane rows are summed
-//   with v_permlane swaps, the NW wave partials meet in LDS (16 x NW floats, double buffered), and each lane applies
-//   H_j to its own 16 elements.  No transposition of the panel, no idle waves.
-template <typename T, int NT, bool PUSHED, int NW, bool ROWP>
+// PAIR (NW = 8 only: two panel columns per wave): the owner factors its two columns with two 2-value reductions and
+// publishes the pair (v0, v1, tau0, tau1, v0^T v1); the waves to its right apply BOTH reflectors with ONE 4-value
+// reduction,  c <- c - a0 v0 - a1 v1,  a0 = tau0 v0^T c,  a1 = tau1 (v1^T c - (v0^T v1) a0);  the reflectors go to the
+// workspace after the panel (all threads, coalesced) instead of from the owner's sequential chain.
+template <typename T, int NT, bool PUSHED, int NW, bool PAIR>
 __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
@@ -131,8 +105,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   constexpr int WPC = NP > 2 * PW ? NP - PW : PW;               // W only exists for the trailing column tiles (tn >= 1)
   __shared__ T Wp[NW][PW][WPC];                                 // per-wave partial W (also S partials)
   __shared__ T W2s[PW][NP + 1];
-  __shared__ __attribute__((aligned(16))) T part[ROWP ? 2 : 1][PW][NW];  // ROWP: per-wave partial dot products of a step
-  __shared__ T prowv[ROWP ? 2 : 1][PW];                                  // ROWP: the pivot row of a step
+  __shared__ T pairt[NW];                                       // PAIR: v0^T v1 of every owner's pair
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -254,104 +227,6 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // columns 4w..4w+3 completely -- lane l has rows l, l+64, l+128, l+192.  The column norm and every
     // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
     // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
-    if constexpr (ROWP) {
-      if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs / W2s
-      stamp();
-      const bool safe = p.safe_xlane != 0;
-      for (int j = 0; j < nsteps; ++j) {
-        const int pr = j0 + j;  // pivot row (block-local; always inside wave 0)
-        const int buf = j & 1;
-        T src[16], xb[16];
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) src[tm * 4 + r] = acc[tm][pnl][r];
-        bcast_col16<T>(j, src, xb, safe, lane);
-        if (wave_id == 0) {  // only wave 0 holds rows <= pr: x is the part of column j strictly below the pivot
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (tm < pnl) xb[tm * 4 + r] = T(0);
-              else if (tm == pnl) xb[tm * 4 + r] = (M::row(lane, r) > j) ? xb[tm * 4 + r] : T(0);
-            }
-          // publish the pivot row (all 16 panel columns): element (row j of tile pnl, column cl)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (M::row(lane, r) == j) prowv[buf][cl] = acc[pnl][pnl][r];
-        }
-        T d0 = xb[0] * src[0], d1 = xb[1] * src[1], d2 = xb[2] * src[2], d3 = xb[3] * src[3];
-#pragma unroll
-        for (int i = 4; i < 16; i += 4) {
-          d0 += xb[i] * src[i]; d1 += xb[i + 1] * src[i + 1]; d2 += xb[i + 2] * src[i + 2]; d3 += xb[i + 3] * src[i + 3];
-        }
-        T d = xrow_sum((d0 + d1) + (d2 + d3), safe);
-        if (g == 0) part[buf][cl][wave] = d;
-        lds_barrier();
-        T my, ss;
-        {
-          T a[NW], c2[NW];
-#pragma unroll
-          for (int w = 0; w < NW; ++w) { a[w] = part[buf][cl][w]; c2[w] = part[buf][j][w]; }
-          if constexpr (NW == 8) {
-            my = ((a[0] + a[4]) + (a[1] + a[5])) + ((a[2] + a[6]) + (a[3] + a[7]));
-            ss = ((c2[0] + c2[4]) + (c2[1] + c2[5])) + ((c2[2] + c2[6]) + (c2[3] + c2[7]));
-          } else {
-            my = (a[0] + a[2]) + (a[1] + a[3]);
-            ss = (c2[0] + c2[2]) + (c2[1] + c2[3]);
-          }
-        }
-        const T alpha = prowv[buf][j], pcl = prowv[buf][cl];
-        T beta, tj, scale;
-        if (ss == T(0)) {  // LAPACK larfg: H = I
-          beta = alpha; tj = T(0); scale = T(0);
-        } else {
-          larfg_scalars(alpha, ss, beta, tj, scale);
-        }
-        const bool isj = (cl == j);
-        const T f = (cl > j) ? tj * (scale * my + pcl) : T(0);  // tau * (v^T c) for the columns right of j
-        // Below the pivot row:  column j <- v = scale * x (there x IS the lane's own element),  column c > j <- c - f v,
-        // finished columns unchanged -- one branch-free form  P <- ca * P + cb * x  with per-lane coefficients.
-        const T ca = isj ? scale : T(1), cb = isj ? T(0) : -(f * scale);
-        if (wave_id == 0) {
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (tm < pnl) continue;  // rows above the panel's diagonal block: finished R entries
-              T cur = acc[tm][pnl][r];
-              if (tm == pnl) {
-                const int re = M::row(lane, r);
-                if (re > j) cur = ca * cur + cb * xb[tm * 4 + r];
-                else if (re == j) cur = isj ? beta : cur - f;  // v = 1 on the pivot row
-              } else {
-                cur = ca * cur + cb * xb[tm * 4 + r];
-              }
-              acc[tm][pnl][r] = cur;
-            }
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tm][pnl][r] = ca * acc[tm][pnl][r] + cb * xb[tm * 4 + r];
-        }
-        if (tid == 0) { tau[pr] = tj; taus[pr] = tj; }
-      }
-      stamp();
-      // the finished panel -> Vs[row][c] with explicit unit diagonal / zeros above (identity reflectors: all zero)
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lr = rowl(tm, r), dg = j0 + cl;
-          Vs[lr * VLD + cl] = (cl < nsteps) ? (lr > dg ? acc[tm][pnl][r] : (lr == dg ? T(1) : T(0))) : T(0);
-        }
-      lds_barrier();
-      // reflectors to the workspace, transposed (thread = row: each store instruction writes 256 contiguous bytes per wave)
-#pragma unroll
-      for (int c = 0; c < PW; ++c) Vt[(int64_t)(j0 + c) * BR + tid] = Vs[tid * VLD + c];
-      if (tid < PW && tid >= nsteps) tau[j0 + tid] = T(0);
-    } else {
     T pc[CPW][NW];  // [column CPW*w + cc][row lane + 64 q]
     if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
@@ -374,6 +249,94 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
     for (int owv = 0; owv < NW; ++owv) {
       if (owv * CPW < nsteps) {  // block-uniform
+        if constexpr (PAIR) {
+          static_assert(!PAIR || CPW == 2, "PAIR needs two columns per wave");
+          const int j = owv * 2, jj = j0 + j, jj1 = jj + 1;
+          const bool two = j + 1 < nsteps;  // block-uniform: the second column of the pair takes a step as well
+          if (wave_id == owv) {
+            // ---- column 0: x0 = sub-column below the pivot; ||x0||^2 and x0 . c1 in one 2-value reduction
+            T x0[NW];
+            x0[0] = (lane > jj) ? pc[0][0] : T(0);
+#pragma unroll
+            for (int q = 1; q < NW; ++q) x0[q] = pc[0][q];
+            T s00 = x0[0] * x0[0], s01 = x0[0] * pc[1][0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) { s00 += x0[q] * x0[q]; s01 += x0[q] * pc[1][q]; }
+            wave_sum2(s00, s01);
+            const T alpha0 = lane_get(pc[0][0], jj);
+            T beta0, t0, sc0;
+            if (s00 == T(0)) { beta0 = alpha0; t0 = T(0); sc0 = T(0); }  // LAPACK larfg: H = I
+            else larfg_scalars(alpha0, s00, beta0, t0, sc0);
+            T v0[NW];
+            v0[0] = (lane > jj) ? x0[0] * sc0 : (lane == jj ? T(1) : T(0));
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v0[q] = x0[q] * sc0;
+            {  // H0 on column 1: v0^T c1 = sc0 * x0^T c1 + c1[jj]
+              const T f = t0 * (sc0 * s01 + lane_get(pc[1][0], jj));
+#pragma unroll
+              for (int q = 0; q < NW; ++q) pc[1][q] -= f * v0[q];
+            }
+            if (lane == jj) pc[0][0] = beta0;  // R[jj][jj]
+            // ---- column 1: ||x1||^2 and v0 . x1 (for v0^T v1) in one 2-value reduction
+            T v1[NW], t1 = T(0), t12 = T(0);
+            if (two) {
+              T x1[NW];
+              x1[0] = (lane > jj1) ? pc[1][0] : T(0);
+#pragma unroll
+              for (int q = 1; q < NW; ++q) x1[q] = pc[1][q];
+              T s11 = x1[0] * x1[0], s0v = v0[0] * x1[0];
+#pragma unroll
+              for (int q = 1; q < NW; ++q) { s11 += x1[q] * x1[q]; s0v += v0[q] * x1[q]; }
+              wave_sum2(s11, s0v);
+              const T alpha1 = lane_get(pc[1][0], jj1);
+              T beta1, sc1;
+              if (s11 == T(0)) { beta1 = alpha1; t1 = T(0); sc1 = T(0); }
+              else larfg_scalars(alpha1, s11, beta1, t1, sc1);
+              v1[0] = (lane > jj1) ? x1[0] * sc1 : (lane == jj1 ? T(1) : T(0));
+#pragma unroll
+              for (int q = 1; q < NW; ++q) v1[q] = x1[q] * sc1;
+              t12 = sc1 * s0v + lane_get(v0[0], jj1);  // v1 = sc1 * x1 below row jj1, 1 on it
+              if (lane == jj1) pc[1][0] = beta1;
+            } else {
+#pragma unroll
+              for (int q = 0; q < NW; ++q) v1[q] = T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+              Vs[(lane + 64 * q) * VLD + j] = v0[q];
+              Vs[(lane + 64 * q) * VLD + j + 1] = v1[q];
+            }
+            if (lane == 0) {
+              tau[jj] = t0; taus[jj] = t0;
+              if (two) { tau[jj1] = t1; taus[jj1] = t1; }
+              pairt[owv] = t12;
+            }
+          }
+          lds_barrier();  // the owner's pair (two columns of Vs), its taus and v0^T v1 are visible
+          if (wave_id > owv && j0 + wave_id * 2 < n) {  // waves right of the owner apply H1 H0 to their two columns
+            T v0[NW], v1[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+              v0[q] = Vs[(lane + 64 * q) * VLD + j];
+              v1[q] = Vs[(lane + 64 * q) * VLD + j + 1];
+            }
+            const T t0 = taus[jj], t1 = two ? taus[jj1] : T(0), t12 = pairt[owv];
+            T d4[4] = {v0[0] * pc[0][0], v0[0] * pc[1][0], v1[0] * pc[0][0], v1[0] * pc[1][0]};
+#pragma unroll
+            for (int q = 1; q < NW; ++q) {
+              d4[0] += v0[q] * pc[0][q]; d4[1] += v0[q] * pc[1][q];
+              d4[2] += v1[q] * pc[0][q]; d4[3] += v1[q] * pc[1][q];
+            }
+            wave_sum4(d4);
+            const T a0a = t0 * d4[0], a0b = t0 * d4[1];
+            const T a1a = t1 * (d4[2] - t12 * a0a), a1b = t1 * (d4[3] - t12 * a0b);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+              pc[0][q] -= a0a * v0[q] + a1a * v1[q];
+              pc[1][q] -= a0b * v0[q] + a1b * v1[q];
+            }
+          }
+        } else {
         if (wave_id == owv) {  // wave-uniform: local Householder QR of columns CPW*owv .. CPW*owv + CPW-1
           auto local = [&](auto OC) {
             constexpr int oc = decltype(OC)::value;
@@ -454,6 +417,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             }
           }
         }
+        }
       }
     }
     stamp();
@@ -471,12 +435,19 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         }
       }
     }
-    for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
-      Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
-      if (tid == 0) tau[j0 + j] = T(0);
+    if constexpr (PAIR) {
+      // the whole panel's reflectors to the workspace, transposed (thread = row: 256 contiguous bytes per wave and
+      // store); Vs is complete after the last phase's barrier, unused reflectors are zero columns
+#pragma unroll
+      for (int j = 0; j < PW; ++j) Vt[(int64_t)(j0 + j) * BR + tid] = Vs[tid * VLD + j];
+      if (tid < PW && tid >= nsteps) tau[j0 + tid] = T(0);
+    } else {
+      for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
+        Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
+        if (tid == 0) tau[j0 + j] = T(0);
+      }
     }
     lds_barrier();
-    }
     // (5) S = V^T V over the block (MFMA, K = BR split over the waves), then the triangular factor T
     {
       Acc s = M::zero();
@@ -567,26 +538,6 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   if constexpr (NT > 1) panel(IC<1>{});
   if constexpr (NT > 2) panel(IC<2>{});
   if constexpr (NT > 3) panel(IC<3>{});
-  if constexpr (ROWP) {
-    // R = the upper triangle of the block's first min(rows, n) rows: they live in wave 0's tiles
-    if (wave_id == 0) {
-      T* __restrict__ Ro = p.Rout + bt * p.strideR + (p.top ? 0 : (int64_t)b * n * p.ldr);
-      const int rr = p.top ? kb : n;
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = tm * 16 + M::row(lane, r), col = tn * PW + cl;
-            if (col < n && row < rr) {
-              T rv = (row <= col && row < kb) ? acc[tm][tn][r] : T(0);
-              if constexpr (sizeof(T) == 4) { if (bexp != 0) rv = ldexpf((float)rv, bexp); }
-              Ro[(int64_t)row * p.ldr + col] = rv;
-            }
-          }
-    }
-  }
   lds_barrier();
 }
 
@@ -795,8 +746,7 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 }
 
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
-int g_qr_variant = 2;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 0 column-owning panels (round 1), 1 row-layout panels
-                                // with ds_bpermute shuffles, 2 row-layout panels with DPP / v_permlane (default)
+int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
 struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
   const void* Rm = nullptr;
@@ -828,17 +778,16 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
     const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
     const bool pushed = (l == 0 && pu.Rm);
-    p.safe_xlane = (g_qr_variant == 1);
-#define TTR_QR_LAUNCH(PU, NWV, RP) \
-  hipLaunchKernelGGL((qr_factor_kernel<T, NT, PU, NWV, RP>), grid, dim3(64 * NWV), 0, stream, p)
-    if (g_qr_variant == 0) {
-      if (pl.nw[l] == 8) { if (pushed) TTR_QR_LAUNCH(true, 8, false); else TTR_QR_LAUNCH(false, 8, false); }
-      else { if (pushed) TTR_QR_LAUNCH(true, 4, false); else TTR_QR_LAUNCH(false, 4, false); }
+    if (pl.nw[l] == 8 && g_qr_variant != 0) {
+      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, true>), grid, dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, true>), grid, dim3(512), 0, stream, p);
+    } else if (pl.nw[l] == 8) {
+      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, false>), grid, dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, false>), grid, dim3(512), 0, stream, p);
     } else {
-      if (pl.nw[l] == 8) { if (pushed) TTR_QR_LAUNCH(true, 8, true); else TTR_QR_LAUNCH(false, 8, true); }
-      else { if (pushed) TTR_QR_LAUNCH(true, 4, true); else TTR_QR_LAUNCH(false, 4, true); }
+      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 4, false>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 4, false>), grid, dim3(256), 0, stream, p);
     }
-#undef TTR_QR_LAUNCH
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;

@@ -39,7 +39,7 @@ def qr_variants(B):
     core = torch.randn(B, 64, 64, 64, generator=g, device="cuda")
     P = (Rm[:2].double() @ core[:2].double().reshape(2, 64, -1)).reshape(2, 4096, 64)
     stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
-    for v in (0, 1, 2):
+    for v in (0, 1):
         h.set_knob(h.KNOB_QR_PANEL, v)
         try:
             ms = ev_time(lambda: h.qr_factor_pushed(Rm, core), 5)
@@ -66,7 +66,7 @@ def qr_variants(B):
         except Exception as e:  # noqa: BLE001
             print(json.dumps({"qr_variant": v, "error": repr(e)}), flush=True)
         finally:
-            h.set_knob(h.KNOB_QR_PANEL, 2)
+            h.set_knob(h.KNOB_QR_PANEL, 1)
 
 
 def step_variants(B, steps=3):
@@ -76,7 +76,7 @@ def step_variants(B, steps=3):
     sys.path.insert(0, ROOT)
     import bench
     inp = bench.make_input(B, torch.device("cuda"), seed=1234)
-    for v in (0, 2):
+    for v in (0, 1):
         h.set_knob(h.KNOB_QR_PANEL, v)
         try:
             def step():
@@ -104,11 +104,36 @@ def step_variants(B, steps=3):
         except Exception as e:  # noqa: BLE001
             print(json.dumps({"step_variant": v, "error": repr(e)}), flush=True)
         finally:
-            h.set_knob(h.KNOB_QR_PANEL, 2)
+            h.set_knob(h.KNOB_QR_PANEL, 1)
+
+
+def sweep_kernels(B):
+    """The R2L kernels on the metric's bond shape (64 x 2048 per item): fused kernels vs the generic GEMM they replace."""
+    import torch
+    from tntorch_amd import _hip as h
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M = torch.randn(B, 64, 2048, generator=g, device="cuda")
+    V1 = torch.linalg.qr(torch.randn(B, 64, 64, generator=g, device="cuda"))[0].contiguous()
+    sig = torch.rand(B, 64, generator=g, device="cuda") + 0.5
+    res = {"B": B}
+    res["gemm_gram_ms"] = ev_time(lambda: h.gemm(M, M, transB=True), 5)
+    res["rowgram_ms"] = ev_time(lambda: h.rowgram(M), 5)
+    res["gemm_rotate_plus_gram_ms"] = ev_time(lambda: h.gemm(h.gemm(V1, M, transA=True), h.gemm(V1, M, transA=True), transB=True), 3)
+    res["rotgram_ms"] = ev_time(lambda: h.rowgram(M, V1), 5)
+    res["gemm_project_ms"] = ev_time(lambda: h.gemm(V1[:, :, :32], M, transA=True, rowscale=sig, rowscale_mode=h.SCALE_DIV), 5)
+    res["project_ms"] = ev_time(lambda: h.project(M, V1, V1, sig, 32, True), 5)
+    res["eigh_tridiag_ms"] = None
+    G = h.gemm(M, M, transB=True)
+    res["eigh_tridiag_ms"] = ev_time(lambda: h.eigh_trunc(G, h.EIG_RAW, False, 0.0, 64, abs_floor=h.SOLVER_TRIDIAG), 3)
+    Vt, _, _ = h.eigh_trunc(G, h.EIG_RAW, False, 0.0, 64, abs_floor=h.SOLVER_TRIDIAG)
+    G2 = h.rowgram(M, Vt)
+    res["eigh_live_ms"] = ev_time(lambda: h.eigh_trunc(G2, h.EIG_RAW, False, 0.0, 32, abs_floor=h.SOLVER_JACOBI_LIVE), 3)
+    res["bytes_M"] = M.numel() * 4
+    print(json.dumps({"sweep_kernels": res}), flush=True)
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["micro", "qr", "step"]
+    what = sys.argv[1:] or ["micro", "qr", "sweep", "step"]
     if "micro" in what:
         try:
             microbench()
@@ -116,6 +141,12 @@ if __name__ == "__main__":
             print(json.dumps({"microbench_error": repr(e)}), flush=True)
     if "qr" in what:
         qr_variants(2048)
+    if "sweep" in what:
+        try:
+            sweep_kernels(2048)
+            sweep_kernels(64)
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"sweep_error": repr(e)}), flush=True)
     if "step" in what:
         step_variants(2048)
         step_variants(64)
