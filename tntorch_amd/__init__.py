@@ -12,6 +12,7 @@ from .tensor import *  # noqa: F401,F403
 from .create import *  # noqa: F401,F403
 from .metrics import *  # noqa: F401,F403
 from . import dist_batch  # noqa: F401
+from ._patch import patch  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -38,23 +38,39 @@ def left_unfolding(core: torch.Tensor, batch: bool = False) -> torch.Tensor:
 
 
 def reduce(ts, function, eps=0, rmax=np.iinfo(np.int32).max, algorithm="svd", verbose=False, **kwargs):
-    """Combine a sequence of tensors with ``function`` (e.g. ``operator.add``), rounding every intermediate
-    result (tools.py:460-512): a binary-counter tree, so that operands of similar rank meet."""
+    """Fold a sequence (or generator) of tensors with ``function`` (``operator.add``, ``tn.cat`` ...), rounding after
+    every combination so that no intermediate exceeds ``rmax`` / ``eps`` -- same contract as tools.py:460-512.
+
+    The combinations form a balanced tree built on the fly like a binary counter: ``slots[h]`` holds the rounded result
+    of a complete group of 2**h consecutive elements (or nothing); a new element enters at height 0 and, like a carry,
+    merges upwards while the slot at its height is occupied.  Operands of a merge therefore always cover equally many
+    elements (similar ranks meet), at most log2(len) partial results are alive, and ``function`` always receives the
+    EARLIER group first (order matters for e.g. concatenation).  At the end the remaining groups are merged from the
+    oldest (highest) to the newest.
+    """
     from .round import round as _round
 
-    d = dict()
-    start = time.time()
-    for i, elem in enumerate(ts):
-        if verbose and i % 100 == 0:
-            print("reduce: element {}, time={:g}".format(i, time.time() - start))
-        climb = 0  # for going up the tree
-        while climb in d:
-            elem = _round(function(d[climb], elem, **kwargs), eps=eps, rmax=rmax, algorithm=algorithm)
-            d.pop(climb)
-            climb += 1
-        d[climb] = elem
-    keys = list(d.keys())
-    result = d[keys[0]]
-    for key in keys[1:]:
-        result = _round(function(result, d[key], **kwargs), eps=eps, rmax=rmax, algorithm=algorithm)
+    def merge(older, newer):
+        return _round(function(older, newer, **kwargs), eps=eps, rmax=rmax, algorithm=algorithm)
+
+    slots = []
+    started = time.time()
+    for count, item in enumerate(ts):
+        if verbose and count % 100 == 0:
+            print("reduce: element {}, time={:g}".format(count, time.time() - started))
+        height = 0
+        while height < len(slots) and slots[height] is not None:
+            item = merge(slots[height], item)
+            slots[height] = None
+            height += 1
+        if height == len(slots):
+            slots.append(item)
+        else:
+            slots[height] = item
+    groups = [g for g in reversed(slots) if g is not None]
+    if not groups:
+        raise ValueError("reduce() needs at least one tensor")
+    result = groups[0]
+    for g in groups[1:]:
+        result = merge(result, g)
     return result
