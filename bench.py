@@ -10,10 +10,13 @@ gathers the rounded cores on rank 0 with a single RCCL gather.
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config c3        # BASELINE config C3 (512 dense 32^5 -> rank 8), one line in the same format
+    python bench.py --config c1        # BASELINE config C1 class (dense 64^k -> rank 16, the largest k that fits)
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definition of every field).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,9 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_CORES, MODE, R_IN, R_OUT = 8, 64, 64, 32
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FLOP_PER_TENSOR = 8.72e8   # SURVEY 8d, algorithmic flops of one 64^8 r64->r32 rounding
-BYTES_PER_TENSOR = 2.69e7  # SURVEY 8d, algorithmic bytes (every core read once / written once per sweep)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate (no xf32 on gfx950)
+RIDGE = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # 19.7 flop/B
+FLOP_PER_TENSOR = 8.72e8    # SURVEY 8d, algorithmic flops of one 64^8 r64->r32 rounding
+BYTES_PER_TENSOR = 2.69e7   # SURVEY 8d, algorithmic bytes (every core read once / written once per sweep)
 
 
 def make_input(B, device, seed):
@@ -49,26 +54,71 @@ def make_input(B, device, seed):
     return cores
 
 
-def algorithmic_bytes_per_tensor():
-    """Bytes each kernel kind must move per tensor GIVEN ITS INTERFACE (float32, M workload): operands read
-    once, results written once.  (SURVEY 8d's 2.69e7 B/tensor is the fully fused lower bound for the whole
-    sweep and is reported separately as `whole_sweep_hbm_frac`.)"""
+def kernel_model():
+    """Algorithmic work of every kernel kind PER TENSOR of the metric workload (float32): `flops` = the arithmetic the
+    kernel's algorithm performs, `bytes` = what it must move given its interface (operands read once, results written
+    once, including the reflectors / T factors / R a factorisation leaves behind).  DESIGN.md section 6 derives them."""
     s = 4
-    mid = R_IN * MODE * R_IN
-    first = 1 * MODE * R_IN
-    last = R_IN * MODE * 1
-    qr_factor = s * (first + (N_CORES - 2) * mid)                     # every core but the last enters one QR
-    qr_apply = s * (1 * MODE * R_OUT + (N_CORES - 2) * R_IN * MODE * R_OUT)  # Q [U sigma; 0]: (R I) x 32 per core
-    push = s * (2 * (N_CORES - 2) * mid + 2 * last + (N_CORES - 1) * R_IN * R_IN)    # R @ next core: read + write
-    n_big = MODE * R_OUT                                              # right unfolding of a middle core: 64 x 2048
-    per_bond = s * (R_IN * n_big                                      # Gram(M)
-                    + 2 * R_IN * n_big                                # V1^T M: read + write
-                    + R_IN * n_big                                    # Gram(M1)
-                    + R_IN * n_big + R_OUT * n_big)                   # projection: read M1, write V^T
-    last_bond = s * (4 * R_IN * MODE + R_IN * MODE + R_OUT * MODE)
-    gemm = push + (N_CORES - 2) * per_bond + last_bond
-    eigh = 2 * (N_CORES - 1) * s * 2 * R_IN * R_IN                    # two Jacobi passes per bond: G in, V out
-    return {"qr_factor": qr_factor, "qr_apply": qr_apply, "gemm": gemm, "eigh": eigh}
+    n, I, Rr, ro = R_IN, MODE, R_IN, R_OUT
+    mid = N_CORES - 2                                  # cores 1..6: pushed 4096 x 64 factorisations
+    m = Rr * I
+    hh = lambda rows, cols: 2.0 * rows * cols * cols - 2.0 * cols ** 3 / 3.0      # Householder QR (factor only)
+    leaf_blocks, leaf_rows = 8, 512
+    # factor: level 0 = 8 blocks of 512 x 64 (+ the fused push R @ core), level 1 = one 512 x 64 block of stacked R's
+    f_flops = mid * (leaf_blocks * hh(leaf_rows, n) + hh(leaf_blocks * n, n) + 2.0 * Rr * Rr * I * n) + hh(I, n)
+    f_bytes = mid * s * (Rr * I * n            # core read
+                         + m * n               # reflectors written (level 0)
+                         + 2 * leaf_blocks * n * n + leaf_blocks * n * n   # stacked R written + read, level-1 reflectors
+                         + 9 * 4 * 256 + n * n) + s * (I * n * 2)
+    # apply: Q [C; 0] with C = U sigma (64 x 32): per level W = V^T C and C += V W2 over all reflector rows
+    a_flops = mid * 4.0 * (m + leaf_blocks * n) * n * ro + 4.0 * I * n * ro
+    a_bytes = mid * s * (m * n + leaf_blocks * n * n + m * ro + 2 * leaf_blocks * n * ro) + s * (I * n + I * ro)
+    nb = I * ro                                        # right unfolding of a middle core: 64 x 2048
+    bonds = [(Rr, nb)] * (N_CORES - 2) + [(Rr, I)]     # bond N-1 is 64 x 64
+    sym = 10.0 / 16.0                                  # the Gram kernels compute 10 of the 16 tiles
+    rg_flops = sum(2.0 * R * R * c * sym for R, c in bonds)
+    rg_bytes = sum(s * R * c for R, c in bonds)
+    ro_flops = sum(2.0 * R * R * c * (1 + sym) for R, c in bonds)
+    pj_flops = sum(2.0 * R * ro * c for R, c in bonds)
+    pj_bytes = sum(s * (R + ro) * c for R, c in bonds)
+    eig_bytes = 2 * (N_CORES - 1) * s * 2 * Rr * Rr
+    eig_flops = 2 * (N_CORES - 1) * 9.0 * Rr ** 3      # SURVEY 8d's 9 m^3 per eigenproblem
+    gemm_flops = 2.0 * Rr * Rr * I                     # last-core push
+    gemm_bytes = s * (Rr * Rr + 2 * Rr * I)
+    return {
+        "qr_factor": {"flops": f_flops, "bytes": f_bytes},
+        "qr_apply": {"flops": a_flops, "bytes": a_bytes},
+        "rowgram": {"flops": rg_flops, "bytes": rg_bytes},
+        "rotgram": {"flops": ro_flops, "bytes": rg_bytes},
+        "project": {"flops": pj_flops, "bytes": pj_bytes},
+        "eigh": {"flops": eig_flops, "bytes": eig_bytes},
+        "gemm": {"flops": gemm_flops, "bytes": gemm_bytes},
+    }
+
+
+def source_sha():
+    """Hash of the kernel sources: PMC numbers in profiles/pmc_latest.json only describe the build they were taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tntorch_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_latest.json"
+    try:
+        pmc = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable pmc_latest.json: {e!r}"
+    if pmc.get("source_sha") != source_sha():
+        print("bench.py: WARNING: profiles/pmc_latest.json was collected from a different kernel build "
+              f"({pmc.get('source_sha')} != {source_sha()}): `traffic` / `mfma_util` are reported as null", file=sys.stderr)
+        return None, "stale: collected from a different kernel build"
+    return pmc, None
 
 
 def cpu_baseline(budget_s=25.0):
@@ -124,6 +174,41 @@ def cpu_baseline(budget_s=25.0):
     }
 
 
+def parity_check(inp, out, items):
+    """Items of the LAST timed step against the oracle's default algorithm (LAPACK gesdd, round.py:96): identical ranks,
+    ||ours - oracle|| / ||oracle|| through float64 TT inner products (tests/test_gpu_parity.py states the 2e-5 bound)."""
+    import math
+
+    import oracle
+
+    worst, ranks_ok = 0.0, True
+    for i in items:
+        one = [c[i].cpu() for c in inp]
+        ref = oracle.round_tt(one, rmax=R_OUT, algorithm="svd")
+        ours = [c[i].cpu() for c in out.cores]
+        ranks_ok = ranks_ok and oracle.tt_ranks(ours) == oracle.tt_ranks(ref)
+        a = [c.double() for c in ours]
+        b = [c.double() for c in ref]
+        aa, bb, ab = oracle.tt_dot(a, a), oracle.tt_dot(b, b), oracle.tt_dot(a, b)
+        worst = max(worst, math.sqrt(max((aa + bb - 2 * ab).item(), 0.0) / bb.item()))
+    return {"items": list(items), "rel_err_vs_oracle_svd": worst, "ranks_identical": ranks_ok, "bound": 2e-5,
+            "ok": bool(ranks_ok and worst <= 2e-5)}
+
+
+def timed_steps(step, drain, fence, warmup, steps):
+    for _ in range(warmup):
+        step()
+    drain()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    gathered = drain()  # every step's gather has completed inside the timed region
+    fence()
+    return time.perf_counter() - t0, out, gathered
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,11 +217,18 @@ def main():
     ap.add_argument("--batch", type=int, default=2048,
                     help="tensors per GPU per step (2048 = eight single-wave 64x64 eigenproblems per CU; 13 GB of cores)")
     ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
+    ap.add_argument("--config", default="metric", choices=["metric", "c1", "c3"],
+                    help="metric (default): the headline workload; c1 / c3: BASELINE's dense configs (tools/bench_dense.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch / single-tensor extra measurements")
     ap.add_argument("--single-stream", action="store_true",
                     help="issue the timed region on one stream too (for rocprofv3 kernel traces: with sub-batch "
                          "streams the traced kernel durations overlap)")
     args = ap.parse_args()
+    if args.config != "metric":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_dense
+        return bench_dense.main(args)
 
     import torch.distributed as dist
 
@@ -153,9 +245,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    nccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        nccl_ranks = dist.get_world_size()
     _hip.lib()  # fail loudly if the kernels are not built
     from tntorch_amd import _hipops
     if args.single_stream:
@@ -191,16 +285,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    gathered = drain()  # every step's gather has completed inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, out, gathered = timed_steps(step, drain, fence, args.warmup, args.steps)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -224,34 +309,45 @@ def main():
     _hipops.STREAM_CHUNKS_ENABLED = not args.single_stream
 
     if rank == 0:
-        if out is not None:
-            assert list(out.ranks_tt) == [1] + [R_OUT] * (N_CORES - 1) + [1], out.ranks_tt
+        assert list(out.ranks_tt) == [1] + [R_OUT] * (N_CORES - 1) + [1], out.ranks_tt
         tensors = B * world * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         cores_per_s = tensors * N_CORES / elapsed
-        abytes = algorithmic_bytes_per_tensor()
-        kinds = {k: v for k, v in prof.items() if v["launches"] > 0 and k in abytes}
-        dom = max(kinds, key=lambda k: kinds[k]["ms"])
-        launches = kinds[dom]["launches"]
-        avg_launch_ms = kinds[dom]["ms"] / launches
-        bytes_per_launch = abytes[dom] * B * args.steps / launches
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-                traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is not None and pmc.get("_batch"):
-                    traffic = traffic * B / pmc["_batch"]
-            except Exception:
-                traffic = None
-        per_kind = {
-            k: {"ms_per_step": v["ms"] / args.steps,
-                "achieved_GBs": abytes[k] * B * args.steps / (v["ms"] * 1e-3) / 1e9,
-                "frac_of_hbm_peak": abytes[k] * B * args.steps / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            for k, v in kinds.items()
-        }
+        model = kernel_model()
+        pmc, pmc_note = load_pmc()
+        per_kind = {}
+        for k, v in prof.items():
+            if v["launches"] == 0 or k not in model:
+                continue
+            sec = v["ms"] * 1e-3
+            fl = model[k]["flops"] * B * args.steps
+            by = model[k]["bytes"] * B * args.steps
+            ai = fl / by
+            bound = "mfma" if ai > RIDGE else "hbm"
+            tf, gbs = fl / sec / 1e12, by / sec / 1e9
+            entry = {
+                "ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                "flops_per_step": model[k]["flops"] * B, "bytes_per_step": model[k]["bytes"] * B,
+                "arithmetic_intensity": ai, "bound": bound,
+                "achieved_TFLOPs": tf, "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TF,
+                "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                "frac": tf / MFMA_F32_PEAK_TF if bound == "mfma" else gbs / HBM_PEAK_GBS,
+            }
+            if pmc and k in pmc:
+                sc = B / pmc.get("_batch", B)
+                if pmc[k].get("hbm_bytes_per_step") is not None:
+                    entry["traffic_bytes_per_step"] = pmc[k]["hbm_bytes_per_step"] * sc
+                if pmc[k].get("mfma_util") is not None:
+                    entry["mfma_util"] = pmc[k]["mfma_util"]
+            per_kind[k] = entry
+        dom = max(per_kind, key=lambda k: per_kind[k]["ms_per_step"])
+        d = per_kind[dom]
+        launches = prof[dom]["launches"]
+        if d["bound"] == "mfma":
+            ach, peak, unit = d["achieved_TFLOPs"], MFMA_F32_PEAK_TF, "TFLOP/s"
+        else:
+            ach, peak, unit = d["achieved_GBs"], HBM_PEAK_GBS, "GB/s"
+        traffic = d.get("traffic_bytes_per_step")
         res = {
             "metric": "TT rounding 64^8 rank-64 -> rank-32 (round_tt rmax=32), cores/s",
             "value": cores_per_s,
@@ -272,28 +368,55 @@ def main():
                 "streams_per_gpu": 1 if args.single_stream else 2,
                 "parallelism": f"batch-sharded x{world}, one async RCCL gather of packed cores per step (overlapped with the next step)" if world > 1 else "single GPU",
             },
+            "nccl_ranks": nccl_ranks,
             "tensors_per_s": tensors / elapsed,
             "gflops": FLOP_PER_TENSOR * tensors / elapsed / 1e9,
+            "whole_sweep_frac_of_mfma_f32_peak": FLOP_PER_TENSOR * tensors / elapsed / 1e12 / MFMA_F32_PEAK_TF,
             "whole_sweep_hbm_frac": BYTES_PER_TENSOR * tensors / elapsed / 1e9 / HBM_PEAK_GBS,
             "roofline": {
                 "kernel": dom,
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "avg_launch_ms": avg_launch_ms,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bound": d["bound"],
+                "achieved": ach,
+                "peak": peak,
+                "unit": unit,
+                "frac": ach / peak,
+                "traffic": None if traffic is None else traffic * args.steps / launches,
+                "traffic_note": pmc_note if traffic is None else "FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_latest.json, same kernel build)",
+                "mfma_util": d.get("mfma_util"),
+                "avg_launch_ms": prof[dom]["ms"] / launches,
+                "algorithmic_flops_per_launch": d["flops_per_step"] * args.steps / launches,
+                "algorithmic_bytes_per_launch": d["bytes_per_step"] * args.steps / launches,
+                "arithmetic_intensity": d["arithmetic_intensity"],
+                "ridge_flop_per_byte": RIDGE,
                 "launches": launches,
             },
             "roofline_per_kernel": per_kind,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
         }
+        try:
+            res["parity"] = parity_check(inp, out, (0, B - 1) if B > 1 else (0,))
+        except Exception as e:  # noqa: BLE001
+            res["parity"] = {"ok": False, "error": repr(e)}
+        if world == 1 and not args.no_extras:
+            extras = {}
+            for Bx, label, st in ((64, "batch_64", 10), (1, "single_tensor", 20)):
+                if Bx >= B:
+                    continue
+                small = [c[:Bx].contiguous() for c in inp]
+
+                def sstep(small=small):
+                    t = tn.Tensor(small, batch=True)
+                    t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+                    return t
+                el, _, _ = timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)
+                extras[label] = {"tensors_per_step": Bx, "ms_per_step": el / st * 1e3, "cores_per_s": Bx * N_CORES * st / el}
+            res["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_best"] = cores_per_s / cb["value"]
+            if "extras" in res and "single_tensor" in res["extras"]:
+                res["extras"]["single_tensor"]["speedup_vs_cpu_best"] = res["extras"]["single_tensor"]["cores_per_s"] / cb["value"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -286,7 +286,8 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
 #define TTR_PROF_MISC 4
 #define TTR_PROF_ROTGRAM 5
 #define TTR_PROF_PROJECT 6
-#define TTR_PROF_NKINDS 7
+#define TTR_PROF_ROWGRAM 7
+#define TTR_PROF_NKINDS 8
 /* Diagnostics: when set to a device buffer of >= 64 int64, block (0,0) of every level-0 QR factor launch writes
  * its s_memtime stamps at phase boundaries there.  NULL disables. */
 int ttr_debug_set_qr_stamps(void* device_buffer);

@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
-PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc", "rotgram", "project")
+PROF_KINDS = ("gemm", "qr_factor", "qr_apply", "eigh", "misc", "rotgram", "project", "rowgram")
 
 _lib = None
 

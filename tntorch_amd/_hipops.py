@@ -78,6 +78,10 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     # an item 1e-6 times smaller than its neighbours is not swamped by their noise level.
     A, a_exp = _hip.pow2_normalize(A)
     delta = 8.0 * torch.finfo(A.dtype).eps / math.sqrt(max(1, m * n))
+    # (an all-zero item keeps exponent 0: its perturbation is scaled down by 1e-20 -- still generic directions for the
+    # panels, the QR kernel factors every block at its own exponent, but R comes back at 1e-28 instead of 1e-8.  A
+    # [Bt]-element mask: the only torch arithmetic here.)
+    live = torch.sign(_hip.norm(A.reshape(Bt, -1))).clamp_min(1e-20)
     gen = torch.Generator(device=A.device)
     for j0 in range(0, n, pw):
         j1 = min(j0 + pw, n)
@@ -85,8 +89,8 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         W = A[:, :, j0:j1].contiguous()
         gen.manual_seed(0x5EED + j0)
         noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
-        eye = torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous()
-        _hip.gemm_axpby(noise, eye, W, delta, 1.0)             # W += delta * noise
+        eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(), scale=live)
+        _hip.gemm_axpby(noise, eye, W, delta, 1.0)             # W += delta * noise (zero items: += 0)
         if j0 == 0:
             Qj, Rjj = _hip.qr(W)
         else:

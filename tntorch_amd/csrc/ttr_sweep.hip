@@ -6,7 +6,7 @@
 //                                                    never written -- it only exists 16 columns at a time in registers)
 //   ttr_project   right = diag(1/sigma) (V1 V2r)^T M,  left = (V1 V2r) diag(sigma)                          round.py:163-172
 //
-// All three stream M once, 16 columns per wave and step, and keep every intermediate in MFMA accumulator registers:
+// All three stream M once, 16 (projection: 32) columns per wave and step, and keep every intermediate in MFMA accumulator registers:
 //   * the rotated 16-column slab is computed TRANSPOSED (slab^T = M_c^T V1: A operand = 16 x 4 pieces of M read straight
 //     from global memory, B operand = V1 from LDS), which leaves it in the accumulator layout
 //     lane (g, cl), register r  <->  slab[row 16 t + cl][column 4 g + r];
@@ -51,6 +51,26 @@ __host__ __device__ inline void split_range(int64_t chunks, int nsplit, int spli
   c1 = c0 + per < chunks ? c0 + per : chunks;
 }
 
+// N consecutive elements with one (or two) wide loads when the caller established the alignment, element-wise otherwise
+template <typename T, int N>
+struct Pack {
+  T v[N];
+};
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> load_pack(const T* __restrict__ p, bool aligned, int64_t valid) {
+  Pack<T, N> out;
+  if (aligned && valid >= N) {
+    typedef T VT __attribute__((ext_vector_type(N)));
+    const VT x = *reinterpret_cast<const VT*>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out.v[i] = x[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out.v[i] = (i < valid) ? p[i] : T(0);
+  }
+  return out;
+}
+
 // ---------------------------------------------------------------- Gram matrix of the (rotated) rows
 template <typename T, bool IDENT>
 __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
@@ -76,34 +96,7 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
   Acc G[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) G[i] = M::zero();
-  int64_t cb, ce;
-  split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
-  for (int64_t c = cb + wave; c < ce; c += 4) {
-    const int64_t c0 = c * 16;
-    Acc mw[4];
-    if constexpr (IDENT) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * t + cl;
-          const int64_t col = c0 + M::row(lane, r);
-          mw[t][r] = (row < R && col < p.n) ? Mp[(int64_t)row * p.ldm + col] : T(0);
-        }
-    } else {
-      T a[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int k = 4 * ks + g;
-        a[ks] = (k < R && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        mw[t] = M::zero();
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) mw[t] = M::mma(a[ks], Vl[(4 * ks + g) * KLD + 16 * t + cl], mw[t]);
-      }
-    }
+  auto gram_update = [&](const Acc (&mw)[4]) {
     int idx = 0;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
@@ -113,6 +106,47 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
         for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
         ++idx;
       }
+  };
+  if constexpr (IDENT) {
+    // 16 columns per step: lane (g, cl) register r <-> M[16 t + cl][c0 + 4 g + r] (any assignment of the 16 columns to
+    // (g, r) serves the Gram sum): four consecutive elements, one 16-byte load per row tile
+    const bool al = ((p.ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0);
+    int64_t cb, ce;
+    split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
+    for (int64_t c = cb + wave; c < ce; c += 4) {
+      const int64_t col = c * 16 + 4 * g;
+      Acc mw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = 16 * t + cl;
+        const Pack<T, 4> x = load_pack<T, 4>(Mp + (int64_t)row * p.ldm + col, al, row < R ? p.n - col : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[t][r] = x.v[r];
+      }
+      gram_update(mw);
+    }
+  } else {
+    // 16 columns per step; A operand = 16 x 4 pieces of M straight from global memory (four 64-byte row segments per
+    // load).  The kernel runs at ~80 % of the fp32 MFMA rate like this (measured): wider loads only cost registers.
+    int64_t cb, ce;
+    split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
+    for (int64_t c = cb + wave; c < ce; c += 4) {
+      const int64_t c0 = c * 16;
+      T a[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + g;
+        a[ks] = (k < R && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
+      }
+      Acc mw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mw[t] = M::zero();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) mw[t] = M::mma(a[ks], Vl[(4 * ks + g) * KLD + 16 * t + cl], mw[t]);
+      }
+      gram_update(mw);
+    }
   }
   // reduce the four waves' partial tiles and write the block's partial Gram matrix (both triangles)
   __syncthreads();  // Vl is dead: smem becomes the reduction buffer
@@ -141,67 +175,113 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
-  __shared__ __attribute__((aligned(16))) T Ul[64 * KLD];  // U = V1 V2[:, :ro] as [k][i] (i = output row), zero padded
+  constexpr int V1LD = 66;  // [k][m]: A-operand reads (16 k x 2 m per 32 lanes: words 66 cl + g) hit 32 banks
+  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];  // V2[:, :ro] as [m][i]; later U = V1 V2[:, :ro] as [k][i] (zero padded)
+  T* Ul = V2l;
+  __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];
+  __shared__ T isg[64];  // 1 / sigma of the output rows (TTR_SCALE_DIV semantics: 0 below the smallest normal), or 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
   const int64_t b = blockIdx.y;
   const int split = blockIdx.x;
   const T* __restrict__ Mp = p.M + b * p.strideM;
   const int R = p.R, ro = p.ro;
+  const int nt = (ro + 15) / 16;
   const T* __restrict__ V2 = p.V2 + b * p.strideV2;
   const T* __restrict__ sg = p.sigma ? p.sigma + b * p.stride_sigma : nullptr;
-  {
-    const T* __restrict__ V1 = p.V1 ? p.V1 + b * p.strideV1 : nullptr;
-    T* __restrict__ Lo = (p.left && split == 0) ? p.left + b * p.strideL : nullptr;
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-      const int k = idx >> 6, i = idx & 63;
-      T u = T(0);
-      if (k < R && i < ro) {
-        if (V1) {
-          for (int m = 0; m < R; ++m) u += V1[(int64_t)k * p.ldv1 + m] * V2[(int64_t)m * p.ldv2 + i];
-        } else {
-          u = V2[(int64_t)k * p.ldv2 + i];
-        }
-        if (Lo) Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? u * sg[i] : u;
-      }
-      Ul[k * KLD + i] = u;
-    }
-    __syncthreads();
+  T* __restrict__ Lo = (p.left && split == 0) ? p.left + b * p.strideL : nullptr;
+  // ---- prologue: U = V1 V2[:, :ro] on the matrix cores (or U = V2[:, :ro]); split 0 also emits left = U diag(sigma)
+  for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+    const int m = idx >> 6, i = idx & 63;
+    V2l[m * KLD + i] = (m < R && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
   }
-  const int nt = (ro + 15) / 16;
-  int64_t cb, ce;
-  split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
-  T* __restrict__ Ro = p.right + b * p.strideR;
-  T rs[4][4];  // 1 / sigma of this lane's output rows
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * t + M::row(lane, r);
-      T s = T(1);
-      if (p.scale_right && sg && row < ro) {
-        const T x = sg[row];
-        s = (fabs((double)x) < (double)Num<T>::tiny()) ? T(0) : T(1) / x;  // TTR_SCALE_DIV semantics
-      }
-      rs[t][r] = s;
+  if (tid < 64) {
+    T sc = T(1);
+    if (p.scale_right && sg && tid < ro) {
+      const T x = sg[tid];
+      sc = (fabs((double)x) < (double)Num<T>::tiny()) ? T(0) : T(1) / x;
     }
+    isg[tid] = sc;
+  }
+  if (p.V1) {
+    const T* __restrict__ V1 = p.V1 + b * p.strideV1;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, m = idx & 63;
+      V1l[k * V1LD + m] = (k < R && m < R) ? V1[(int64_t)k * p.ldv1 + m] : T(0);
+    }
+  }
+  __syncthreads();
+  {
+    const int tk = wave;  // this wave's 16 rows k of U
+    Acc ureg[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      ureg[ti] = M::zero();
+      if (ti < nt) {
+        if (p.V1) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+            ureg[ti] = M::mma(V1l[(16 * tk + cl) * V1LD + 4 * ks + g], V2l[(4 * ks + g) * KLD + 16 * ti + cl], ureg[ti]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ureg[ti][r] = V2l[(16 * tk + M::row(lane, r)) * KLD + 16 * ti + cl];
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading V2l: U takes its place
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * tk + M::row(lane, r), i = 16 * ti + cl;
+        Ul[k * KLD + i] = ureg[ti][r];
+        if (Lo && ti < nt && k < R && i < ro) Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? ureg[ti][r] * sg[i] : ureg[ti][r];
+      }
+  }
+  __syncthreads();
+  // ---- main loop: 32 columns per step as two interleaved 16-column slabs (columns c0 + 2 i + u): 8-byte loads of M
+  // (whole 128-byte lines per 16 lanes) and 8-byte stores of the result
+  T* __restrict__ Ro = p.right + b * p.strideR;
+  const bool al = ((p.ldm & 1) == 0) && ((p.ldr & 1) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (2 * sizeof(T) - 1)) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(Ro) & (2 * sizeof(T) - 1)) == 0);
+  int64_t cb, ce;
+  split_range((p.n + 31) / 32, p.nsplit, split, cb, ce);
   for (int64_t c = cb + wave; c < ce; c += 4) {
-    const int64_t c0 = c * 16;
-    T bm[16];
+    const int64_t col = c * 32 + 2 * cl;
+    T bm[2][16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const int k = 4 * ks + g;
-      bm[ks] = (k < R && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
+      const Pack<T, 2> x = load_pack<T, 2>(Mp + (int64_t)k * p.ldm + col, al, k < R ? p.n - col : 0);
+      bm[0][ks] = x.v[0];
+      bm[1][ks] = x.v[1];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t < nt) {
-        Acc acc = M::zero();
+        Acc acc0 = M::zero(), acc1 = M::zero();
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = M::mma(Ul[(4 * ks + g) * KLD + 16 * t + cl], bm[ks], acc);
+        for (int ks = 0; ks < 16; ++ks) {
+          const T af = Ul[(4 * ks + g) * KLD + 16 * t + cl];
+          acc0 = M::mma(af, bm[0][ks], acc0);
+          acc1 = M::mma(af, bm[1][ks], acc1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * t + M::row(lane, r);
-          if (row < ro && c0 + cl < p.n) Ro[(int64_t)row * p.ldr + c0 + cl] = acc[r] * rs[t][r];
+          if (row < ro && col < p.n) {
+            const T sc = isg[row];
+            T* dst = Ro + (int64_t)row * p.ldr + col;
+            if (al && col + 2 <= p.n) {
+              typedef T VT __attribute__((ext_vector_type(2)));
+              VT o;
+              o[0] = acc0[r] * sc;
+              o[1] = acc1[r] * sc;
+              *reinterpret_cast<VT*>(dst) = o;
+            } else {
+              dst[0] = acc0[r] * sc;
+              if (col + 1 < p.n) dst[1] = acc1[r] * sc;
+            }
+          }
         }
       }
     }
@@ -209,9 +289,9 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
 }
 
 static int pick_split(int64_t n, int64_t batch) {
-  const int64_t chunks = (n + 15) / 16;
+  const int64_t chunks = (n + 31) / 32;        // (the projection walks 32 columns per step and wave)
   int64_t want = (2048 + batch - 1) / batch;  // aim at >= 2048 workgroups on the 256 CUs ...
-  int64_t maxs = chunks / 16;                 // ... but keep >= 4 steps per wave
+  int64_t maxs = chunks / 8;                  // ... but keep >= 2 steps per wave
   if (maxs < 1) maxs = 1;
   int64_t s = want < maxs ? want : maxs;
   if (s > 64) s = 64;
@@ -227,7 +307,7 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.G = (T*)G; p.nsplit = (int)nsplit;
-  ProfScope prof(V1 ? TTR_PROF_ROTGRAM : TTR_PROF_GEMM, stream);
+  ProfScope prof(V1 ? TTR_PROF_ROTGRAM : TTR_PROF_ROWGRAM, stream);
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
     SweepArgs<T> q = p;
