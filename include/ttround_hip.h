@@ -248,6 +248,28 @@ int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
                 void* left, int64_t ldl, int64_t strideL, void* stream);
 
 /*
+ * The same fused kernels for TALL matrices (rows x n, n <= 64, row-major): the unfoldings a dense right-to-left TT-SVD
+ * truncates first -- prod(I_1..I_{N-1}) rows, I_N columns, the whole input tensor in bytes (tensor.py:401-408 via
+ * round.py:101-135 with the Gram matrix on the short side).  The contraction runs over the rows, 16 per wave and step.
+ *   ttr_colgram     G = M^T M   (V1 = NULL)   or   G = (M V1)^T (M V1): the rotated matrix is never written
+ *                   (`workspace`: split-K partials, size from ttr_colgram_workspace_bytes; G is the reduced n x n matrix)
+ *   ttr_colproject  left = M U [diag(1/sigma)] (rows x ro),  right = [diag(sigma)] U^T (ro x n),  U = V1 V2[:, :ro]
+ *                   (left_ortho = 1: the scalings in brackets, round.py:173-178; 0: round.py:179-182)
+ * A 'svd' truncation of such an unfolding therefore reads it three times and writes only ro / n of its size.
+ */
+int64_t ttr_colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch);
+int ttr_colgram(int dtype, int64_t rows, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* workspace, int64_t workspace_bytes,
+                void* stream);
+int ttr_colproject(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch,
+                   const void* M, int64_t ldm, int64_t strideM,
+                   const void* V1, int64_t ldv1, int64_t strideV1,
+                   const void* V2, int64_t ldv2, int64_t strideV2,
+                   const void* sigma, int64_t stride_sigma, int left_ortho,
+                   void* left, int64_t ldl, int64_t strideL,
+                   void* right, int64_t ldr, int64_t strideR, void* stream);
+
+/*
  * Exact power-of-two normalisation, one launch: e[b] = binary exponent of ||x[b]|| (0 for a zero / non-finite norm),
  * out[b] = x[b] * 2^-e[b], and, when `expo_acc` is given, expo_acc[b] += e[b].  (`out` may alias `x`; out = NULL:
  * exponents only.)

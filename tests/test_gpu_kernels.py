@@ -525,3 +525,32 @@ def test_orth_fixup(dt, columns):
     assert torch.equal(Xd[0], before[0])                                   # nothing dead: untouched, bit for bit
     live = out[1, :9] if True else None
     assert (live - X[1, :9]).abs().max() < t                               # live vectors are never modified
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,n,B", [(4096, 64, 2), (100000, 32, 1), (1000, 37, 3), (33, 5, 2), (7, 1, 1), (300000, 64, 1), (64, 64, 40)])
+def test_colsweep_gram_project(dt, rows, n, B):
+    """ttr_colgram / ttr_colproject (tall matrices, contraction over the rows) against float64 torch."""
+    h = _hip()
+    g = torch.Generator().manual_seed(rows + n)
+    M = torch.randn(B, rows, n, generator=g, dtype=torch.float64).to(dt)
+    V1 = torch.linalg.qr(torch.randn(B, n, n, generator=g, dtype=torch.float64))[0].to(dt)
+    V2 = torch.linalg.qr(torch.randn(B, n, n, generator=g, dtype=torch.float64))[0].to(dt)
+    sig = (torch.rand(B, n, generator=g, dtype=torch.float64) + 0.5).to(dt)
+    Md, V1d, V2d = M.double(), V1.double(), V2.double()
+    t = tol(dt, 2e-5, 1e-12)
+    G = h.colgram(M.cuda()).cpu().double()
+    Gr = Md.transpose(1, 2) @ Md
+    assert (G - Gr).abs().max() / Gr.abs().max() < t
+    G2 = h.colgram(M.cuda(), V1.cuda()).cpu().double()
+    Mw = Md @ V1d
+    G2r = Mw.transpose(1, 2) @ Mw
+    assert (G2 - G2r).abs().max() / G2r.abs().max() < t
+    ro = max(1, n // 2)
+    U = V1d @ V2d[:, :, :ro]
+    left, right = h.colproject(M.cuda(), V1.cuda(), V2.cuda(), sig.cuda(), ro, left_ortho=True)
+    assert (left.cpu().double() - (Md @ U) / sig.double()[:, None, :ro]).abs().max() / Md.abs().max() < 4 * t
+    assert (right.cpu().double() - U.transpose(1, 2) * sig.double()[:, :ro, None]).abs().max() < t
+    left, right = h.colproject(M.cuda(), None, V2.cuda(), sig.cuda(), ro, left_ortho=False)
+    assert (left.cpu().double() - Md @ V2d[:, :, :ro]).abs().max() / Md.abs().max() < 4 * t
+    assert (right.cpu().double() - V2d[:, :, :ro].transpose(1, 2)).abs().max() < t

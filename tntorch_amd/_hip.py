@@ -94,6 +94,16 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_colgram_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "ttr_colgram": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_colproject": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+    ),
     "ttr_pow2_normalize": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ttr_scale_batch": (
         c_int,
@@ -540,6 +550,60 @@ def project(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma
                          int(bool(scale_right)), right.data_ptr(), n, ro * n,
                          left.data_ptr() if left is not None else None, ro, R * ro, _stream()), "ttr_project")
     return right, left
+
+
+def colsweep_fused_ok(M: torch.Tensor) -> bool:
+    """The fused tall-matrix kernels (column Gram / rotated Gram / projection) hold up to 64 columns."""
+    return M.shape[2] <= 64
+
+
+@_on_device
+def colgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[batch, n, n] = M^T M (V1 None) or (M V1)^T (M V1) for a tall M [batch, rows, n], n <= 64 (ttr_colgram)."""
+    L = lib()
+    dt = dtype_code(M.dtype)
+    M, ldm, sM = _mat(M)
+    batch, rows, n = M.shape
+    G = torch.empty((batch, n, n), dtype=M.dtype, device=M.device)
+    if batch == 0:
+        return G
+    wsb = L.ttr_colgram_workspace_bytes(dt, rows, n, batch)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=M.device) if wsb > 0 else None
+    v1p, ldv, sV = None, 0, 0
+    if V1 is not None:
+        V1, ldv, sV = _mat(V1)
+        assert V1.shape == (batch, n, n)
+        v1p = V1.data_ptr()
+    _check(L.ttr_colgram(dt, rows, n, batch, M.data_ptr(), ldm, sM, v1p, ldv, sV, G.data_ptr(),
+                         ws.data_ptr() if ws is not None else None, wsb, _stream()), "ttr_colgram")
+    return G
+
+
+@_on_device
+def colproject(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma: Optional[torch.Tensor], ro: int,
+               left_ortho: bool):
+    """left [batch, rows, ro] = M U [/ sigma], right [batch, ro, n] = [sigma] U^T with U = V1 V2[:, :ro] (ttr_colproject)."""
+    L = lib()
+    dt = dtype_code(M.dtype)
+    M, ldm, sM = _mat(M)
+    batch, rows, n = M.shape
+    V2, ldv2, sV2 = _mat(V2)
+    v1p, ldv1, sV1 = None, 0, 0
+    if V1 is not None:
+        V1, ldv1, sV1 = _mat(V1)
+        v1p = V1.data_ptr()
+    left = torch.empty((batch, rows, ro), dtype=M.dtype, device=M.device)
+    right = torch.empty((batch, ro, n), dtype=M.dtype, device=M.device)
+    if batch == 0:
+        return left, right
+    sp, ss = None, 0
+    if sigma is not None:
+        sigma = sigma.contiguous()
+        sp, ss = sigma.data_ptr(), sigma.shape[-1]
+    _check(L.ttr_colproject(dt, rows, n, ro, batch, M.data_ptr(), ldm, sM, v1p, ldv1, sV1, V2.data_ptr(), ldv2, sV2, sp, ss,
+                            int(bool(left_ortho)), left.data_ptr(), ro, rows * ro, right.data_ptr(), n, ro * n, _stream()),
+           "ttr_colproject")
+    return left, right
 
 
 @_on_device

@@ -330,6 +330,27 @@ def truncate(
             _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
         return Truncation(left, None, right, r)
 
+    if not left_side and _hip.colsweep_fused_ok(M):
+        # Tall matrix with up to 64 columns (the first, largest steps of a dense right-to-left TT-SVD): the same fused
+        # kernels with the contraction over the rows.  The unfolding is read three times ('eig': twice) and only the
+        # carry (r / n of its size) is written -- no rotated copy of the input.
+        V1 = None
+        if algorithm == "svd":
+            V1, _, _ = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V, sig, info = _hip.eigh_trunc(_hip.colgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_JACOBI_LIVE)
+        else:
+            V, sig, info = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_REF, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_TRIDIAG)
+        r = _select_rank(info, batch, rmax, k)
+        if r == 0:
+            return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
+                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True)
+        left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
+        if algorithm == "svd" and left_ortho:
+            _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
+        return Truncation(left, None, right, r)
+
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         if left_side:

@@ -266,6 +266,14 @@ int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t 
                            int64_t strideV2, const void* sigma, int64_t stride_sigma, int scale_right, void* right,
                            int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream);
 
+int64_t colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch);
+int colgram_dispatch(int dtype, int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
+                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream);
+int colproject_dispatch(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
+                        int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
+                        int64_t strideV2, const void* sigma, int64_t stride_sigma, int left_ortho, void* left, int64_t ldl,
+                        int64_t strideL, void* right, int64_t ldr, int64_t strideR, hipStream_t stream);
+
 extern long long* g_qr_dbg;
 extern int g_qr_variant;
 
@@ -472,6 +480,35 @@ int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, cons
   TTR_REQUIRE(!scale_right || sigma, TTR_E_INVALID, "ttr_project: scale_right needs sigma");
   return sweep_project_dispatch(dtype, R, n, ro, batch, M, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
                                 stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, (hipStream_t)stream);
+}
+
+int64_t ttr_colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch) {
+  if (rows <= 0 || n <= 0 || batch <= 0) return 0;
+  return colgram_workspace_bytes(dtype, rows, n, batch);
+}
+
+int ttr_colgram(int dtype, int64_t rows, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* workspace, int64_t workspace_bytes,
+                void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_colgram: bad dtype %d", dtype);
+  TTR_REQUIRE(rows >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_colgram: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(M && G, TTR_E_INVALID, "ttr_colgram: null pointer");
+  return colgram_dispatch(dtype, rows, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+int ttr_colproject(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* M, int64_t ldm,
+                   int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
+                   int64_t strideV2, const void* sigma, int64_t stride_sigma, int left_ortho, void* left, int64_t ldl,
+                   int64_t strideL, void* right, int64_t ldr, int64_t strideR, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_colproject: bad dtype %d", dtype);
+  TTR_REQUIRE(rows >= 1 && n >= 1 && ro >= 1 && batch >= 0, TTR_E_INVALID, "ttr_colproject: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(M && V2 && left, TTR_E_INVALID, "ttr_colproject: null pointer");
+  TTR_REQUIRE(!left_ortho || sigma, TTR_E_INVALID, "ttr_colproject: left_ortho needs sigma");
+  return colproject_dispatch(dtype, rows, n, ro, batch, M, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
+                             stride_sigma, left_ortho, left, ldl, strideL, right, ldr, strideR, (hipStream_t)stream);
 }
 
 int ttr_pow2_normalize(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out,

@@ -234,10 +234,16 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * tk + M::row(lane, r), i = 16 * ti + cl;
         Ul[k * KLD + i] = ureg[ti][r];
-        if (Lo && ti < nt && k < R && i < ro) Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? ureg[ti][r] * sg[i] : ureg[ti][r];
       }
   }
   __syncthreads();
+  if (Lo) {  // left = U diag(sigma), coalesced, from the LDS image
+    for (int idx = tid; idx < R * ro; idx += kThreads) {
+      const int k = idx / ro, i = idx - k * ro;
+      const T u = Ul[k * KLD + i];
+      Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? u * sg[i] : u;
+    }
+  }
   // ---- main loop: 32 columns per step as two interleaved 16-column slabs (columns c0 + 2 i + u): 8-byte loads of M
   // (whole 128-byte lines per 16 lanes) and 8-byte stores of the result
   T* __restrict__ Ro = p.right + b * p.strideR;
@@ -286,6 +292,340 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
       }
     }
   }
+}
+
+// ================================================================ tall matrices (dense TT-SVD steps): M is rows x n, n <= 64
+// The first (largest) step of a dense right-to-left TT-SVD truncates a (prod I_1..I_{N-1}) x I_N unfolding: millions of
+// rows, at most 64 columns, and the whole input tensor in bytes.  Same register technique with the roles of rows and
+// columns exchanged -- the contraction runs over the ROWS, 16 per wave and step:
+//   ttr_colgram    G = M^T M                (ROT = false: the 16 x 16 pieces of M are loaded straight into the accumulator
+//                                            layout, 64-byte row segments) or G = (M V1)^T (M V1) (ROT = true: the rotated
+//                                            16-row slab is an MFMA product whose A operand is read with 16-byte loads)
+//   ttr_colproject left = M U [diag(1/sigma)]  (rows x ro),  right = [diag(sigma)] U^T (ro x n),  U = V1 V2[:, :ro]
+// 'svd' therefore reads the tensor three times and writes only the carry (ro / n of its size) -- no rotated copy.
+constexpr int CLD = 68;  // LDS images [k][j] read with k = 16 kk + 4 g + u: 4 * 68 = 16 mod 32 -> the two lane rows of a
+                         // 32-lane group hit disjoint banks
+
+template <typename T>
+struct ColArgs {
+  int64_t rows;
+  int n;
+  const T* M;
+  int64_t ldm, strideM;
+  const T* V1;
+  int64_t ldv1, strideV1;
+  T* G;        // [batch][nsplit][n][n]
+  int nsplit;
+  const T* V2;
+  int64_t ldv2, strideV2;
+  const T* sigma;
+  int64_t stride_sigma;
+  int ro;
+  int left_ortho;  // 1: left columns divided by sigma, right rows multiplied (round.py:173-178); 0: plain (round.py:179-182)
+  T* left;
+  int64_t ldl, strideL;
+  T* right;
+  int64_t ldr, strideR;
+};
+
+template <typename T, bool ROT>
+__global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
+  using M = Mfma<T>;
+  using Acc = typename M::Acc;
+  constexpr int RED = 4 * 10 * 256;
+  constexpr int VSZ = 64 * CLD;
+  __shared__ __attribute__((aligned(16))) T smem[RED > VSZ ? RED : VSZ];
+  T* Vl = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
+  const int64_t b = blockIdx.y;
+  const int split = blockIdx.x;
+  const T* __restrict__ Mp = p.M + b * p.strideM;
+  const int n = p.n;
+  if constexpr (ROT) {
+    const T* __restrict__ V1 = p.V1 + b * p.strideV1;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, j = idx & 63;
+      Vl[k * CLD + j] = (k < n && j < n) ? V1[(int64_t)k * p.ldv1 + j] : T(0);
+    }
+    __syncthreads();
+  }
+  Acc G[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) G[i] = M::zero();
+  int64_t cb, ce;
+  split_range((p.rows + 15) / 16, p.nsplit, split, cb, ce);
+  const bool al = ((p.ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0);
+  for (int64_t c = cb + wave; c < ce; c += 4) {
+    const int64_t r0 = c * 16;
+    Acc mw[4];
+    if constexpr (!ROT) {
+      // lane (g, cl), register r <-> M[r0 + 4 g + r][16 t + cl]
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = r0 + 4 * g + r;
+          const int col = 16 * t + cl;
+          mw[t][r] = (row < p.rows && col < n) ? Mp[row * p.ldm + col] : T(0);
+        }
+    } else {
+      // A operand: lane (i = cl, g) holds M[r0 + cl][16 kk + 4 g + u]; K step (kk, u) <-> k = 16 kk + 4 g + u
+      T a[4][4];
+      const int64_t row = r0 + cl;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int col = 16 * kk + 4 * g;
+        const Pack<T, 4> x = load_pack<T, 4>(Mp + row * p.ldm + col, al, row < p.rows ? n - col : 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[kk][u] = x.v[u];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mw[t] = M::zero();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) mw[t] = M::mma(a[kk][u], Vl[(16 * kk + 4 * g + u) * CLD + 16 * t + cl], mw[t]);
+      }
+    }
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < 4; ++tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
+        ++idx;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) smem[(wave * 10 + i) * 256 + lane * 4 + r] = G[i][r];
+  __syncthreads();
+  T* __restrict__ Gout = p.G + ((int64_t)b * p.nsplit + split) * n * n;
+  for (int idx = tid; idx < 10 * 256; idx += kThreads) {
+    const int tile = idx >> 8, e = idx & 255, ln = e >> 2, r = e & 3;
+    const T v = (smem[idx] + smem[2560 + idx]) + (smem[5120 + idx] + smem[7680 + idx]);
+    int ti = 0, rem = tile;
+    while (rem >= 4 - ti) { rem -= 4 - ti; ++ti; }
+    const int tj = ti + rem;
+    const int row = 16 * ti + M::row(ln, r), col = 16 * tj + (ln & 15);
+    if (row < n && col < n) {
+      Gout[row * n + col] = v;
+      if (ti != tj) Gout[col * n + row] = v;
+    }
+  }
+}
+
+// out[b][e] = sum_p in[b][p][e]  (fixed order: deterministic)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sum_parts_kernel(const T* __restrict__ in, T* __restrict__ out, int parts, int64_t count) {
+  const int64_t b = blockIdx.y;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < count; e += (int64_t)gridDim.x * kThreads) {
+    T s = T(0);
+    for (int q = 0; q < parts; ++q) s += in[((int64_t)b * parts + q) * count + e];
+    out[b * count + e] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
+  using M = Mfma<T>;
+  using Acc = typename M::Acc;
+  constexpr int V1LD = 66;
+  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];   // V2[:, :ro] as [m][i] (prologue only)
+  __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];  // V1 as [k][m] (prologue only)
+  __shared__ __attribute__((aligned(16))) T Ul[64 * CLD];    // U = V1 V2[:, :ro] as [k][i], zero padded
+  __shared__ T csc[64];                                      // column scale of left (1 / sigma or 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
+  const int64_t b = blockIdx.y;
+  const int split = blockIdx.x;
+  const T* __restrict__ Mp = p.M + b * p.strideM;
+  const int n = p.n, ro = p.ro;
+  const int nt = (ro + 15) / 16;
+  const T* __restrict__ V2 = p.V2 + b * p.strideV2;
+  const T* __restrict__ sg = p.sigma ? p.sigma + b * p.stride_sigma : nullptr;
+  T* __restrict__ Rt = (p.right && split == 0) ? p.right + b * p.strideR : nullptr;
+  for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+    const int m = idx >> 6, i = idx & 63;
+    V2l[m * KLD + i] = (m < n && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
+  }
+  if (p.V1) {
+    const T* __restrict__ V1 = p.V1 + b * p.strideV1;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, m = idx & 63;
+      V1l[k * V1LD + m] = (k < n && m < n) ? V1[(int64_t)k * p.ldv1 + m] : T(0);
+    }
+  }
+  if (tid < 64) {
+    T sc = T(1);
+    if (p.left_ortho && sg && tid < ro) {
+      const T x = sg[tid];
+      sc = (fabs((double)x) < (double)Num<T>::tiny()) ? T(0) : T(1) / x;
+    }
+    csc[tid] = sc;
+  }
+  __syncthreads();
+  {
+    const int tk = wave;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      Acc u = M::zero();
+      if (ti < nt) {
+        if (p.V1) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+            u = M::mma(V1l[(16 * tk + cl) * V1LD + 4 * ks + g], V2l[(4 * ks + g) * KLD + 16 * ti + cl], u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = V2l[(16 * tk + M::row(lane, r)) * KLD + 16 * ti + cl];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * tk + M::row(lane, r), i = 16 * ti + cl;
+        Ul[k * CLD + i] = u[r];
+      }
+    }
+  }
+  __syncthreads();
+  if (Rt) {  // right = [diag(sigma)] U^T, coalesced, from the LDS image
+    for (int idx = tid; idx < ro * n; idx += kThreads) {
+      const int i = idx / n, k = idx - i * n;
+      const T u = Ul[k * CLD + i];
+      Rt[(int64_t)i * p.ldr + k] = (p.left_ortho && sg) ? u * sg[i] : u;
+    }
+  }
+  T* __restrict__ Lo = p.left + b * p.strideL;
+  const bool al = ((p.ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0);
+  int64_t cb, ce;
+  split_range((p.rows + 15) / 16, p.nsplit, split, cb, ce);
+  for (int64_t c = cb + wave; c < ce; c += 4) {
+    const int64_t r0 = c * 16;
+    T a[4][4];
+    const int64_t row = r0 + cl;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int col = 16 * kk + 4 * g;
+      const Pack<T, 4> x = load_pack<T, 4>(Mp + row * p.ldm + col, al, row < p.rows ? n - col : 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[kk][u] = x.v[u];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nt) {
+        Acc acc = M::zero();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = M::mma(a[kk][u], Ul[(16 * kk + 4 * g + u) * CLD + 16 * t + cl], acc);
+        const int col = 16 * t + cl;
+        const T sc = csc[col < 64 ? col : 0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t orow = r0 + M::row(lane, r);
+          if (orow < p.rows && col < ro) Lo[orow * p.ldl + col] = acc[r] * sc;
+        }
+      }
+    }
+  }
+}
+
+static int col_split(int64_t rows, int64_t batch) {
+  const int64_t chunks = (rows + 15) / 16;
+  int64_t want = (4096 + batch - 1) / batch;
+  int64_t maxs = chunks / 16;  // >= 4 steps per wave
+  if (maxs < 1) maxs = 1;
+  int64_t s = want < maxs ? want : maxs;
+  if (s > 4096) s = 4096;
+  return (int)(s < 1 ? 1 : s);
+}
+
+int64_t colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch) {
+  const int sp = col_split(rows, batch);
+  return sp > 1 ? (int64_t)sp * batch * n * n * (dtype == TTR_F64 ? 8 : 4) : 0;
+}
+
+template <typename T>
+static int colgram_typed(int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
+                         const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes,
+                         hipStream_t stream) {
+  const int sp = col_split(rows, batch);
+  TTR_REQUIRE(sp == 1 || (ws && ws_bytes >= (int64_t)sp * batch * n * n * (int64_t)sizeof(T)), TTR_E_WORKSPACE,
+              "ttr_colgram: workspace too small");
+  ColArgs<T> p{};
+  p.rows = rows; p.n = (int)n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
+  p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
+  p.G = sp == 1 ? (T*)G : (T*)ws; p.nsplit = sp;
+  ProfScope prof(V1 ? TTR_PROF_ROTGRAM : TTR_PROF_ROWGRAM, stream);
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    ColArgs<T> q = p;
+    q.M = p.M + b0 * strideM;
+    if (V1) q.V1 = p.V1 + b0 * strideV1;
+    q.G = p.G + b0 * sp * n * n;
+    const dim3 grid((unsigned)sp, (unsigned)nb);
+    if (V1) hipLaunchKernelGGL((colgram_kernel<T, true>), grid, dim3(kThreads), 0, stream, q);
+    else hipLaunchKernelGGL((colgram_kernel<T, false>), grid, dim3(kThreads), 0, stream, q);
+    if (sp > 1) {
+      int64_t gx = ceil_div(n * n, kThreads);
+      hipLaunchKernelGGL(sum_parts_kernel<T>, dim3((unsigned)gx, (unsigned)nb), dim3(kThreads), 0, stream,
+                         (const T*)q.G, (T*)G + b0 * n * n, sp, n * n);
+    }
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int colgram_dispatch(int dtype, int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
+                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  TTR_REQUIRE(n >= 1 && n <= 64, TTR_E_UNSUPPORTED, "ttr_colgram: %lld columns (the fused kernels hold <= 64)", (long long)n);
+  if (dtype == TTR_F32) return colgram_typed<float>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream);
+  return colgram_typed<double>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream);
+}
+
+template <typename T>
+static int colproject_typed(int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
+                            const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2, int64_t strideV2,
+                            const void* sigma, int64_t stride_sigma, int left_ortho, void* left, int64_t ldl,
+                            int64_t strideL, void* right, int64_t ldr, int64_t strideR, hipStream_t stream) {
+  ColArgs<T> p{};
+  p.rows = rows; p.n = (int)n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
+  p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
+  p.V2 = (const T*)V2; p.ldv2 = ldv2; p.strideV2 = strideV2;
+  p.sigma = (const T*)sigma; p.stride_sigma = stride_sigma; p.ro = (int)ro; p.left_ortho = left_ortho;
+  p.left = (T*)left; p.ldl = ldl; p.strideL = strideL;
+  p.right = (T*)right; p.ldr = ldr; p.strideR = strideR;
+  p.nsplit = col_split(rows, batch);
+  ProfScope prof(TTR_PROF_PROJECT, stream);
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    ColArgs<T> q = p;
+    q.M = p.M + b0 * strideM;
+    if (V1) q.V1 = p.V1 + b0 * strideV1;
+    q.V2 = p.V2 + b0 * strideV2;
+    if (sigma) q.sigma = p.sigma + b0 * stride_sigma;
+    q.left = p.left + b0 * strideL;
+    if (right) q.right = p.right + b0 * strideR;
+    hipLaunchKernelGGL(colproject_kernel<T>, dim3((unsigned)p.nsplit, (unsigned)nb), dim3(kThreads), 0, stream, q);
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int colproject_dispatch(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
+                        int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
+                        int64_t strideV2, const void* sigma, int64_t stride_sigma, int left_ortho, void* left, int64_t ldl,
+                        int64_t strideL, void* right, int64_t ldr, int64_t strideR, hipStream_t stream) {
+  TTR_REQUIRE(n >= 1 && n <= 64 && ro >= 1 && ro <= n, TTR_E_UNSUPPORTED,
+              "ttr_colproject: %lld columns / %lld kept (the fused kernel holds <= 64 columns)", (long long)n, (long long)ro);
+  if (dtype == TTR_F32)
+    return colproject_typed<float>(rows, n, ro, batch, Mx, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
+                                   stride_sigma, left_ortho, left, ldl, strideL, right, ldr, strideR, stream);
+  return colproject_typed<double>(rows, n, ro, batch, Mx, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
+                                  stride_sigma, left_ortho, left, ldl, strideL, right, ldr, strideR, stream);
 }
 
 static int pick_split(int64_t n, int64_t batch) {
