@@ -171,14 +171,19 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
 }
 
 // ---------------------------------------------------------------- projection onto the kept directions
+// LDS image of U = V1 V2[:, :ro] shared by the projection kernels: rows k in blocks of 16 (one block per wave of the
+// prologue), block stride UBLK, row stride KLD -- so that a wave can write ITS 16 rows over the V1 rows only it reads.
+constexpr int V1LD = 82;            // V1 as [k][m]: A-operand reads (16 k x 2 m per 32 lanes: words 82 cl + g) hit 32 banks
+constexpr int UBLK = 16 * V1LD;     // 1312 >= 16 * KLD
+__device__ __forceinline__ int urow(int k) { return (k >> 4) * UBLK + (k & 15) * KLD; }
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
-  constexpr int V1LD = 66;  // [k][m]: A-operand reads (16 k x 2 m per 32 lanes: words 66 cl + g) hit 32 banks
-  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];  // V2[:, :ro] as [m][i]; later U = V1 V2[:, :ro] as [k][i] (zero padded)
-  T* Ul = V2l;
-  __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];
+  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];   // V2[:, :ro] as [m][i], zero padded (prologue only)
+  __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];  // V1 as [k][m]; wave w then overwrites ITS rows 16 w .. 16 w + 15
+  T* Ul = V1l;                                               // with U rows (urow()): no other wave reads them before
   __shared__ T isg[64];  // 1 / sigma of the output rows (TTR_SCALE_DIV semantics: 0 below the smallest normal), or 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
   const int64_t b = blockIdx.y;
@@ -208,39 +213,38 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
       const int k = idx >> 6, m = idx & 63;
       V1l[k * V1LD + m] = (k < R && m < R) ? V1[(int64_t)k * p.ldv1 + m] : T(0);
     }
-  }
-  __syncthreads();
-  {
-    const int tk = wave;  // this wave's 16 rows k of U
-    Acc ureg[4];
+    __syncthreads();
+    // wave w: rows 16 w .. 16 w + 15 of U.  All four tiles are computed before the first one is stored (the stores
+    // overwrite the wave's own V1 rows), and go straight from the accumulators to LDS.
+    Acc u0 = M::zero(), u1 = M::zero(), u2 = M::zero(), u3 = M::zero();
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      ureg[ti] = M::zero();
-      if (ti < nt) {
-        if (p.V1) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks)
-            ureg[ti] = M::mma(V1l[(16 * tk + cl) * V1LD + 4 * ks + g], V2l[(4 * ks + g) * KLD + 16 * ti + cl], ureg[ti]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ureg[ti][r] = V2l[(16 * tk + M::row(lane, r)) * KLD + 16 * ti + cl];
-        }
-      }
+    for (int ks = 0; ks < 16; ++ks) {
+      const T a = V1l[(16 * wave + cl) * V1LD + 4 * ks + g];
+      u0 = M::mma(a, V2l[(4 * ks + g) * KLD + cl], u0);
+      u1 = M::mma(a, V2l[(4 * ks + g) * KLD + 16 + cl], u1);
+      u2 = M::mma(a, V2l[(4 * ks + g) * KLD + 32 + cl], u2);
+      u3 = M::mma(a, V2l[(4 * ks + g) * KLD + 48 + cl], u3);
     }
-    __syncthreads();  // every wave is done reading V2l: U takes its place
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * tk + M::row(lane, r), i = 16 * ti + cl;
-        Ul[k * KLD + i] = ureg[ti][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      T* dst = Ul + urow(16 * wave + M::row(lane, r)) + cl;
+      dst[0] = u0[r];
+      dst[16] = u1[r];
+      dst[32] = u2[r];
+      dst[48] = u3[r];
+    }
+  } else {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, i = idx & 63;
+      Ul[urow(k) + i] = V2l[k * KLD + i];
+    }
   }
   __syncthreads();
   if (Lo) {  // left = U diag(sigma), coalesced, from the LDS image
     for (int idx = tid; idx < R * ro; idx += kThreads) {
       const int k = idx / ro, i = idx - k * ro;
-      const T u = Ul[k * KLD + i];
+      const T u = Ul[urow(k) + i];
       Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? u * sg[i] : u;
     }
   }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
         Acc acc0 = M::zero(), acc1 = M::zero();
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const T af = Ul[(4 * ks + g) * KLD + 16 * t + cl];
+          const T af = Ul[urow(4 * ks + g) + 16 * t + cl];
           acc0 = M::mma(af, bm[0][ks], acc0);
           acc1 = M::mma(af, bm[1][ks], acc1);
         }
@@ -468,26 +472,28 @@ __global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
     csc[tid] = sc;
   }
   __syncthreads();
-  {
-    const int tk = wave;
+  if (p.V1) {  // wave w: rows 16 w .. 16 w + 15 of U, straight from the accumulators to LDS
+    Acc u0 = M::zero(), u1 = M::zero(), u2 = M::zero(), u3 = M::zero();
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      Acc u = M::zero();
-      if (ti < nt) {
-        if (p.V1) {
+    for (int ks = 0; ks < 16; ++ks) {
+      const T a = V1l[(16 * wave + cl) * V1LD + 4 * ks + g];
+      u0 = M::mma(a, V2l[(4 * ks + g) * KLD + cl], u0);
+      u1 = M::mma(a, V2l[(4 * ks + g) * KLD + 16 + cl], u1);
+      u2 = M::mma(a, V2l[(4 * ks + g) * KLD + 32 + cl], u2);
+      u3 = M::mma(a, V2l[(4 * ks + g) * KLD + 48 + cl], u3);
+    }
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks)
-            u = M::mma(V1l[(16 * tk + cl) * V1LD + 4 * ks + g], V2l[(4 * ks + g) * KLD + 16 * ti + cl], u);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) u[r] = V2l[(16 * tk + M::row(lane, r)) * KLD + 16 * ti + cl];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * tk + M::row(lane, r), i = 16 * ti + cl;
-        Ul[k * CLD + i] = u[r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      T* dst = Ul + (16 * wave + M::row(lane, r)) * CLD + cl;
+      dst[0] = u0[r];
+      dst[16] = u1[r];
+      dst[32] = u2[r];
+      dst[48] = u3[r];
+    }
+  } else {
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, i = idx & 63;
+      Ul[k * CLD + i] = V2l[k * KLD + i];
     }
   }
   __syncthreads();
