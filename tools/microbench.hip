@@ -96,7 +96,38 @@ static void run(const char* name, int insts_per_iter) {
   hipFree(out); hipFree(cyc);
 }
 
-int main() {
+// back-to-back v_mfma_f32_16x16x4_f32 on four independent accumulators: the 100 % reference for the MFMA-busy counter
+__global__ void mfma_kernel(float* out, int iters) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const float x = threadIdx.x * 1e-3f, y = 1.0f + x;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, y, a3, 0, 0, 0);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+
+static void run_mfma() {
+  float* out;
+  hipMalloc(&out, sizeof(float) * 256 * 4096);
+  const int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_kernel, dim3(1024), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_kernel, dim3(1024), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double flops = 1024.0 * 4 * iters * 4 * 2048.0;  // blocks x waves x iters x 4 MFMA x 2048 flop
+  printf("{\"microbench\": \"v_mfma_f32_16x16x4_f32 x4 back to back, 4 waves/SIMD\", \"ms\": %.3f, \"tflops\": %.1f}\n", ms, flops / ms / 1e9);
+  hipFree(out);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'm') { run_mfma(); return 0; }
   run<0>("v_fma_f32 x8 independent", 8);
   run<1>("v_pk_fma_f32 x4 independent", 4);
   run<2>("v_mov_dpp row_newbcast x8", 8);

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiles of one round, collected on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r02
+# -> gpurun_out/<tag>/: kernel trace of bench.py (single stream), separate --pmc passes (HBM bytes, MFMA busy),
+#    the MFMA-busy calibration, pmc_latest.json and readable summaries.  Copy what should be judged into profiles/.
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B=2048
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --steps 5 --warmup 2 --single-stream --no-cpu-baseline --no-extras > $OUT/kt_bench.json 2> $OUT/kt.err
+python $R/tools/rocprof_summary.py $(find $OUT/kt -name "*kernel_trace.csv" | head -1) > $OUT/kernel_stats.txt 2>> $OUT/kt.err
+for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
+  name=${spec%%:*}; ctrs=${spec#*:}
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- python $R/tools/pmc_step.py $B > $OUT/pmc_$name.log 2>&1
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $R/tools/microbench.hip -o /tmp/ttr_microbench 2> /dev/null
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_calib -o p -- /tmp/ttr_microbench m > $OUT/pmc_mfma_calib.log 2>&1
+python $R/tools/pmc_to_json.py $OUT 2 $B > $OUT/pmc_summary.txt 2> $OUT/pmc_summary.err
+tail -n 30 $OUT/pmc_summary.txt
+head -n 25 $OUT/kernel_stats.txt
