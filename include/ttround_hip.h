@@ -140,6 +140,20 @@ int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n
                          const void* core, int64_t stride_core,
                          void* R, int64_t ldr, int64_t strideR,
                          void* workspace, int64_t workspace_bytes, void* stream);
+/*
+ * The same fused push + factorisation for the middle core of a TT SUM a + b (tensor.py:445-668): the next core is the
+ * block-diagonal blockdiag(a_core [ra][I][ca], b_core [rb][I][cb]) of tensor.py's `__add__`, which is never
+ * materialised -- the kernel reads the two blocks where they lie (column tiles inside one block only walk that block's
+ * rows: half the multiply-adds of the padded core for equal ranks).  Rm is k x (ra + rb); workspace size and the
+ * implicit Q (ttr_qr_apply_pushed) are those of ttr_qr_factor_pushed with n = ca + cb.  This is the "add, then round"
+ * fusion of tools.reduce (tools.py:460-512).
+ */
+int ttr_qr_factor_pushed_sum(int dtype, int64_t k, int64_t I, int64_t batch,
+                             const void* Rm, int64_t ldrm, int64_t strideRm,
+                             const void* core_a, int64_t ra, int64_t ca, int64_t stride_a,
+                             const void* core_b, int64_t rb, int64_t cb, int64_t stride_b,
+                             void* R, int64_t ldr, int64_t strideR,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch,
                         void* workspace, int64_t workspace_bytes,
                         const void* C, int64_t ldc, int64_t strideC, int64_t kcols,

@@ -554,3 +554,28 @@ def test_colsweep_gram_project(dt, rows, n, B):
     left, right = h.colproject(M.cuda(), None, V2.cuda(), sig.cuda(), ro, left_ortho=False)
     assert (left.cpu().double() - Md @ V2d[:, :, :ro]).abs().max() / Md.abs().max() < 4 * t
     assert (right.cpu().double() - V2d[:, :, :ro].transpose(1, 2)).abs().max() < t
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("k,ra,rb,I,ca,cb", [(64, 32, 32, 64, 32, 32), (20, 7, 9, 11, 5, 12), (64, 40, 24, 16, 16, 48), (33, 10, 3, 70, 30, 20)])
+def test_qr_pushed_sum(dt, k, ra, rb, I, ca, cb, qr_variant):
+    """Fused push of the block-diagonal middle core of a TT sum: same factorisation as pushing the padded core."""
+    h = _hip()
+    g = torch.Generator().manual_seed(k + ra * 3 + I)
+    B = 2
+    Rm = torch.randn(B, k, ra + rb, generator=g, dtype=torch.float64).to(dt)
+    a = torch.randn(B, ra, I, ca, generator=g, dtype=torch.float64).to(dt)
+    b = torch.randn(B, rb, I, cb, generator=g, dtype=torch.float64).to(dt)
+    za, zb = torch.zeros(B, ra, I, cb, dtype=dt), torch.zeros(B, rb, I, ca, dtype=dt)
+    core = torch.cat([torch.cat([a, za], dim=-1), torch.cat([zb, b], dim=-1)], dim=1)
+    n = ca + cb
+    P = (Rm.double() @ core.double().reshape(B, ra + rb, I * n)).reshape(B, k * I, n)
+    f = h.qr_factor_pushed_sum(Rm.cuda(), a.cuda(), b.cuda())
+    Q = h.qr_apply(f).cpu().double()
+    R = f.R.cpu().double()
+    kq = min(k * I, n)
+    assert Q.shape == (B, k * I, kq) and R.shape == (B, kq, n)
+    assert (Q.transpose(1, 2) @ Q - torch.eye(kq, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
+    assert (Q @ R - P).abs().max() / P.abs().max() < tol(dt, 2e-5, 1e-12)
+    f2 = h.qr_factor_pushed(Rm.cuda(), core.cuda())
+    assert (f2.R.cpu().double().abs() - R.abs()).abs().max() / R.abs().max() < tol(dt, 3e-4, 1e-10)

@@ -883,3 +883,38 @@ def test_non_current_device():
     t.round_tt(rmax=5)
     assert all(c.device.index == 1 for c in t.cores)
     assert rel_diff(dense(to_list(t.cores)), dense(inp)) <= 5e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_fused_add_round_matches_materialised(dt):
+    """tools.reduce(operator.add) on device tensors rounds every sum WITHOUT materialising its block-diagonal cores
+    (ttr_qr_factor_pushed_sum): same tensor as `round(a + b)` on the padded cores and as the oracle's reduction tree,
+    in eps mode (with the Tucker stage of round()), rmax mode and batch mode."""
+    import operator
+    f32 = dt == torch.float32
+    torch.manual_seed(21)
+    parts = [oracle.tt_randn([9, 10, 8, 9, 7], 3, dtype=dt) for _ in range(6)]
+    ts = [gpu_tensor(p) for p in parts]
+    want = sum(dense(p) for p in parts)
+    red = tn.reduce(ts, operator.add, eps=1e-6 if f32 else 1e-10)
+    assert rel_diff(red.torch().cpu(), want) <= (5e-5 if f32 else 1e-9)
+    ref_cores, _ = oracle.reduce_sum(parts, eps=1e-6 if f32 else 1e-10)
+    assert sum(red.ranks_tt.tolist()) <= sum(ranks(ref_cores)) + 2
+    red3 = tn.reduce(ts, operator.add, rmax=4)
+    mat = tn.round_tt(ts[0] + ts[1], rmax=4)                                   # the generic path on the padded cores
+    fus = tn.Tensor._round_of_sum(ts[0], ts[1], eps=1e-14, rmax=4)
+    assert fus is not None and fus.ranks_tt.tolist() == mat.ranks_tt.tolist() == [1, 4, 4, 4, 4, 1]
+    assert rel_diff(fus.torch().cpu(), mat.torch().cpu()) <= (2e-5 if f32 else 1e-10)
+    assert red3.ranks_tt.tolist() == [1, 4, 4, 4, 4, 1]
+    # batch mode, two-stream sized batch, unequal ranks of the addends
+    a = oracle.tt_randn([6, 7, 5, 6], 3, dtype=dt, batch_size=130)
+    b = oracle.tt_randn([6, 7, 5, 6], 5, dtype=dt, batch_size=130)
+    ta, tb = gpu_tensor(a, batch=True), gpu_tensor(b, batch=True)
+    fus = tn.Tensor._round_of_sum(ta, tb, rmax=8)
+    X = oracle.tt_to_dense([c.double() for c in a], batch=True) + oracle.tt_to_dense([c.double() for c in b], batch=True)
+    assert fus.ranks_tt.tolist() == [1, 6, 8, 6, 1]
+    assert rel_diff(fus.torch().cpu(), X) <= (5e-6 if f32 else 1e-12)            # rank 8 = 3 + 5: exact
+    # ranks above the fused kernel's 64 columns fall back to the padded core
+    a = oracle.tt_randn([4, 5, 4], 40, dtype=dt)
+    fb = tn.Tensor._round_of_sum(gpu_tensor(a), gpu_tensor(a), eps=1e-6)
+    assert rel_diff(fb.torch().cpu(), 2 * dense(a)) <= (5e-5 if f32 else 1e-9)

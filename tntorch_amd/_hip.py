@@ -71,6 +71,11 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_void_p],
     ),
+    "ttr_qr_factor_pushed_sum": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "ttr_qr_apply_pushed": (
         c_int,
         [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
@@ -380,6 +385,30 @@ def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
                                       R.data_ptr(), n, kq * n, ws.data_ptr(), wsb, _stream())
         _check(code, "ttr_qr_factor_pushed")
     return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I))
+
+
+@_on_device
+def qr_factor_pushed_sum(Rm: torch.Tensor, a4: torch.Tensor, b4: torch.Tensor) -> QrFactors:
+    """Factor the left unfolding of ``Rm @ blockdiag(a, b)`` (Rm [batch, k, ra + rb], a [batch, ra, I, ca],
+    b [batch, rb, I, cb]) without forming the block-diagonal core of the TT sum (ttr_qr_factor_pushed_sum)."""
+    L = lib()
+    dt = dtype_code(a4.dtype)
+    Rm, ldrm, sRm = _mat(Rm)
+    a4, b4 = a4.contiguous(), b4.contiguous()
+    batch, ra, I, ca = a4.shape
+    _, rb, _, cb = b4.shape
+    k, n = Rm.shape[1], ca + cb
+    assert Rm.shape[2] == ra + rb and Rm.shape[0] == batch and b4.shape[0] == batch and b4.shape[2] == I
+    kq = min(k * I, n)
+    R = torch.empty((batch, kq, n), dtype=a4.dtype, device=a4.device)
+    wsb = L.ttr_qr_pushed_workspace_bytes(dt, I, n, max(batch, 1))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a4.device)
+    if batch > 0:
+        code = L.ttr_qr_factor_pushed_sum(dt, k, I, batch, Rm.data_ptr(), ldrm, sRm, a4.data_ptr(), ra, ca, ra * I * ca,
+                                          b4.data_ptr(), rb, cb, rb * I * cb, R.data_ptr(), n, kq * n, ws.data_ptr(), wsb,
+                                          _stream())
+        _check(code, "ttr_qr_factor_pushed_sum")
+    return QrFactors(ws, wsb, k * I, n, batch, a4.dtype, R, pushed=(k, I))
 
 
 @_on_device

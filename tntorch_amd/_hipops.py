@@ -501,6 +501,50 @@ def right_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor
     return L
 
 
+class SumCore:
+    """Middle core of a TT sum a + b (tensor.py:445-668) kept as its two diagonal blocks: ``blockdiag(a, b)`` with
+    a [B, ra, I, ca], b [B, rb, I, cb] is what ``__add__`` would materialise (a core (ra+rb)^2 / (ra^2+rb^2) times larger,
+    half of it zeros).  The L2R sweep feeds the blocks straight to ``ttr_qr_factor_pushed_sum``."""
+
+    __slots__ = ("a", "b")
+
+    def __init__(self, a: torch.Tensor, b: torch.Tensor):
+        assert a.dim() == 4 and b.dim() == 4 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2]
+        self.a, self.b = a, b
+
+    @property
+    def shape(self):
+        return torch.Size((self.a.shape[0], self.a.shape[1] + self.b.shape[1], self.a.shape[2], self.a.shape[3] + self.b.shape[3]))
+
+    @property
+    def dtype(self):
+        return self.a.dtype
+
+    @property
+    def device(self):
+        return self.a.device
+
+    def __getitem__(self, idx):
+        return SumCore(self.a[idx], self.b[idx])
+
+    def dense(self) -> torch.Tensor:
+        a, b = self.a, self.b
+        za = a.new_zeros(a.shape[:-1] + (b.shape[-1],))
+        zb = b.new_zeros(b.shape[:-1] + (a.shape[-1],))
+        return torch.cat([torch.cat([a, za], dim=-1), torch.cat([zb, b], dim=-1)], dim=1)
+
+
+def sum_cores(ca: Sequence[torch.Tensor], cb: Sequence[torch.Tensor]) -> List:
+    """Cores of a + b for [B, r0, I, r1] trains: first / last cores concatenated (small), middle cores lazy."""
+    N = len(ca)
+    if N == 1:
+        return [ca[0] + cb[0]]  # (only reached for one-mode tensors; a plain vector sum)
+    out: List = [torch.cat([ca[0], cb[0]], dim=-1)]
+    out += [SumCore(a, b) for a, b in zip(ca[1:-1], cb[1:-1])]
+    out.append(torch.cat([ca[-1], cb[-1]], dim=1))
+    return out
+
+
 class _ExplicitQ:
     """Stand-in for ``_hip.QrFactors`` when Q had to be formed (blocked QR above the TSQR column limit)."""
 
@@ -633,6 +677,18 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
     for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
         Bt, r0, I, r1 = c[mu].shape
         rows_k = r0 if Rprev is None else Rprev.shape[1]
+        if isinstance(c[mu], SumCore):
+            if Rprev is not None and _hip.pushed_supported(Rprev.shape[1], r0, I, r1, c[mu].dtype):
+                f = _hip.qr_factor_pushed_sum(Rprev, c[mu].a, c[mu].b)  # blockdiag(a, b) is never materialised
+                facs.append((f, rows_k, I))
+                Rprev = f.R
+                if Rprev.dtype == torch.float32:
+                    if expo is None:
+                        expo = torch.zeros(Bt, dtype=torch.int32, device=Rprev.device)
+                    Rprev, _ = _hip.pow2_normalize(Rprev, expo_acc=expo)
+                c[mu] = None
+                continue
+            c[mu] = c[mu].dense()  # ranks above the fused kernel's 64 columns: the padded core after all
         if r1 > _hip.max_qr_cols(c[mu].dtype):
             # more columns than a TSQR panel holds (TT rank > 64): explicit Q from the blocked QR
             A = c[mu] if Rprev is None else _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1))

@@ -246,6 +246,10 @@ int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch
 int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
                               int64_t ldrm, int64_t strideRm, const void* Cn, int64_t strideCn, void* R, int64_t ldr,
                               int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
+int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch, const void* Rm, int64_t ldrm,
+                                  int64_t strideRm, const void* Ca, int64_t ra, int64_t ca, int64_t strideCa,
+                                  const void* Cb, int64_t rb, int64_t cb, int64_t strideCb, void* R, int64_t ldr,
+                                  int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
 int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
                              int64_t strideO, hipStream_t stream);
@@ -374,6 +378,18 @@ int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n
   TTR_REQUIRE(Rm && core && R && workspace, TTR_E_INVALID, "ttr_qr_factor_pushed: null pointer");
   return qr_factor_pushed_dispatch(dtype, k, Rin, I, n, batch, Rm, ldrm, strideRm, core, stride_core, R, ldr, strideR,
                                    workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttr_qr_factor_pushed_sum(int dtype, int64_t k, int64_t I, int64_t batch, const void* Rm, int64_t ldrm,
+                             int64_t strideRm, const void* core_a, int64_t ra, int64_t ca, int64_t stride_a,
+                             const void* core_b, int64_t rb, int64_t cb, int64_t stride_b, void* R, int64_t ldr,
+                             int64_t strideR, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_factor_pushed_sum: bad dtype %d", dtype);
+  TTR_REQUIRE(batch >= 0, TTR_E_INVALID, "ttr_qr_factor_pushed_sum: negative batch");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Rm && core_a && core_b && R && workspace, TTR_E_INVALID, "ttr_qr_factor_pushed_sum: null pointer");
+  return qr_factor_pushed_sum_dispatch(dtype, k, I, batch, Rm, ldrm, strideRm, core_a, ra, ca, stride_a, core_b, rb, cb,
+                                       stride_b, R, ldr, strideR, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* workspace,

@@ -63,6 +63,11 @@ struct QrLevel {
   const T* Cn;         // next core [pRin][pI][n] contiguous
   int64_t strideCn;
   int pk, pRin, pI;
+  // block-diagonal next core (the middle core of a TT sum a + b, tensor.py:445-668, never materialised): rows < sumRa /
+  // columns < sumCa come from Cn = a's core [sumRa][pI][sumCa], the rest from Cn2 = b's core [pRin - sumRa][pI][n - sumCa]
+  const T* Cn2;
+  int64_t strideCn2;
+  int sumRa, sumCa;
   long long* dbg;      // optional: cycle stamps of block (0,0) at phase boundaries (diagnostics)
 };
 
@@ -140,24 +145,53 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
     const int imode = b * NW + wave;
-    const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
-    const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
     const bool ivalid = imode < p.pI;
     const int ksteps = (p.pRin + 3) >> 2;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int r0 = ks * 4 + g;
-      T bv[NT], av[4];
+    if (p.Cn2 == nullptr) {
+      const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
+      const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int r0 = ks * 4 + g;
+        T bv[NT], av[4];
 #pragma unroll
-      for (int tn = 0; tn < NT; ++tn) {
-        const int col = tn * PW + cl;
-        bv[tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
+        for (int tn = 0; tn < NT; ++tn) {
+          const int col = tn * PW + cl;
+          bv[tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[tn], acc[tm][tn]);
       }
+    } else {
+      // block-diagonal core blockdiag(a, b): column tiles that lie inside one diagonal block only walk that block's
+      // rows (for equal ranks: half the K steps), tiles that straddle the boundary see the zero blocks as zeros
+      const int ra = p.sumRa, ca = p.sumCa, cb = n - ca;
+      const T* __restrict__ Ca = p.Cn + bt * p.strideCn + (int64_t)imode * ca;
+      const T* __restrict__ Cb = p.Cn2 + bt * p.strideCn2 + (int64_t)imode * cb;
+      const int64_t sa = (int64_t)p.pI * ca, sb = (int64_t)p.pI * cb;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int r0 = ks * 4 + g;
+        T av[4];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
+        for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+        for (int tn = 0; tn < NT; ++tn) {
+          const int c0 = tn * PW;
+          const bool all_a = c0 + PW <= ca, all_b = c0 >= ca;  // wave-uniform
+          if ((all_a && ks * 4 >= ra) || (all_b && ks * 4 + 3 < ra)) continue;  // this tile's rows of the step are all zero
+          const int col = c0 + cl;
+          T bvv = T(0);
+          if (ivalid && r0 < p.pRin && col < n) {
+            if (col < ca) { if (r0 < ra) bvv = Ca[(int64_t)r0 * sa + col]; }
+            else if (r0 >= ra) bvv = Cb[(int64_t)(r0 - ra) * sb + (col - ca)];
+          }
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[tn], acc[tm][tn]);
+          for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = M::mma(av[tm], bvv, acc[tm][tn]);
+        }
+      }
     }
     lds_barrier();  // Rs aliases Vs
   } else {
@@ -753,6 +787,9 @@ struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factoris
   int64_t ldrm = 0, strideRm = 0;
   const void* Cn = nullptr;
   int64_t strideCn = 0;
+  const void* Cn2 = nullptr;  // block-diagonal core: second block
+  int64_t strideCn2 = 0;
+  int sumRa = 0, sumCa = 0;
   int k = 0, Rin = 0, I = 0;
 };
 
@@ -765,6 +802,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
     p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
+    p.Cn2 = (const T*)pu.Cn2; p.strideCn2 = pu.strideCn2; p.sumRa = pu.sumRa; p.sumCa = pu.sumCa;
     p.X = l == 0 ? A : ws + pl.off_x[l];
     p.ldx = l == 0 ? lda : n;
     p.strideX = l == 0 ? strideA : pl.m[l] * n;
@@ -899,6 +937,24 @@ int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int6
   if (rc != TTR_OK) return rc;
   Pushed pu;
   pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Cn; pu.strideCn = strideCn;
+  pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
+  const int64_t m = pushed_rows(I);
+  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
+  return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
+}
+
+// Fused push of a block-diagonal core: QR of the left unfolding of Rm * blockdiag(a, b) (a: [ra][I][ca], b: [rb][I][cb]).
+int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch, const void* Rm, int64_t ldrm,
+                                  int64_t strideRm, const void* Ca, int64_t ra, int64_t ca, int64_t strideCa,
+                                  const void* Cb, int64_t rb, int64_t cb, int64_t strideCb, void* R, int64_t ldr,
+                                  int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int64_t n = ca + cb, Rin = ra + rb;
+  const int rc = pushed_ok(dtype, k, Rin, I, n);
+  if (rc != TTR_OK) return rc;
+  TTR_REQUIRE(ra >= 1 && rb >= 1 && ca >= 1 && cb >= 1, TTR_E_INVALID, "ttr_qr_factor_pushed_sum: empty block");
+  Pushed pu;
+  pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Ca; pu.strideCn = strideCa;
+  pu.Cn2 = Cb; pu.strideCn2 = strideCb; pu.sumRa = (int)ra; pu.sumCa = (int)ca;
   pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
   const int64_t m = pushed_rows(I);
   if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);

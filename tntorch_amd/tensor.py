@@ -434,6 +434,35 @@ class Tensor(object):
             print("round_tt time (orthogonalization + truncation sweeps):", time.time() - start)
         self.cores = self._denorm(out)
 
+    @staticmethod
+    def _round_of_sum(a: "Tensor", b: "Tensor", eps=1e-14, rmax=None, algorithm="svd"):
+        """``round(a + b)`` (tensor.py:445-668 followed by tensor.py:2085-2098) for two pure TT tensors on the device
+        without materialising the block-diagonal cores of the sum: the L2R sweep reads the two addends' cores directly
+        (``ttr_qr_factor_pushed_sum``), and the error the TT stage reached is taken from inner products with the
+        addends, <a+b, a+b> = <a,a> + 2<a,b> + <b,b>.  Returns None when the fusion does not apply (the caller then
+        takes the generic path)."""
+        from . import _hipops
+        from .metrics import dot
+
+        if not (isinstance(a, Tensor) and isinstance(b, Tensor)) or a.batch != b.batch or a.shape != b.shape:
+            return None
+        if a._has_factors() or b._has_factors() or a.dim() < 3:
+            return None
+        ca, cb = a._norm4(), b._norm4()
+        if not (ca[0].is_cuda and cb[0].is_cuda and ca[0].dtype == cb[0].dtype):
+            return None
+        N = a.dim()
+        rm = list(rmax) if hasattr(rmax, "__len__") else [rmax] * (N - 1)
+        out = ops_for(ca[0]).round_tt(_hipops.sum_cores(ca, cb), eps, rm, algorithm, a.batch, None)
+        res = Tensor(a._denorm(out), batch=a.batch)
+        if not a.batch and eps > 0:  # second half of round(): Tucker stage with the remaining budget
+            gg = dot(a, a) + 2 * dot(a, b) + dot(b, b)
+            err2 = (gg + dot(res, res) - 2 * (dot(a, res) + dot(b, res))).clamp(0)
+            reached = float(torch.sqrt(err2) / torch.sqrt(gg.clamp(0)))
+            if reached < eps:
+                res.round_tucker((1 + eps) / (1 + reached) - 1, algorithm=algorithm)
+        return res
+
     def round_tucker(
         self,
         eps: float = 1e-14,

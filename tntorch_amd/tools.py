@@ -48,9 +48,17 @@ def reduce(ts, function, eps=0, rmax=np.iinfo(np.int32).max, algorithm="svd", ve
     EARLIER group first (order matters for e.g. concatenation).  At the end the remaining groups are merged from the
     oldest (highest) to the newest.
     """
+    import operator
+
     from .round import round as _round
+    from .tensor import Tensor
 
     def merge(older, newer):
+        if function is operator.add and not kwargs:
+            # add-then-round fused: the concatenated cores of the sum are never materialised (device TT tensors)
+            fused = Tensor._round_of_sum(older, newer, eps=eps, rmax=rmax, algorithm=algorithm)
+            if fused is not None:
+                return fused
         return _round(function(older, newer, **kwargs), eps=eps, rmax=rmax, algorithm=algorithm)
 
     slots = []
