@@ -98,4 +98,5 @@ def test_bench_under_torchrun_single_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["nccl_ranks"] == 1 and d["unit"] == "cores/s" and d["value"] > 0
     assert d["parity"]["ok"], d["parity"]
-    assert d["roofline"]["bound"] in ("mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
+    # at this small batch the latency-bound eigensolver can be the dominant kind: bench.py labels it "valu"
+    assert d["roofline"]["bound"] in ("mfma", "hbm", "valu") and 0 < d["roofline"]["frac"] < 1

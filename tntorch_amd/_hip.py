@@ -15,7 +15,8 @@ from typing import Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttround_hip.so")
+# TTR_LIB_PATH: load another build of the same library (kernel experiments: several variants side by side)
+LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2

@@ -100,6 +100,8 @@ template <typename T, int NT, bool PUSHED, int NW, bool PAIR>
 __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
+  typedef T V2 __attribute__((ext_vector_type(2)));  // fp32: v_pk_mul / v_pk_fma operands (two rows per instruction)
+  typedef T V4 __attribute__((ext_vector_type(4)));
   constexpr int NP = PW * NT;  // padded column count
   constexpr int BR = 64 * NW;  // rows = threads of this block
   constexpr int NTH = 64 * NW;
@@ -108,7 +110,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   __shared__ T taus[NP];
   __shared__ T Ts[PW * VLD], Ss[PW * VLD];
   constexpr int WPC = NP > 2 * PW ? NP - PW : PW;               // W only exists for the trailing column tiles (tn >= 1)
-  __shared__ T Wp[NW][PW][WPC];                                 // per-wave partial W (also S partials)
+  // per-wave partial W (also S partials) Wp[NW][PW][WPC]; during the Householder phases of a PAIR panel the same storage is
+  // the reflector exchange buffer Xp[2][64][XLD] (double-buffered by phase parity): lane l's 16 values (v0[0..7], v1[0..7])
+  // as four 16-byte accesses at a 20-word lane stride -- conflict-free for ds_write_b128 and ds_read_b128
+  constexpr int XLD = 20;
+  constexpr int WP_ELEMS = NW * PW * WPC, XP_ELEMS = PAIR ? 2 * 64 * XLD : 0;
+  __shared__ __attribute__((aligned(32))) T WXs[WP_ELEMS > XP_ELEMS ? WP_ELEMS : XP_ELEMS];
+  T (*Wp)[PW][WPC] = reinterpret_cast<T (*)[PW][WPC]>(WXs);
+  T* const Xp = WXs;
+  __shared__ T Xs[PW * VLD];                                    // scratch of the recursive T construction
   __shared__ T W2s[PW][NP + 1];
   __shared__ T pairt[NW];                                       // PAIR: v0^T v1 of every owner's pair
 
@@ -125,6 +135,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   const int kb = rows < n ? rows : n;
   auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
+  int dbgi = 0;
+  auto stamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  stamp();
   Acc acc[4][NT];
   if constexpr (PUSHED) {
     // acc <- Rm (pk x pRin) * C[:, i, :] (pRin x n) for this wave's mode index i = NW*b + wave: the wave's 64
@@ -139,33 +152,63 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       const int kk = idx >> 6, r0 = idx & 63;
       Rs[kk * RLD + r0] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
     }
-    lds_barrier();
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
     const int imode = b * NW + wave;
     const bool ivalid = imode < p.pI;
     const int ksteps = (p.pRin + 3) >> 2;
     if (p.Cn2 == nullptr) {
+      // The wave's core slice C[:, i, :] (pRin rows of n values, 16 KiB for a 64 x 64 x 64 core) is streamed in groups
+      // of four K steps with the NEXT group's loads in flight under the current group's MFMAs: with one K step per
+      // round trip (16 KiB in flight per CU) the whole phase ran at the memory latency -- 64 k of a block's 189 k cycles
+      // under load (cycle stamps) -- two groups keep 64 KiB per block in flight.
       const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
       const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int r0 = ks * 4 + g;
-        T bv[NT], av[4];
+      constexpr int KG = 4;
+      T bvA[KG][NT], bvB[KG][NT];
+      auto load_group = [&](int grp, T (&bv)[KG][NT]) {
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn) {
-          const int col = tn * PW + cl;
-          bv[tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
+        for (int kk = 0; kk < KG; ++kk) {
+          const int r0 = (grp * KG + kk) * 4 + g;
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) {
+            const int col = tn * PW + cl;
+            bv[kk][tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
+          }
         }
+      };
+      auto mma_group = [&](int grp, const T (&bv)[KG][NT]) {
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
+        for (int kk = 0; kk < KG; ++kk) {
+          const int r0 = (grp * KG + kk) * 4 + g;  // rows >= pRin: the staged Rs column is zero (and bv is zero)
+          T av[4];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+          for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
 #pragma unroll
-          for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[tn], acc[tm][tn]);
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[kk][tn], acc[tm][tn]);
+        }
+      };
+      const int ngroups = (ksteps + KG - 1) / KG;  // <= 4 (pRin <= 64)
+      load_group(0, bvA);  // in flight while Rs is being staged
+      lds_barrier();
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
+      for (int grp = 0; grp < ngroups; grp += 2) {
+        if (grp + 1 < ngroups) load_group(grp + 1, bvB);
+        mma_group(grp, bvA);
+        if (grp + 1 < ngroups) {
+          if (grp + 2 < ngroups) load_group(grp + 2, bvA);
+          mma_group(grp + 1, bvB);
+        }
       }
     } else {
+      lds_barrier();
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
       // block-diagonal core blockdiag(a, b): column tiles that lie inside one diagonal block only walk that block's
       // rows (for equal ranks: half the K steps), tiles that straddle the boundary see the zero blocks as zeros
       const int ra = p.sumRa, ca = p.sumCa, cb = n - ca;
@@ -241,9 +284,16 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           for (int r = 0; r < 4; ++r) acc[tm][tn][r] = ldexpf((float)acc[tm][tn][r], -bexp);
     }
   }
-  int dbgi = 0;
-  auto stamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
   stamp();
+#ifdef TTR_QR_WSTAMPS
+  // diagnostics build only: per-wave cycle stamps of the first panel's phases, dbg[64 + 40 * wave + 4 * phase + k]
+  auto wstamp = [&](int pn, int k4) {
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && pn == 0) p.dbg[64 + 40 * wave_id + k4] = (long long)clock64();
+  };
+#define TTR_WSTAMP(pn, k4) wstamp(pn, k4)
+#else
+#define TTR_WSTAMP(pn, k4)
+#endif
   const int64_t blk = bt * p.nb + b;
   T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
   T* __restrict__ tau = p.tau + blk * (int64_t)NP;
@@ -262,16 +312,27 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // reflector dot product are then wave-local DPP reductions; the only cross-wave traffic of a
     // Householder step is the reflector itself: ONE barrier per step.  Rows <= jj only exist in q = 0.
     T pc[CPW][NW];  // [column CPW*w + cc][row lane + 64 q]
+    // PAIR keeps its two columns as row PAIRS (pcv[cc][h] = rows lane + 128 h, lane + 128 h + 64): every element-wise
+    // operation of a Householder step is then a packed two-row instruction -- the step chain is bound by the number of
+    // instructions the one active wave has to issue (~8 cycles each, measured), not by their width
+    V2 pcv[2][NW / 2];
     if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Vs[rowl(tm, r) * VLD + cl] = acc[tm][pnl][r];
     lds_barrier();
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc)
+      for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-      for (int q = 0; q < NW; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * CPW + cc];
+        for (int q = 0; q < NW; ++q) pcv[cc][q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + wave * 2 + cc];
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * CPW + cc];
+    }
     lds_barrier();  // all columns are in registers before reflectors start overwriting Vs
     stamp();
     if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
@@ -281,96 +342,135 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // apply it to its remaining columns, ... -- all wave-local, no barrier), publishes the reflectors, and after
     // ONE barrier the waves to its right apply them to their own columns.  A panel costs NW barrier phases
     // instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
-    for (int owv = 0; owv < NW; ++owv) {
-      if (owv * CPW < nsteps) {  // block-uniform
-        if constexpr (PAIR) {
-          static_assert(!PAIR || CPW == 2, "PAIR needs two columns per wave");
-          const int j = owv * 2, jj = j0 + j, jj1 = jj + 1;
-          const bool two = j + 1 < nsteps;  // block-uniform: the second column of the pair takes a step as well
-          if (wave_id == owv) {
+    if constexpr (PAIR) {
+      // Every wave runs its OWN sequence of phases (same number of barriers for all): first the phases of the owners to
+      // its left (barrier, apply their pair), then its own (factor, publish, barrier, deferred stores), then only the
+      // barriers of the owners to its right.  One loop with all three roles under branches made the register allocator
+      // keep the columns in two register sets and copy all 16 values back and forth in every phase.
+      static_assert(!PAIR || (CPW == 2 && NW == 8), "PAIR: two columns per wave, eight waves");
+      constexpr int NH = NW / 2;
+      const int nph = (nsteps + 1) >> 1;            // phases = column pairs that take a step (block-uniform)
+      const bool mine = wave_id < nph;
+      const int napply = mine ? wave_id : nph;
+      const bool live = j0 + wave_id * 2 < n;       // the wave's columns exist
+      for (int owv = 0; owv < napply; ++owv) {
+        const int jj = j0 + owv * 2, jj1 = jj + 1;
+        T* const xb = Xp + (owv & 1) * (64 * XLD) + lane * XLD;
+        lds_barrier();  // the owner's pair (exchange slot), its taus and v0^T v1 are visible
+        TTR_WSTAMP(pnl, 4 * owv + 2);
+        if (live) {     // apply H1 H0 to the two columns
+            const V4* const xr = reinterpret_cast<const V4*>(xb);
+            const V4 r0 = xr[0], r1 = xr[1], r2 = xr[2], r3 = xr[3];
+            const V2 w0[NH] = {V2{r0.x, r0.y}, V2{r0.z, r0.w}, V2{r1.x, r1.y}, V2{r1.z, r1.w}};
+            const V2 w1[NH] = {V2{r2.x, r2.y}, V2{r2.z, r2.w}, V2{r3.x, r3.y}, V2{r3.z, r3.w}};
+            const T ta = taus[jj], tb = taus[jj1], t12 = pairt[owv];
+            V2 e0 = w0[0] * pcv[0][0], e1 = w0[0] * pcv[1][0], e2 = w1[0] * pcv[0][0], e3 = w1[0] * pcv[1][0];
+#pragma unroll
+            for (int h = 1; h < NH; ++h) {
+              e0 = w0[h] * pcv[0][h] + e0; e1 = w0[h] * pcv[1][h] + e1;
+              e2 = w1[h] * pcv[0][h] + e2; e3 = w1[h] * pcv[1][h] + e3;
+            }
+            T d4[4] = {e0.x + e0.y, e1.x + e1.y, e2.x + e2.y, e3.x + e3.y};
+            wave_sum4(d4);
+            const T a0a = ta * d4[0], a0b = ta * d4[1];
+            const T a1a = tb * (d4[2] - t12 * a0a), a1b = tb * (d4[3] - t12 * a0b);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+              pcv[0][h] = (pcv[0][h] - a0a * w0[h]) - a1a * w1[h];
+              pcv[1][h] = (pcv[1][h] - a0b * w0[h]) - a1b * w1[h];
+            }
+        }
+        TTR_WSTAMP(pnl, 4 * owv + 3);
+      }
+      if (mine) {
+        const int owv = wave_id;
+        const int j = owv * 2, jj = j0 + j, jj1 = jj + 1;
+        const bool two = j + 1 < nsteps;  // the second column of the pair takes a step as well
+        T* const xb = Xp + (owv & 1) * (64 * XLD) + lane * XLD;  // this phase's exchange slot of the lane
+        TTR_WSTAMP(pnl, 4 * owv + 0);
+        {
+            V2 v0[NH], v1[NH];
+            T t0 = T(0), t1 = T(0);
             // ---- column 0: x0 = sub-column below the pivot; ||x0||^2 and x0 . c1 in one 2-value reduction
-            T x0[NW];
-            x0[0] = (lane > jj) ? pc[0][0] : T(0);
+            V2 x0[NH];
+            x0[0] = pcv[0][0];
+            if (!(lane > jj)) x0[0].x = T(0);
 #pragma unroll
-            for (int q = 1; q < NW; ++q) x0[q] = pc[0][q];
-            T s00 = x0[0] * x0[0], s01 = x0[0] * pc[1][0];
+            for (int h = 1; h < NH; ++h) x0[h] = pcv[0][h];
+            V2 e00 = x0[0] * x0[0], e01 = x0[0] * pcv[1][0];
 #pragma unroll
-            for (int q = 1; q < NW; ++q) { s00 += x0[q] * x0[q]; s01 += x0[q] * pc[1][q]; }
+            for (int h = 1; h < NH; ++h) { e00 = x0[h] * x0[h] + e00; e01 = x0[h] * pcv[1][h] + e01; }
+            T s00 = e00.x + e00.y, s01 = e01.x + e01.y;
             wave_sum2(s00, s01);
-            const T alpha0 = lane_get(pc[0][0], jj);
-            T beta0, t0, sc0;
+            const T alpha0 = lane_get(pcv[0][0].x, jj);
+            T beta0, sc0;
             if (s00 == T(0)) { beta0 = alpha0; t0 = T(0); sc0 = T(0); }  // LAPACK larfg: H = I
             else larfg_scalars(alpha0, s00, beta0, t0, sc0);
-            T v0[NW];
-            v0[0] = (lane > jj) ? x0[0] * sc0 : (lane == jj ? T(1) : T(0));
 #pragma unroll
-            for (int q = 1; q < NW; ++q) v0[q] = x0[q] * sc0;
+            for (int h = 0; h < NH; ++h) v0[h] = x0[h] * sc0;
+            if (!(lane > jj)) v0[0].x = (lane == jj) ? T(1) : T(0);
             {  // H0 on column 1: v0^T c1 = sc0 * x0^T c1 + c1[jj]
-              const T f = t0 * (sc0 * s01 + lane_get(pc[1][0], jj));
+              const T f = t0 * (sc0 * s01 + lane_get(pcv[1][0].x, jj));
 #pragma unroll
-              for (int q = 0; q < NW; ++q) pc[1][q] -= f * v0[q];
+              for (int h = 0; h < NH; ++h) pcv[1][h] = pcv[1][h] - f * v0[h];
             }
-            if (lane == jj) pc[0][0] = beta0;  // R[jj][jj]
+            if (lane == jj) pcv[0][0].x = beta0;  // R[jj][jj]
             // ---- column 1: ||x1||^2 and v0 . x1 (for v0^T v1) in one 2-value reduction
-            T v1[NW], t1 = T(0), t12 = T(0);
+            T t12 = T(0);
             if (two) {
-              T x1[NW];
-              x1[0] = (lane > jj1) ? pc[1][0] : T(0);
+              V2 x1[NH];
+              x1[0] = pcv[1][0];
+              if (!(lane > jj1)) x1[0].x = T(0);
 #pragma unroll
-              for (int q = 1; q < NW; ++q) x1[q] = pc[1][q];
-              T s11 = x1[0] * x1[0], s0v = v0[0] * x1[0];
+              for (int h = 1; h < NH; ++h) x1[h] = pcv[1][h];
+              V2 e11 = x1[0] * x1[0], e0v = v0[0] * x1[0];
 #pragma unroll
-              for (int q = 1; q < NW; ++q) { s11 += x1[q] * x1[q]; s0v += v0[q] * x1[q]; }
+              for (int h = 1; h < NH; ++h) { e11 = x1[h] * x1[h] + e11; e0v = v0[h] * x1[h] + e0v; }
+              T s11 = e11.x + e11.y, s0v = e0v.x + e0v.y;
               wave_sum2(s11, s0v);
-              const T alpha1 = lane_get(pc[1][0], jj1);
+              const T alpha1 = lane_get(pcv[1][0].x, jj1);
               T beta1, sc1;
               if (s11 == T(0)) { beta1 = alpha1; t1 = T(0); sc1 = T(0); }
               else larfg_scalars(alpha1, s11, beta1, t1, sc1);
-              v1[0] = (lane > jj1) ? x1[0] * sc1 : (lane == jj1 ? T(1) : T(0));
 #pragma unroll
-              for (int q = 1; q < NW; ++q) v1[q] = x1[q] * sc1;
-              t12 = sc1 * s0v + lane_get(v0[0], jj1);  // v1 = sc1 * x1 below row jj1, 1 on it
-              if (lane == jj1) pc[1][0] = beta1;
+              for (int h = 0; h < NH; ++h) v1[h] = x1[h] * sc1;
+              if (!(lane > jj1)) v1[0].x = (lane == jj1) ? T(1) : T(0);
+              t12 = sc1 * s0v + lane_get(v0[0].x, jj1);  // v1 = sc1 * x1 below row jj1, 1 on it
+              if (lane == jj1) pcv[1][0].x = beta1;
             } else {
 #pragma unroll
-              for (int q = 0; q < NW; ++q) v1[q] = T(0);
+              for (int h = 0; h < NH; ++h) v1[h] = V2{T(0), T(0)};
             }
+            // publish the pair: four 16-byte stores per lane
+            V4* const xw = reinterpret_cast<V4*>(xb);
+            xw[0] = V4{v0[0].x, v0[0].y, v0[1].x, v0[1].y};
+            xw[1] = V4{v0[2].x, v0[2].y, v0[3].x, v0[3].y};
+            xw[2] = V4{v1[0].x, v1[0].y, v1[1].x, v1[1].y};
+            xw[3] = V4{v1[2].x, v1[2].y, v1[3].x, v1[3].y};
+            if (lane == 0) { taus[jj] = t0; taus[jj1] = t1; pairt[owv] = t12; }
+        }
+        TTR_WSTAMP(pnl, 4 * owv + 1);
+        lds_barrier();
+        TTR_WSTAMP(pnl, 4 * owv + 2);
+        {
+            // off the critical path (the other waves are applying the pair): the reflectors go to the [row][j] panel
+            // image the MFMA phases read, and to the workspace (transposed: 256 contiguous bytes per store)
+            // (read back from the exchange slot: keeping the pair in registers across the barrier costs spills)
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
-              Vs[(lane + 64 * q) * VLD + j] = v0[q];
-              Vs[(lane + 64 * q) * VLD + j + 1] = v1[q];
+              const T a = xb[q], c = xb[NW + q];
+              Vs[(lane + 64 * q) * VLD + j] = a;
+              Vs[(lane + 64 * q) * VLD + j + 1] = c;
+              Vt[(int64_t)jj * BR + lane + 64 * q] = a;
+              Vt[(int64_t)jj1 * BR + lane + 64 * q] = c;
             }
-            if (lane == 0) {
-              tau[jj] = t0; taus[jj] = t0;
-              if (two) { tau[jj1] = t1; taus[jj1] = t1; }
-              pairt[owv] = t12;
-            }
-          }
-          lds_barrier();  // the owner's pair (two columns of Vs), its taus and v0^T v1 are visible
-          if (wave_id > owv && j0 + wave_id * 2 < n) {  // waves right of the owner apply H1 H0 to their two columns
-            T v0[NW], v1[NW];
-#pragma unroll
-            for (int q = 0; q < NW; ++q) {
-              v0[q] = Vs[(lane + 64 * q) * VLD + j];
-              v1[q] = Vs[(lane + 64 * q) * VLD + j + 1];
-            }
-            const T t0 = taus[jj], t1 = two ? taus[jj1] : T(0), t12 = pairt[owv];
-            T d4[4] = {v0[0] * pc[0][0], v0[0] * pc[1][0], v1[0] * pc[0][0], v1[0] * pc[1][0]};
-#pragma unroll
-            for (int q = 1; q < NW; ++q) {
-              d4[0] += v0[q] * pc[0][q]; d4[1] += v0[q] * pc[1][q];
-              d4[2] += v1[q] * pc[0][q]; d4[3] += v1[q] * pc[1][q];
-            }
-            wave_sum4(d4);
-            const T a0a = t0 * d4[0], a0b = t0 * d4[1];
-            const T a1a = t1 * (d4[2] - t12 * a0a), a1b = t1 * (d4[3] - t12 * a0b);
-#pragma unroll
-            for (int q = 0; q < NW; ++q) {
-              pc[0][q] -= a0a * v0[q] + a1a * v1[q];
-              pc[1][q] -= a0b * v0[q] + a1b * v1[q];
-            }
-          }
-        } else {
+            if (lane == 0) { tau[jj] = taus[jj]; tau[jj1] = taus[jj1]; }
+        }
+        for (int k = owv + 1; k < nph; ++k) lds_barrier();
+      }
+    } else {
+    for (int owv = 0; owv < NW; ++owv) {
+      if (owv * CPW < nsteps) {  // block-uniform
         if (wave_id == owv) {  // wave-uniform: local Householder QR of columns CPW*owv .. CPW*owv + CPW-1
           auto local = [&](auto OC) {
             constexpr int oc = decltype(OC)::value;
@@ -451,8 +551,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             }
           }
         }
-        }
       }
+    }
     }
     stamp();
     {
@@ -463,18 +563,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       for (int cc = 0; cc < CPW; ++cc) {
         const int c = j0 + wave_id * CPW + cc;
         if (c < n && lane < rr) {
-          T rv = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
+          T rv;
+          if constexpr (PAIR) rv = (lane <= c && lane < kb) ? (cc == 0 ? pcv[0][0].x : pcv[1][0].x) : T(0);
+          else rv = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
           if constexpr (sizeof(T) == 4) { if (bexp != 0) rv = ldexpf((float)rv, bexp); }
           Ro[(int64_t)lane * p.ldr + c] = rv;
         }
       }
     }
     if constexpr (PAIR) {
-      // the whole panel's reflectors to the workspace, transposed (thread = row: 256 contiguous bytes per wave and
-      // store); Vs is complete after the last phase's barrier, unused reflectors are zero columns
-#pragma unroll
-      for (int j = 0; j < PW; ++j) Vt[(int64_t)(j0 + j) * BR + tid] = Vs[tid * VLD + j];
-      if (tid < PW && tid >= nsteps) tau[j0 + tid] = T(0);
+      // the owners stored their pairs themselves; columns no phase covered are identity reflectors
+      for (int j = (nsteps + 1) & ~1; j < PW; ++j) Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
+      if (tid < PW && tid >= ((nsteps + 1) & ~1)) tau[j0 + tid] = T(0);
     } else {
       for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
         Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
@@ -484,12 +584,13 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     lds_barrier();
     // (5) S = V^T V over the block (MFMA, K = BR split over the waves), then the triangular factor T
     {
-      Acc s = M::zero();
+      Acc s4[4] = {M::zero(), M::zero(), M::zero(), M::zero()};  // four chains: a dependent MFMA waits ~40 cycles
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const T a = Vs[(wave * 64 + ks * 4 + g) * VLD + cl];
-        s = M::mma(a, a, s);
+        s4[ks & 3] = M::mma(a, a, s4[ks & 3]);
       }
+      const Acc s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][cl] = s[r];
     }
@@ -501,19 +602,38 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       Ss[i * VLD + k] = acc_s;
     }
     lds_barrier();
-    if (tid < PW) {  // larft (forward, columnwise): T[0:j,j] = -tau_j T[0:j,0:j] S[0:j,j], T[j][j] = tau_j
-      const int i = tid;
-      T trow[PW];
-#pragma unroll
-      for (int jc = 0; jc < PW; ++jc) {
-        T a2 = 0;
-#pragma unroll
-        for (int k = 0; k < jc; ++k) a2 += (k >= i ? trow[k] : T(0)) * Ss[k * VLD + jc];
-        const T tj = taus[j0 + jc];
-        trow[jc] = (i < jc) ? -tj * a2 : (i == jc ? tj : T(0));
-        Ts[i * VLD + jc] = trow[jc];
-        Tg[pnl * PW * PW + i * PW + jc] = trow[jc];
+    if (wave_id == 0) {
+      // The triangular factor T (larft): T = (strict_upper(S) + diag(1 / tau))^-1, built by recursive doubling instead
+      // of the column recurrence (16 dependent steps of up to 15 FMAs on 16 lanes: ~5 k cycles per panel, measured):
+      // two diagonal blocks T11, T22 of width h are joined by  T12 = -T11 S12 T22  for h = 1, 2, 4, 8 -- two small
+      // products per level, one output element per lane, wave-local LDS exchange (no workgroup barrier).
+      for (int e = lane; e < PW * PW; e += 64) {
+        const int i = e >> 4, k = e & 15;
+        Ts[i * VLD + k] = (i == k) ? taus[j0 + i] : T(0);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 1; h < PW; h <<= 1) {
+        const int hh = h * h;
+        const int bq = lane / hh, rr2 = lane % hh, i = rr2 / h, jx = rr2 % h;
+        const int o = bq * 2 * h;           // the block pair covers rows / columns o .. o + 2h - 1
+        const bool act = lane < 8 * h;      // 16 / (2h) block pairs x h^2 outputs
+        if (act) {                          // X = S12 T22
+          T x = T(0);
+#pragma unroll
+          for (int k = 0; k < h; ++k) x += Ss[(o + i) * VLD + o + h + k] * Ts[(o + h + k) * VLD + o + h + jx];
+          Xs[(o + i) * VLD + jx] = x;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (act) {                          // T12 = -T11 X
+          T t = T(0);
+#pragma unroll
+          for (int k = 0; k < h; ++k) t += Ts[(o + i) * VLD + o + k] * Xs[(o + k) * VLD + jx];
+          Ts[(o + i) * VLD + o + h + jx] = -t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      for (int e = lane; e < PW * PW; e += 64) Tg[pnl * PW * PW + e] = Ts[(e >> 4) * VLD + (e & 15)];
     }
     // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand.  W does not
     // depend on T: it is formed in the same barrier interval as the (serial, 16-lane) larft recurrence above, so
