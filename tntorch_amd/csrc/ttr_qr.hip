@@ -160,49 +160,71 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       // of four K steps with the NEXT group's loads in flight under the current group's MFMAs: with one K step per
       // round trip (16 KiB in flight per CU) the whole phase ran at the memory latency -- 64 k of a block's 189 k cycles
       // under load (cycle stamps) -- two groups keep 64 KiB per block in flight.
-      const T* __restrict__ Cn = p.Cn + bt * p.strideCn + (int64_t)imode * n;
-      const int64_t cstride = (int64_t)p.pI * n;  // r0 stride
+      // Addressing: a wave-uniform row pointer (SGPR pair, advanced per K step) plus ONE per-lane 32-bit element offset
+      // -- the loads are issued back to back without per-load address arithmetic; partial shapes (ragged mode / rank /
+      // column counts) take the general path: unconditional loads from clamped offsets, masked afterwards (no branches).
+      const int imode_u = b * NW + wave_id;  // = imode, provably wave-uniform
+      const T* __restrict__ Cb = p.Cn + bt * p.strideCn;
+      const unsigned cs = (unsigned)p.pI * (unsigned)n;  // r0 stride in elements (host checks pRin * pI * n < 2^31)
+      const unsigned loff = (unsigned)g * cs + (unsigned)cl;
+      const bool full = ivalid && n == NP && (p.pRin & 15) == 0;  // wave-uniform: every element of every group exists
       constexpr int KG = 4;
-      T bvA[KG][NT], bvB[KG][NT];
-      auto load_group = [&](int grp, T (&bv)[KG][NT]) {
+      const int ngroups = (ksteps + KG - 1) / KG;  // <= 4 (pRin <= 64)
+      auto stream = [&](auto FULL) {
+        constexpr bool kFull = decltype(FULL)::value != 0;
+        T bvA[KG][NT], bvB[KG][NT];
+        auto load_group = [&](int grp, T (&bv)[KG][NT]) {
+          if constexpr (kFull) {
+            const T* __restrict__ rowp = Cb + (size_t)imode_u * n + (size_t)(grp * KG * 4) * cs;
 #pragma unroll
-        for (int kk = 0; kk < KG; ++kk) {
-          const int r0 = (grp * KG + kk) * 4 + g;
+            for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-          for (int tn = 0; tn < NT; ++tn) {
-            const int col = tn * PW + cl;
-            bv[kk][tn] = (ivalid && r0 < p.pRin && col < n) ? Cn[(int64_t)r0 * cstride + col] : T(0);
+              for (int tn = 0; tn < NT; ++tn) bv[kk][tn] = rowp[(size_t)(kk * 4) * cs + loff + tn * PW];
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+              const int r0 = (grp * KG + kk) * 4 + g;
+#pragma unroll
+              for (int tn = 0; tn < NT; ++tn) {
+                const int col = tn * PW + cl;
+                const bool ok = ivalid && r0 < p.pRin && col < n;
+                const unsigned o = ok ? (unsigned)imode_u * (unsigned)n + (unsigned)r0 * cs + (unsigned)col : 0u;
+                const T v = Cb[o];
+                bv[kk][tn] = ok ? v : T(0);
+              }
+            }
+          }
+        };
+        auto mma_group = [&](int grp, const T (&bv)[KG][NT]) {
+#pragma unroll
+          for (int kk = 0; kk < KG; ++kk) {
+            const int r0 = (grp * KG + kk) * 4 + g;  // rows >= pRin: the staged Rs column is zero (and bv is zero)
+            T av[4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[kk][tn], acc[tm][tn]);
+          }
+        };
+        load_group(0, bvA);  // in flight while Rs is being staged
+        lds_barrier();
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
+        for (int grp = 0; grp < ngroups; grp += 2) {
+          if (grp + 1 < ngroups) load_group(grp + 1, bvB);
+          mma_group(grp, bvA);
+          if (grp + 1 < ngroups) {
+            if (grp + 2 < ngroups) load_group(grp + 2, bvA);
+            mma_group(grp + 1, bvB);
           }
         }
       };
-      auto mma_group = [&](int grp, const T (&bv)[KG][NT]) {
-#pragma unroll
-        for (int kk = 0; kk < KG; ++kk) {
-          const int r0 = (grp * KG + kk) * 4 + g;  // rows >= pRin: the staged Rs column is zero (and bv is zero)
-          T av[4];
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[kk][tn], acc[tm][tn]);
-        }
-      };
-      const int ngroups = (ksteps + KG - 1) / KG;  // <= 4 (pRin <= 64)
-      load_group(0, bvA);  // in flight while Rs is being staged
-      lds_barrier();
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
-      for (int grp = 0; grp < ngroups; grp += 2) {
-        if (grp + 1 < ngroups) load_group(grp + 1, bvB);
-        mma_group(grp, bvA);
-        if (grp + 1 < ngroups) {
-          if (grp + 2 < ngroups) load_group(grp + 2, bvA);
-          mma_group(grp + 1, bvB);
-        }
-      }
+      if (full) stream(IC<1>{});
+      else stream(IC<0>{});
     } else {
       lds_barrier();
 #pragma unroll
@@ -1047,6 +1069,8 @@ static int pushed_ok(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n) {
   TTR_REQUIRE(k >= 1 && k <= 64 && Rin >= 1 && Rin <= 64 && I >= 1 && n >= 1 && n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED,
               "ttr_qr_*_pushed: k, Rin, n must be <= 64 (got %lld, %lld, %lld)", (long long)k, (long long)Rin, (long long)n);
   TTR_REQUIRE(k * I >= n, TTR_E_UNSUPPORTED, "ttr_qr_*_pushed: needs k*I >= n (tall unfolding)");
+  TTR_REQUIRE(Rin * I * n < (int64_t(1) << 31), TTR_E_UNSUPPORTED,
+              "ttr_qr_*_pushed: core of %lld elements exceeds the kernel's 32-bit element offsets", (long long)(Rin * I * n));
   return TTR_OK;
 }
 
