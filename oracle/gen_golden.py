@@ -319,6 +319,30 @@ def case_producers():
                            "ref": "tensor.py:687-773, 2309-2320; tools.py:460-512", "dtype": "float64"}, **groups)
 
 
+def case_consumers():
+    """tools.shift_mode (tools.py:650-697) and matrix.TTMatrix construction / torch() / trace() (matrix.py:23-175)."""
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(23)
+    g = tn.rand([5, 6, 7, 4, 8], ranks_tt=[3, 4, 5, 2])
+    groups = {"g": npl(g.cores)}
+    specs = [(1, 2, 1e-3), (3, -2, 1e-6), (0, 4, "same"), (4, -4, 1e-2), (2, 1, 0.3)]
+    for k, (n, sh, eps) in enumerate(specs):
+        t = tn.Tensor([c.clone() for c in g.cores])
+        tn.shift_mode(t, n, sh, eps=eps)  # in place (returns None for shift != 0)
+        groups[f"shift{k}"] = npl(t.cores)
+    m = torch.rand(11 * 3 * 4, 23 * 2 * 3)
+    ttm = tn.TTMatrix(m, input_dims=[11, 3, 4], output_dims=[23, 2, 3], ranks=[20, 7])
+    sq = torch.rand(6 * 5, 6 * 5)
+    tsq = tn.TTMatrix(sq, input_dims=[6, 5], output_dims=[6, 5], ranks=[36])
+    groups.update({"m": m.numpy(), "ttm_cores": npl(ttm.cores), "ttm_dense": ttm.torch().numpy(), "sq": sq.numpy(),
+                   "tsq_cores": npl(tsq.cores), "tsq_trace": np.asarray(tsq.trace().item())})
+    save("consumers_f64", {"what": "tn.shift_mode on a rank-(3,4,5,2) TT for (n, shift, eps) in " + repr(specs)
+                           + "; tn.TTMatrix(rand(132, 138), input_dims=[11,3,4], output_dims=[23,2,3], ranks=[20,7]) cores / "
+                           "torch(); TTMatrix(rand(30, 30), [6,5], [6,5], ranks=[36]).trace()",
+                           "ref": "tools.py:650-697; matrix.py:23-175", "dtype": "float64", "shift_specs": [list(map(str, sp)) for sp in specs]},
+         **groups)
+
+
 def case_known_answers():
     """docs/tutorials/decompositions.ipynb cells 1, 3, 18 (analytic 128^3 function)."""
     torch.set_default_dtype(torch.float64)
@@ -346,7 +370,7 @@ def case_known_answers():
 
 CASES = [case_round_eps_f64, case_round_rmax_f32, case_round_batch_f64, case_dense_f64, case_dense_batch_f32, case_c0,
          case_truncated_svd, case_orthogonalize, case_round_tucker, case_ctor_tucker, case_round_general, case_cp_als,
-         case_producers, case_known_answers]
+         case_producers, case_consumers, case_known_answers]
 
 if __name__ == "__main__":
     # no arguments: regenerate everything; otherwise only the named cases (the CP-ALS case is reproducible only

@@ -55,6 +55,10 @@ __all__ = [
     "tt_norm",
     "bond_singular_values",
     "gauge_align",
+    "shift_mode",
+    "ttmatrix_cores",
+    "ttmatrix_to_dense",
+    "ttmatrix_trace",
 ]
 
 Cores = List[torch.Tensor]
@@ -647,3 +651,66 @@ def gauge_align(ref: Sequence[torch.Tensor], ours: Sequence[torch.Tensor]) -> Co
         out[k] = out[k] * s[:, None, None]
         out[k - 1] = out[k - 1] * s[None, None, :]
     return out
+
+
+# --------------------------------------------------------------------------
+# consumers next to the path: tools.shift_mode, matrix.TTMatrix
+# --------------------------------------------------------------------------
+def shift_mode(cores: Sequence[torch.Tensor], n: int, shift: int, eps=1e-3, algorithm: str = "svd") -> Cores:
+    """tools.py:650-697 on pure TT cores (non-batch): orthogonalise at ``n`` (tools.py:667), then per exchange contract
+    the two cores with swapped modes (``einsum("iaj,jbk->ibak")``, tools.py:680-681) and split by truncated_svd with
+    ``eps / sqrt(|shift|)`` or, for ``eps == 'same'``, ``eps=0, rmax=R2`` (tools.py:682-692)."""
+    cores = [c.clone() for c in cores]
+    N = len(cores)
+    assert 0 <= n + shift < N
+    if shift == 0:
+        return cores
+    orthogonalize(cores, n)
+    sign = 1 if shift > 0 else -1
+    for i in range(n, n + shift, sign):
+        c1, c2, left_ortho = (i, i + 1, True) if sign == 1 else (i - 1, i, False)
+        R1, I1, R2 = cores[c1].shape
+        _, I2, R3 = cores[c2].shape
+        sc = torch.einsum("iaj,jbk->ibak", cores[c1], cores[c2]).reshape(R1 * I2, I1 * R3)
+        if isinstance(eps, str):
+            if eps != "same":
+                raise ValueError("Relative error '{}' not recognized".format(eps))
+            left, right = truncated_svd(sc, eps=0, rmax=R2, left_ortho=left_ortho, algorithm=algorithm)
+        elif eps >= 0:
+            left, right = truncated_svd(sc, eps=eps / math.sqrt(abs(shift)), left_ortho=left_ortho, algorithm=algorithm)
+        else:
+            raise ValueError("Relative error '{}' not recognized".format(eps))
+        r = left.shape[1]
+        cores[c1] = left.reshape(R1, I2, r)
+        cores[c2] = right.reshape(r, I1, R3)
+    return cores
+
+
+def ttmatrix_cores(M: torch.Tensor, ranks: Sequence[int], input_dims: Sequence[int], output_dims: Sequence[int],
+                   algorithm: str = "svd") -> Cores:
+    """matrix.py:59-111 (non-batch): reshape to i_0..i_{d-1} o_0..o_{d-1}, interleave to (i_k o_k)_k, decompose with
+    ``tn.Tensor(tensor, ranks_tt=ranks)`` and view every core as ``[r, i_k, o_k, r']``."""
+    d = len(input_dims)
+    tensor = M.reshape(list(input_dims) + list(output_dims))
+    perm = [k + off for k in range(d) for off in (0, d)]
+    tensor = tensor.permute(perm).reshape([input_dims[k] * output_dims[k] for k in range(d)])
+    cores = dense_to_tt(tensor, list(ranks), algorithm=algorithm)
+    return [c.reshape(c.shape[0], input_dims[k], output_dims[k], c.shape[-1]) for k, c in enumerate(cores)]
+
+
+def ttmatrix_to_dense(cores4: Sequence[torch.Tensor]) -> torch.Tensor:
+    """matrix.py:113-151: contract the flattened train and undo the interleaving."""
+    d = len(cores4)
+    idims, odims = [c.shape[1] for c in cores4], [c.shape[2] for c in cores4]
+    dense = tt_to_dense([c.reshape(c.shape[0], -1, c.shape[-1]) for c in cores4])
+    dense = dense.reshape([x for k in range(d) for x in (idims[k], odims[k])])
+    rows, cols = math.prod(idims), math.prod(odims)
+    return dense.permute([2 * k for k in range(d)] + [2 * k + 1 for k in range(d)]).reshape(rows, cols)
+
+
+def ttmatrix_trace(cores4: Sequence[torch.Tensor]) -> torch.Tensor:
+    """matrix.py:160-175: ``factor = einsum("i,iaaj->j", factor, core)`` from ``ones(1)``."""
+    factor = torch.ones(1, dtype=cores4[0].dtype)
+    for c in cores4:
+        factor = torch.einsum("i,iaaj->j", factor, c)
+    return factor[0]

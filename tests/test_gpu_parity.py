@@ -918,3 +918,52 @@ def test_fused_add_round_matches_materialised(dt):
     a = oracle.tt_randn([4, 5, 4], 40, dtype=dt)
     fb = tn.Tensor._round_of_sum(gpu_tensor(a), gpu_tensor(a), eps=1e-6)
     assert rel_diff(fb.torch().cpu(), 2 * dense(a)) <= (5e-5 if f32 else 1e-9)
+
+
+# ------------------------------------------------------------------ consumers: shift_mode, TTMatrix
+SHIFT_SPECS = [(1, 2, 1e-3), (3, -2, 1e-6), (0, 4, "same"), (4, -4, 1e-2), (2, 1, 0.3)]
+
+
+@pytest.mark.gpu
+def test_golden_shift_mode_on_device():
+    g = load_case("consumers_f64")
+    src = oracle.tt_to_dense(g["g"])
+    for k, (n, sh, eps) in enumerate(SHIFT_SPECS):
+        t = gpu_tensor(g["g"])
+        r = tn.shift_mode(t, n, sh, eps=eps)
+        assert r is t and all(c.is_cuda for c in t.cores)
+        want = g[f"shift{k}"]
+        assert t.ranks_tt.tolist() == oracle.tt_ranks(want), (k, t.ranks_tt.tolist(), oracle.tt_ranks(want))
+        assert rel_diff(t.torch().cpu(), oracle.tt_to_dense(want)) <= 1e-10, k
+    # float32, larger modes: against the oracle on the same input, and the moved tensor against the permuted source
+    torch.manual_seed(41)
+    cores = oracle.tt_randn([12, 9, 14, 10], [5, 6, 4], dtype=torch.float32)
+    t = gpu_tensor(cores)
+    tn.shift_mode(t, 0, 3, eps=1e-4)
+    want = oracle.shift_mode(cores, 0, 3, eps=1e-4)
+    assert t.ranks_tt.tolist() == oracle.tt_ranks(want)
+    assert rel_diff(t.torch().cpu(), oracle.tt_to_dense([c.double() for c in want])) <= 2e-5
+    assert rel_diff(t.torch().cpu(), oracle.tt_to_dense([c.double() for c in cores]).permute(1, 2, 3, 0)) <= 2e-4
+    assert src is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_golden_ttmatrix_on_device(alg):
+    g = load_case("consumers_f64")
+    ttm = tn.TTMatrix(g["m"].cuda(), input_dims=[11, 3, 4], output_dims=[23, 2, 3], ranks=[20, 7])
+    assert ttm.ranks.tolist() == [20, 7] and all(c.is_cuda for c in ttm.cores)
+    assert [tuple(c.shape) for c in ttm.cores] == [tuple(c.shape) for c in g["ttm_cores"]]
+    assert rel_diff(ttm.torch().cpu(), g["ttm_dense"]) <= 1e-10
+    tsq = tn.TTMatrix(g["sq"].cuda(), input_dims=[6, 5], output_dims=[6, 5], ranks=[36])
+    assert abs(tsq.trace().item() - g["tsq_trace"].item()) <= 1e-10
+    # truncating ranks, float32, batch: against the oracle per item
+    torch.manual_seed(43)
+    mb = torch.rand(3, 16 * 12, 10 * 8, dtype=torch.float32)
+    b = tn.TTMatrix(mb.cuda(), input_dims=[16, 12], output_dims=[10, 8], ranks=[9])
+    assert b.batch and b.ranks.tolist() == [9]
+    for k in range(3):
+        want = oracle.ttmatrix_to_dense(oracle.ttmatrix_cores(mb[k], [9], [16, 12], [10, 8], algorithm=alg))
+        got = b.torch()[k].cpu()
+        assert abs(rel_diff(got, mb[k]) - rel_diff(want, mb[k])) <= 1e-5  # same approximation error
+        assert rel_diff(got, want) <= 5e-4  # flat random spectrum: the rank-9 subspace itself is only defined to ~gap^-1 eps

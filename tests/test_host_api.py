@@ -294,3 +294,60 @@ def test_host_producers_golden():
     # docs/tutorials/arithmetics.ipynb cell 1
     ones = tn.ones([32] * 4)
     assert tn.round((ones + ones) * (ones - 2)).ranks_tt.tolist() == load_meta()["known_answers"]["measured_with_reference_here"]["arith_round_ranks"]
+
+
+# ------------------------------------------------------------------ consumers on the host mirror (8f-4)
+SHIFT_SPECS = [(1, 2, 1e-3), (3, -2, 1e-6), (0, 4, "same"), (4, -4, 1e-2), (2, 1, 0.3)]
+
+
+def test_host_shift_mode_and_ttmatrix_golden():
+    from parity import load_case
+    g = load_case("consumers_f64")
+    for k, (n, sh, eps) in enumerate(SHIFT_SPECS):
+        t = tn.Tensor([c.clone() for c in g["g"]])
+        r = tn.shift_mode(t, n, sh, eps=eps)
+        assert r is t  # in place on the core list (tools.py:650-697)
+        want = g[f"shift{k}"]
+        assert [tuple(c.shape) for c in t.cores] == [tuple(c.shape) for c in want]
+        assert max((a - b).abs().max().item() for a, b in zip(t.cores, want)) < 1e-10
+    t = tn.Tensor([c.clone() for c in g["g"]])
+    assert tn.shift_mode(t, 2, 0) is t
+    with pytest.raises(ValueError):
+        tn.shift_mode(t, 1, 1, eps=-1.0)
+    with pytest.raises(AssertionError):
+        tn.shift_mode(t, 3, 2)
+    ttm = tn.TTMatrix(g["m"], input_dims=[11, 3, 4], output_dims=[23, 2, 3], ranks=[20, 7])
+    assert ttm.ranks.tolist() == [20, 7] and not ttm.batch
+    assert max((a - b).abs().max().item() for a, b in zip(ttm.cores, g["ttm_cores"])) < 1e-10
+    assert (ttm.torch() - g["ttm_dense"]).abs().max() < 1e-12
+    tsq = tn.TTMatrix(g["sq"], input_dims=[6, 5], output_dims=[6, 5], ranks=[36])
+    assert abs(tsq.trace().item() - g["tsq_trace"].item()) < 1e-12
+    again = tn.TTMatrix(ttm.cores, None, [11, 3, 4], [23, 2, 3])  # from pre-processed cores (matrix.py:48-57)
+    assert again.ranks.tolist() == [20, 7] and (again.torch() - g["ttm_dense"]).abs().max() < 1e-12
+    assert list(ttm.flatten().shape) == [11 * 23, 3 * 2, 4 * 3]
+
+
+def test_host_ttmatrix_batch_matches_items():
+    """The reference's batched TTMatrix constructor raises (matrix.py:73 builds a tensor from a list of tuples); here the
+    batch path works and equals the per-item construction."""
+    torch.manual_seed(5)
+    mb = torch.rand(3, 6 * 5, 4 * 3, dtype=torch.float64)
+    b = tn.TTMatrix(mb, input_dims=[6, 5], output_dims=[4, 3], ranks=[5])
+    assert b.batch and [tuple(c.shape) for c in b.cores] == [(3, 1, 6, 4, 5), (3, 5, 5, 3, 1)]
+    for k in range(3):
+        one = tn.TTMatrix(mb[k], input_dims=[6, 5], output_dims=[4, 3], ranks=[5])
+        assert (one.torch() - b.torch()[k]).abs().max() < 1e-12
+    sq = torch.rand(2, 12, 12, dtype=torch.float64)
+    tb = tn.TTMatrix(sq, input_dims=[4, 3], output_dims=[4, 3], ranks=[16])
+    assert (tb.trace() - torch.stack([torch.trace(x) for x in sq])).abs().max() < 1e-11
+
+
+def test_host_decompress_tucker_factors():
+    torch.manual_seed(8)
+    t = tn.rand([5, 6, 7], ranks_tt=3, ranks_tucker=[2, 3, 4], dtype=torch.float64)
+    d = t.decompress_tucker_factors()
+    assert all(U is None for U in d.Us) and (d.torch() - t.torch()).abs().max() < 1e-12
+    d1 = t.decompress_tucker_factors(dim=1)
+    assert d1.Us[0] is not None and d1.Us[1] is None and (d1.torch() - t.torch()).abs().max() < 1e-12
+    moved = tn.shift_mode(tn.Tensor([c.clone() for c in t.cores], Us=[U.clone() for U in t.Us]), 0, 2, eps=1e-10)
+    assert (moved.torch() - t.torch().permute(1, 2, 0)).abs().max() < 1e-8

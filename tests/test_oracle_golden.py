@@ -206,3 +206,23 @@ def test_producers_golden():
     cores3, _ = oracle.reduce_sum(ts, eps=0, rmax=3)
     ref3 = oracle.tt_to_dense(g["red3_cores"])
     assert (oracle.tt_to_dense(cores3) - ref3).norm() / ref3.norm() < 1e-10
+
+
+SHIFT_SPECS = [(1, 2, 1e-3), (3, -2, 1e-6), (0, 4, "same"), (4, -4, 1e-2), (2, 1, 0.3)]
+
+
+def test_consumers_shift_mode_and_ttmatrix():
+    """tools.shift_mode and matrix.TTMatrix against the reference's recorded outputs."""
+    g = load_case("consumers_f64")
+    for k, (n, sh, eps) in enumerate(SHIFT_SPECS):
+        out = oracle.shift_mode(g["g"], n, sh, eps=eps)
+        want = g[f"shift{k}"]
+        assert oracle.tt_ranks(out) == oracle.tt_ranks(want), (k, oracle.tt_ranks(out), oracle.tt_ranks(want))
+        assert _max_abs(out, want) < 1e-10, k
+    cores = oracle.ttmatrix_cores(g["m"], [20, 7], [11, 3, 4], [23, 2, 3])
+    assert [tuple(c.shape) for c in cores] == [tuple(c.shape) for c in g["ttm_cores"]]
+    assert _max_abs(cores, g["ttm_cores"]) < 1e-10
+    assert (oracle.ttmatrix_to_dense(cores) - g["ttm_dense"]).abs().max() < 1e-12
+    tsq = oracle.ttmatrix_cores(g["sq"], [36], [6, 5], [6, 5])
+    assert abs(oracle.ttmatrix_trace(tsq).item() - g["tsq_trace"].item()) < 1e-12
+    assert abs(oracle.ttmatrix_trace(tsq).item() - torch.trace(g["sq"]).item()) < 1e-11

@@ -11,6 +11,7 @@ from .round import *  # noqa: F401,F403
 from .tensor import *  # noqa: F401,F403
 from .create import *  # noqa: F401,F403
 from .metrics import *  # noqa: F401,F403
+from .matrix import *  # noqa: F401,F403
 from . import dist_batch  # noqa: F401
 from ._patch import patch  # noqa: F401
 

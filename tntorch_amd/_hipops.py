@@ -464,6 +464,24 @@ def mode_mul(core4: torch.Tensor, M3: torch.Tensor) -> torch.Tensor:
     return out.reshape(Bt, M3.shape[1], r0, r1).permute(0, 2, 1, 3).contiguous()
 
 
+def merge_swap(c1: torch.Tensor, c2: torch.Tensor) -> torch.Tensor:
+    """Two neighbouring cores [B, R1, I1, R2], [B, R2, I2, R3] contracted over the bond with their modes exchanged
+    (``einsum("iaj,jbk->ibak")``, tools.py:680-681) -> [B, R1*I2, I1*R3]: one batched MFMA GEMM of the left unfolding
+    with the right unfolding; the mode exchange is a layout copy of the product."""
+    Bt, R1, I1, R2 = c1.shape
+    _, _, I2, R3 = c2.shape
+    prod = _hip.gemm(c1.reshape(Bt, R1 * I1, R2), c2.reshape(Bt, R2, I2 * R3))  # [B, R1*I1, I2*R3]
+    return prod.reshape(Bt, R1, I1, I2, R3).permute(0, 1, 3, 2, 4).reshape(Bt, R1 * I2, I1 * R3)
+
+
+def diag_sum(core5: torch.Tensor) -> torch.Tensor:
+    """[B, r0, a, a, r1] -> [B, r0, r1]: sum over the diagonal of the two mode axes (matrix.py:160-175) as a GEMM of the
+    gathered diagonal slices with a ones vector."""
+    Bt, r0, a, _, r1 = core5.shape
+    d = torch.diagonal(core5, dim1=2, dim2=3).contiguous()  # [B, r0, r1, a] (layout copy)
+    return _sum_last(d.reshape(Bt, r0 * r1, a)).reshape(Bt, r0, r1)
+
+
 def factor_orthogonalize(c: List[torch.Tensor], Us, mu: int) -> None:
     """tensor.py:1771-1798: QR of the Tucker factor [B, I, S], R pushed into the core."""
     if Us is None or Us[mu] is None:

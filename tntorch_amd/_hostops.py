@@ -116,6 +116,18 @@ def mode_mul(core4: torch.Tensor, M3: torch.Tensor) -> torch.Tensor:
     return torch.einsum("bijk,baj->biak", core4, M3)
 
 
+def merge_swap(c1: torch.Tensor, c2: torch.Tensor) -> torch.Tensor:
+    """Two neighbouring cores [B, R1, I1, R2], [B, R2, I2, R3] contracted over the bond with their modes exchanged:
+    ``einsum("iaj,jbk->ibak")`` flattened to [B, R1*I2, I1*R3] (tools.py:680-681)."""
+    sc = torch.einsum("ziaj,zjbk->zibak", c1, c2)
+    return sc.reshape(sc.shape[0], sc.shape[1] * sc.shape[2], sc.shape[3] * sc.shape[4])
+
+
+def diag_sum(core5: torch.Tensor) -> torch.Tensor:
+    """[B, r0, a, a, r1] -> [B, r0, r1]: sum of the slices on the diagonal of the two mode axes (matrix.py:160-175)."""
+    return torch.einsum("ziaaj->zij", core5)
+
+
 def factor_orthogonalize(c: List[torch.Tensor], Us, mu: int) -> None:
     """tensor.py:1771-1798: QR of the Tucker factor [B, I, S], R pushed into the core."""
     if Us is None or Us[mu] is None:

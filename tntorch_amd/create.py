@@ -16,25 +16,36 @@ __all__ = ["rand", "randn", "rand_like", "randn_like", "ones", "zeros", "full"]
 
 def _create(function, *shape, ranks_tt=None, ranks_cp=None, ranks_tucker=None, requires_grad=False, device=None,
             batch=False, dtype=None):
-    if ranks_cp is not None or ranks_tucker is not None:
-        raise NotImplementedError("tntorch_amd creates pure TT tensors only (ranks_cp/ranks_tucker are out of scope)")
+    """create.py:210-357 for TT and TT-Tucker tensors: cores ``[R_n, S_n, R_{n+1}]`` and, where a Tucker rank ``S_n`` is
+    given, factors ``[I_n, S_n]`` (create.py:300-320) -- drawn in the reference's order (factor n, then core n)."""
+    if ranks_cp is not None:
+        raise NotImplementedError("tntorch_amd creates TT / TT-Tucker tensors only (ranks_cp is out of scope)")
     if hasattr(shape[0], "__len__"):
         shape = shape[0]
     shape = [int(s) for s in shape]
     N = len(shape) - 1 if batch else len(shape)
     spatial = shape[1:] if batch else shape
-    if ranks_tt is None:
+    if ranks_tt is None and ranks_tucker is None:
         raise ValueError("Specify at least one of: ranks_tt ranks_cp, ranks_tucker")
+    if ranks_tt is None:
+        raise NotImplementedError("tntorch_amd: a pure Tucker tensor (ranks_tucker without ranks_tt) is a CP-cored format, out of scope")
     if not hasattr(ranks_tt, "__len__"):
         ranks_tt = [ranks_tt] * (N - 1)
     ranks = [1] + [int(r) for r in ranks_tt] + [1]
     assert len(ranks) == N + 1
+    if ranks_tucker is None:
+        ranks_tucker = [None] * N
+    elif not hasattr(ranks_tucker, "__len__"):
+        ranks_tucker = [ranks_tucker] * N
+    assert len(ranks_tucker) == N
     lead = [shape[0]] if batch else []
-    cores = [
-        function(lead + [ranks[n], spatial[n], ranks[n + 1]], requires_grad=requires_grad, device=device, dtype=dtype)
-        for n in range(N)
-    ]
-    return Tensor(cores, batch=batch)
+    cores, Us = [], []
+    for n in range(N):
+        S = ranks_tucker[n]
+        Us.append(None if S is None else function(lead + [spatial[n], int(S)], requires_grad=requires_grad, device=device, dtype=dtype))
+        cores.append(function(lead + [ranks[n], spatial[n] if S is None else int(S), ranks[n + 1]], requires_grad=requires_grad,
+                              device=device, dtype=dtype))
+    return Tensor(cores, Us=Us, batch=batch)
 
 
 def rand(*shape, **kwargs):

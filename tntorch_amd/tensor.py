@@ -296,6 +296,26 @@ class Tensor(object):
     def numpy(self):
         return self.torch().detach().cpu().numpy()
 
+    def decompress_tucker_factors(self, dim="all", _clone=True):
+        """Contract Tucker factors into their cores (tensor.py:1576-1637): returns a tensor without factors along ``dim``
+        (an int, a list, or ``'all'``).  ``_clone=False`` rebinds this tensor's cores instead of copying the others."""
+        if isinstance(dim, str) and dim == "all":
+            dims = list(range(self.dim()))
+        elif hasattr(dim, "__len__"):
+            dims = list(dim)
+        else:
+            dims = [dim]
+        c4, Us3 = self._norm4(), self._norm_us()
+        cores, Us = [], []
+        for n in range(self.dim()):
+            if n in dims and self.Us[n] is not None:
+                cores.append(ops_for(c4[n]).mode_mul(c4[n], Us3[n]))
+                Us.append(None)
+            else:
+                cores.append(c4[n].clone() if _clone else c4[n])
+                Us.append(None if self.Us[n] is None else (self.Us[n].clone() if _clone else self.Us[n]))
+        return Tensor(self._denorm(cores), Us=Us, idxs=self.idxs, batch=self.batch)
+
     # ------------------------------------------------------------------ arithmetic used around the hot path
     def _scalar_like(self, value):
         c0 = self.cores[0]

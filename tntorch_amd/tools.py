@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-__all__ = ["unfolding", "right_unfolding", "left_unfolding", "reduce"]
+__all__ = ["unfolding", "right_unfolding", "left_unfolding", "reduce", "shift_mode"]
 
 
 def unfolding(data: torch.Tensor, n: int, batch: bool = False) -> torch.Tensor:
@@ -82,3 +82,45 @@ def reduce(ts, function, eps=0, rmax=np.iinfo(np.int32).max, algorithm="svd", ve
     for g in groups[1:]:
         result = merge(result, g)
     return result
+
+
+def shift_mode(t, n, shift, eps=1e-3):
+    """Move mode ``n`` of a tensor train ``shift`` positions to the right (``shift > 0``) or left, in place on the core list
+    -- same contract as tools.py:650-697: the train is made ``n``-orthogonal, then every exchange of two neighbouring
+    modes contracts the two cores, swaps the mode axes and splits the result again by ``truncated_svd`` (relative error
+    ``eps / sqrt(|shift|)`` per exchange, or ``eps='same'``: the old bond rank is the cap).  On device tensors the
+    contraction is one MFMA GEMM and the split the Gram / eigensolver / projection kernels of the rounding sweep.
+    """
+    from ._dispatch import ops_for
+    from .round import truncated_svd
+
+    N = t.dim()
+    assert 0 <= n + shift < N
+    if shift == 0:
+        return t
+    if t.batch:
+        raise NotImplementedError("shift_mode: batched tensors are not supported (the reference indexes core.shape[0] as a rank)")
+    if any(U is not None for U in t.Us):
+        t = t.decompress_tucker_factors(_clone=False)
+    if isinstance(eps, str):
+        if eps != "same":
+            raise ValueError("Relative error '{}' not recognized".format(eps))
+    elif not eps >= 0:
+        raise ValueError("Relative error '{}' not recognized".format(eps))
+    t.orthogonalize(n)
+    cores = t._norm4()  # [1, r0, I, r1] views (CP factors become TT cores, as the reference's orthogonalize does)
+    sign = 1 if shift > 0 else -1
+    for i in range(n, n + shift, sign):
+        c1, c2, left_ortho = (i, i + 1, True) if sign == 1 else (i - 1, i, False)
+        _, R1, I1, R2 = cores[c1].shape
+        _, _, I2, R3 = cores[c2].shape
+        sc = ops_for(cores[c1]).merge_swap(cores[c1], cores[c2])[0]  # [R1*I2, I1*R3]
+        if isinstance(eps, str):
+            left, right = truncated_svd(sc, eps=0, rmax=R2, left_ortho=left_ortho)
+        else:
+            left, right = truncated_svd(sc, eps=eps / np.sqrt(np.abs(shift)), left_ortho=left_ortho)
+        newR2 = left.shape[1]
+        cores[c1] = left.reshape(1, R1, I2, newR2)
+        cores[c2] = right.reshape(1, newR2, I1, R3)
+    t.cores = t._denorm(cores)
+    return t
