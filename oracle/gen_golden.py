@@ -299,6 +299,28 @@ def case_cp_als():
     save("cp_als", meta, **groups)
 
 
+def case_cp_variants():
+    """Batched CP-ALS and CP on a Tucker core (tensor.py:214-300, the batch / ranks_tucker branches)."""
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(19)
+    Xb = torch.randn(3, 8, 7, 6)
+    tb = tn.Tensor(Xb, ranks_cp=4, batch=True, max_iter=6, tol=-1.0)
+    groups = {"batch_inp": Xb.numpy(), "batch_r4_it6": npl(tb.cores), "batch_dense": tb.torch().numpy()}
+    fac = [torch.randn(i, 3) for i in (9, 8, 7)]
+    low = torch.einsum("ar,br,cr->abc", *fac)
+    X = low / low.norm() + 1e-2 * torch.randn(9, 8, 7) / np.sqrt(low.numel())
+    torch.manual_seed(21)
+    tt = tn.Tensor(X, ranks_cp=3, ranks_tucker=4, max_iter=5, tol=-1.0)
+    torch.manual_seed(21)  # the ALS start the reference drew: randn(S_n, R) per mode, nothing else consumes the RNG before
+    init = [torch.randn(4, 3) for _ in range(3)]
+    groups.update({"tucker_inp": X.numpy(), "tucker_init": npl(init), "tucker_cores": npl(tt.cores), "tucker_Us": npl(tt.Us),
+                   "tucker_dense": tt.torch().numpy()})
+    save("cp_variants_f64", {"what": "tn.Tensor(randn(3,8,7,6), ranks_cp=4, batch=True, max_iter=6, tol=-1); "
+                             "tn.Tensor(X 9x8x7 rank-3 + noise, ranks_cp=3, ranks_tucker=4, max_iter=5, tol=-1) with its recorded randn start",
+                             "ref": "tensor.py:214-400", "dtype": "float64",
+                             "relerr_tucker": tn.relative_error(X, tt).item()}, **groups)
+
+
 def case_producers():
     """TT x TT product and the rounding tree (tensor.py:687-773, tools.py:460-512)."""
     import operator
@@ -369,7 +391,7 @@ def case_known_answers():
 
 
 CASES = [case_round_eps_f64, case_round_rmax_f32, case_round_batch_f64, case_dense_f64, case_dense_batch_f32, case_c0,
-         case_truncated_svd, case_orthogonalize, case_round_tucker, case_ctor_tucker, case_round_general, case_cp_als,
+         case_truncated_svd, case_orthogonalize, case_round_tucker, case_ctor_tucker, case_round_general, case_cp_als, case_cp_variants,
          case_producers, case_consumers, case_known_answers]
 
 if __name__ == "__main__":

@@ -41,6 +41,8 @@ __all__ = [
     "cp_hosvd_init",
     "cp_to_dense",
     "cp_als",
+    "cp_als_batch",
+    "cp_on_tucker_core",
     "full_rank_tt",
     "dense_to_tt",
     "tt_to_dense",
@@ -446,6 +448,59 @@ def cp_als(data: torch.Tensor, R: int, max_iter: int = 25, tol: float = 1e-4, in
         if len(errors) >= 2 and errors[-2] - errors[-1] < tol:  # tensor.py:380-381
             break
     return cores, errors
+
+
+def cp_als_batch(data: torch.Tensor, R: int, max_iter: int = 25, tol: float = 1e-4, init: Optional[Cores] = None):
+    """The ``batch=True`` branches of tensor.py:214-400 on ``data [B, I_1..I_N]``: HOSVD init per item (tensor.py:228-258),
+    bmm sweeps, error of an iteration = MEAN of the items' relative errors (tensor.py:362-372), one convergence decision."""
+    B, N = data.shape[0], data.dim() - 1
+    if init is None:
+        cores = []
+        for n in range(N):
+            gram = unfolding(data, n, batch=True)
+            gram = gram @ _t(gram)
+            eigvals, eigvecs = torch.linalg.eigh(gram)
+            reverse = torch.arange(eigvals.shape[1] - 1, -1, -1)
+            idx = torch.argsort(eigvals)[:, reverse[:R]]
+            c = eigvecs[[[i] for i in range(len(idx))], :, idx].transpose(-1, -2)
+            if c.shape[2] < R:
+                c = torch.cat((c, torch.randn(c.shape[0], c.shape[1], R - c.shape[2], dtype=c.dtype)), dim=2)
+            cores.append(c)
+    else:
+        cores = [c.clone() for c in init]
+    norms = torch.sqrt(torch.sum(data**2, dim=list(range(1, data.dim()))))
+    grams = [None] + [_t(cores[n]) @ cores[n] for n in range(1, N)]
+    errors = []
+    for _ in range(max_iter):
+        for n in range(N):
+            khatri = torch.ones(B, 1, R, dtype=data.dtype)
+            prod = torch.ones(B, R, R, dtype=data.dtype)
+            for m in range(N - 1, -1, -1):
+                if m != n:
+                    prod = prod * grams[m]
+                    khatri = torch.einsum("bir,bjr->bijr", cores[m], khatri).reshape(B, -1, R)
+            unf = unfolding(data, n, batch=True)
+            cores[n] = _t(torch.linalg.lstsq(prod, _t(unf @ khatri)).solution)
+            grams[n] = _t(cores[n]) @ cores[n]
+        rec = torch.stack([cp_to_dense([c[i] for c in cores]) for i in range(B)])
+        err = data - rec
+        errors.append((torch.sqrt(torch.sum(err**2, dim=list(range(1, err.dim())))) / norms).mean())
+        if len(errors) >= 2 and errors[-2] - errors[-1] < tol:
+            break
+    return cores, errors
+
+
+def cp_on_tucker_core(data: torch.Tensor, R: int, ranks_tucker, init: Cores, max_iter: int = 25, tol: float = 1e-4,
+                      algorithm: str = "svd"):
+    """tensor.py:278-300 (non-batch): full-rank TT, ``round_tucker(rmax=ranks_tucker)``, ALS on the dense Tucker core
+    (``tucker_core()``, tensor.py:1702-1715) from the given start (the reference draws ``randn(S_n, R)`` per mode).
+    Returns (CP factors of the core, Tucker factors, errors)."""
+    N = data.dim()
+    rtk = list(ranks_tucker) if hasattr(ranks_tucker, "__len__") else [ranks_tucker] * N
+    cores, Us = round_tucker(full_rank_tt(data), None, rmax=rtk, algorithm=algorithm)
+    core = tt_to_dense(cores)
+    fac, errors = cp_als(core, R, max_iter=max_iter, tol=tol, init=init)
+    return fac, Us, errors
 
 
 # --------------------------------------------------------------------------

@@ -967,3 +967,35 @@ def test_golden_ttmatrix_on_device(alg):
         got = b.torch()[k].cpu()
         assert abs(rel_diff(got, mb[k]) - rel_diff(want, mb[k])) <= 1e-5  # same approximation error
         assert rel_diff(got, want) <= 5e-4  # flat random spectrum: the rank-9 subspace itself is only defined to ~gap^-1 eps
+
+
+@pytest.mark.gpu
+def test_golden_cp_variants_on_device():
+    """Batched CP-ALS (lock-step items, batch-mean convergence) and CP on a Tucker core on the device."""
+    g = load_case("cp_variants_f64")
+    tb = tn.Tensor(g["batch_inp"].cuda(), ranks_cp=4, batch=True, max_iter=6, tol=-1.0)
+    assert tb.batch and all(c.is_cuda for c in tb.cores) and len(tb.cp_errors) == 6
+    want = g["batch_dense"]
+    got = tb.torch().cpu()
+    # the same ALS sweeps from the same HOSVD start (eigenvector signs cancel in the CP reconstruction)
+    assert rel_diff(got, want) <= 1e-6
+    errs = [(got[i] - g["batch_inp"][i]).norm() / g["batch_inp"][i].norm() for i in range(3)]
+    assert abs(torch.stack(errs).mean().item() - tb.cp_errors[-1]) <= 1e-6
+    # CP on a Tucker core.  The ALS itself, deterministically: the reference's Tucker core and its recorded random start
+    from tntorch_amd import _hipops
+    X = g["tucker_inp"]
+    core = torch.einsum("ijk,ia,jb,kc->abc", X, *g["tucker_Us"])
+    fac, errs = _hipops.cp_als(core.cuda(), 3, 5, -1.0, init=[f.cuda() for f in g["tucker_init"]])
+    assert len(errs) == 5 and all(b <= a + 1e-12 for a, b in zip(errs, errs[1:]))
+    assert rel_diff(oracle.cp_to_dense([f.cpu() for f in fac]), oracle.cp_to_dense(g["tucker_cores"])) <= 1e-6
+    # ... and through the constructor (the device draws its own start; ALS from a random start can stall in a swamp, on
+    # the CPU just as well, so only structure and monotonicity are asserted)
+    torch.manual_seed(0)
+    tt = tn.Tensor(X.cuda(), ranks_cp=3, ranks_tucker=4, max_iter=25)
+    assert [tuple(c.shape) for c in tt.cores] == [(4, 3)] * 3 and [tuple(U.shape) for U in tt.Us] == [(9, 4), (8, 4), (7, 4)]
+    assert all(c.is_cuda for c in tt.cores) and all(U.is_cuda for U in tt.Us)
+    assert all(b <= a + 1e-9 for a, b in zip(tt.cp_errors, tt.cp_errors[1:])) and tt.cp_errors[-1] < 0.6
+    assert rel_diff(tt.torch().cpu(), X) < 0.6
+    Xb = torch.stack([X, X.flip(0)])
+    tbt = tn.Tensor(Xb.cuda(), ranks_cp=3, ranks_tucker=[4, 4, 4], batch=True, max_iter=8)
+    assert tbt.batch and [tuple(c.shape) for c in tbt.cores] == [(2, 4, 3)] * 3 and rel_diff(tbt.torch().cpu(), Xb) < 0.7

@@ -175,8 +175,8 @@ def test_api_errors_and_quirks():
         t.round_tt(rmax=[1])
     with pytest.raises(AssertionError):
         t.left_orthogonalize(2)
-    with pytest.raises(NotImplementedError):
-        tn.Tensor(torch.rand(3, 4, 4, 4), ranks_cp=2, batch=True)   # batched CP-ALS is out of scope
+    with pytest.raises(ValueError, match="CP-TT"):
+        tn.Tensor(torch.rand(4, 4, 4), ranks_cp=2, ranks_tt=2)       # tensor.py:211-212
     # quirks 1, 5, 13, 14
     assert tn.Tensor(torch.ones(4, 4, 4), ranks_tt=3).ranks_tt.tolist() == [1, 1, 1, 1]
     z = tn.Tensor([torch.zeros(1, 5, 3), torch.zeros(3, 5, 3), torch.zeros(3, 5, 1)])
@@ -351,3 +351,19 @@ def test_host_decompress_tucker_factors():
     assert d1.Us[0] is not None and d1.Us[1] is None and (d1.torch() - t.torch()).abs().max() < 1e-12
     moved = tn.shift_mode(tn.Tensor([c.clone() for c in t.cores], Us=[U.clone() for U in t.Us]), 0, 2, eps=1e-10)
     assert (moved.torch() - t.torch().permute(1, 2, 0)).abs().max() < 1e-8
+
+
+def test_host_cp_variants_golden():
+    """Batched CP-ALS and CP on a Tucker core on the host mirror = the reference's recorded outputs."""
+    from parity import load_case
+    g = load_case("cp_variants_f64")
+    tb = tn.Tensor(g["batch_inp"], ranks_cp=4, batch=True, max_iter=6, tol=-1.0)
+    assert tb.batch and [tuple(c.shape) for c in tb.cores] == [(3, 8, 4), (3, 7, 4), (3, 6, 4)] and len(tb.cp_errors) == 6
+    assert max((a - b).abs().max().item() for a, b in zip(tb.cores, g["batch_r4_it6"])) < 1e-7
+    assert (tb.torch() - g["batch_dense"]).abs().max() < 1e-7
+    torch.manual_seed(21)
+    tt = tn.Tensor(g["tucker_inp"], ranks_cp=3, ranks_tucker=4, max_iter=5, tol=-1.0)
+    assert [tuple(c.shape) for c in tt.cores] == [(4, 3)] * 3 and [tuple(U.shape) for U in tt.Us] == [(9, 4), (8, 4), (7, 4)]
+    assert (tt.torch() - g["tucker_dense"]).abs().max() < 1e-8
+    with pytest.raises(ValueError):
+        tn.Tensor(g["tucker_inp"], ranks_cp=3, ranks_tt=2)

@@ -226,3 +226,16 @@ def test_consumers_shift_mode_and_ttmatrix():
     tsq = oracle.ttmatrix_cores(g["sq"], [36], [6, 5], [6, 5])
     assert abs(oracle.ttmatrix_trace(tsq).item() - g["tsq_trace"].item()) < 1e-12
     assert abs(oracle.ttmatrix_trace(tsq).item() - torch.trace(g["sq"]).item()) < 1e-11
+
+
+def test_cp_variants_golden():
+    """Batched CP-ALS and CP on a Tucker core (tensor.py:214-300) against the reference's recorded factors."""
+    g = load_case("cp_variants_f64")
+    cores, errors = oracle.cp_als_batch(g["batch_inp"], 4, max_iter=6, tol=-1.0)
+    assert len(errors) == 6
+    assert max((a - b).abs().max().item() for a, b in zip(cores, g["batch_r4_it6"])) < 1e-7
+    fac, Us, _ = oracle.cp_on_tucker_core(g["tucker_inp"], 3, 4, g["tucker_init"], max_iter=5, tol=-1.0)
+    assert max((a - b).abs().max().item() for a, b in zip(fac, g["tucker_cores"])) < 1e-7
+    assert max((a - b).abs().max().item() for a, b in zip(Us, g["tucker_Us"])) < 1e-9
+    dense = torch.einsum("abc,ia,jb,kc->ijk", oracle.cp_to_dense(fac), *Us)
+    assert (dense - g["tucker_dense"]).abs().max() < 1e-9

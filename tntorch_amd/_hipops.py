@@ -967,35 +967,28 @@ def _cp_solve(prod: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     return _hip.gemm(Z, V, transB=True)[0]
 
 
-def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False):
-    """``tn.Tensor(X, ranks_cp=R)`` for a dense device tensor (tensor.py:210-400, non-batch, HOSVD init).
+class _CpState:
+    """One dense device tensor in the middle of CP-ALS: factors, Gram matrices and one Gauss-Seidel sweep (see cp_als)."""
 
-    Same alternating sweep as the reference (mode 0 .. N-1, Gauss-Seidel), restructured so that the dense
-    tensor is read TWICE per sweep instead of N times and nothing of size I^(N-1) x R or I^N is ever written:
-      * modes 0..N-2 start from  P = X x_{N-1} A_{N-1}  (one ttr_gemm over X; A_{N-1} only changes at the end
-        of the sweep) and fold the other factors in with ttr_krp_contract (trailing modes, then leading modes);
-      * mode N-1 starts from  X_(0)^T A_0  (second ttr_gemm over X) and folds modes 1..N-2 in;
-      * the R x R normal equations use the Hadamard product of the Gram matrices (ttr_hadamard) and the
-        tridiagonal eigensolver; the relative error comes from ||X||^2 - 2<X,T> + ||T||^2 with <X,T> taken from
-        the last MTTKRP (no dense reconstruction, tensor.py:373-379) -- resolved down to ~sqrt(eps).
-    Returns (factors [I_n, R], errors)."""
-    N = X.dim()
-    if N < 2:
-        raise NotImplementedError("tntorch_amd: CP-ALS needs at least 2 modes")
-    shape = list(X.shape)
-    A = cp_hosvd_init(X, R)
-    grams = [None] + [_hip.gemm(A[n][None], A[n][None], transA=True)[0] for n in range(1, N)]
-    xnorm = float(_hip.norm(X.reshape(1, -1))[0].item())
-    errors: List[float] = []
+    def __init__(self, X: torch.Tensor, R: int, init=None):
+        self.X, self.R, self.N = X, R, X.dim()
+        if self.N < 2:
+            raise NotImplementedError("tntorch_amd: CP-ALS needs at least 2 modes")
+        self.shape = list(X.shape)
+        self.A = list(init) if init is not None else cp_hosvd_init(X, R)
+        self.grams = [None] + [_hip.gemm(self.A[n][None], self.A[n][None], transA=True)[0] for n in range(1, self.N)]
+        self.xnorm = float(_hip.norm(X.reshape(1, -1))[0].item())
 
-    def had(skip):
+    def _had(self, skip):
         out = None
-        for m in range(N - 1, -1, -1):
+        for m in range(self.N - 1, -1, -1):
             if m != skip:
-                out = grams[m] if out is None else _hip.hadamard(out, grams[m])
+                out = self.grams[m] if out is None else _hip.hadamard(out, self.grams[m])
         return out
 
-    for it in range(max_iter):
+    def sweep(self) -> float:
+        """Modes 0 .. N-1 once; returns the relative error ||X - T|| / ||X|| after the sweep."""
+        X, A, grams, shape, N, R = self.X, self.A, self.grams, self.shape, self.N, self.R
         P_last = _hip.gemm(X.reshape(1, -1, shape[-1]), A[N - 1][None])[0]  # [I_0 * .. * I_{N-2}, R]
         for n in range(N - 1):
             T = P_last
@@ -1009,7 +1002,7 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
                 for d in shape[m + 1:n + 1]:
                     Qm *= d
                 T = _hip.krp_contract(T.reshape(1, shape[m], Qm, R), A[m])
-            A[n] = _cp_solve(had(n), T.reshape(shape[n], R))
+            A[n] = _cp_solve(self._had(n), T.reshape(shape[n], R))
             grams[n] = _hip.gemm(A[n][None], A[n][None], transA=True)[0]
         T = _hip.gemm(X.reshape(1, shape[0], -1), A[0][None], transA=True)[0]  # [I_1 * .. * I_{N-1}, R]
         for m in range(1, N - 1):
@@ -1018,17 +1011,47 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
                 Qm *= d
             T = _hip.krp_contract(T.reshape(1, shape[m], Qm, R), A[m])
         Y = T.reshape(shape[N - 1], R)
-        A[N - 1] = _cp_solve(had(N - 1), Y)
+        A[N - 1] = _cp_solve(self._had(N - 1), Y)
         grams[N - 1] = _hip.gemm(A[N - 1][None], A[N - 1][None], transA=True)[0]
         xt = float(dense_dot(Y, A[N - 1]).item())
-        tt = float(_sum_all(_hip.hadamard(had(N - 1), grams[N - 1])).item())
-        err = math.sqrt(max(xnorm * xnorm - 2.0 * xt + tt, 0.0)) / xnorm
+        tt = float(_sum_all(_hip.hadamard(self._had(N - 1), grams[N - 1])).item())
+        if self.xnorm == 0.0:
+            return 0.0
+        return math.sqrt(max(self.xnorm * self.xnorm - 2.0 * xt + tt, 0.0)) / self.xnorm
+
+
+def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False, batch: bool = False, init=None):
+    """``tn.Tensor(X, ranks_cp=R)`` for a dense device tensor (tensor.py:210-400; HOSVD init, or the given ``init``
+    factors for CP on a Tucker core, tensor.py:282-300).
+
+    Same alternating sweep as the reference (mode 0 .. N-1, Gauss-Seidel), restructured so that the dense
+    tensor is read TWICE per sweep instead of N times and nothing of size I^(N-1) x R or I^N is ever written:
+      * modes 0..N-2 start from  P = X x_{N-1} A_{N-1}  (one ttr_gemm over X; A_{N-1} only changes at the end
+        of the sweep) and fold the other factors in with ttr_krp_contract (trailing modes, then leading modes);
+      * mode N-1 starts from  X_(0)^T A_0  (second ttr_gemm over X) and folds modes 1..N-2 in;
+      * the R x R normal equations use the Hadamard product of the Gram matrices (ttr_hadamard) and the
+        tridiagonal eigensolver; the relative error comes from ||X||^2 - 2<X,T> + ||T||^2 with <X,T> taken from
+        the last MTTKRP (no dense reconstruction, tensor.py:373-379) -- resolved down to ~sqrt(eps).
+    ``batch``: X is [B, I_1..I_N]; the items run in lock step (one sweep of every item per iteration) because the
+    reference decides convergence ONCE on the batch-mean error (tensor.py:362-381); factors come back as [B, I_n, R].
+    Returns (factors, errors)."""
+    if batch:
+        Bt = X.shape[0]
+        states = [_CpState(X[i], R, None if init is None else [f[i] for f in init]) for i in range(Bt)]
+    else:
+        states = [_CpState(X, R, init)]
+    errors: List[float] = []
+    for it in range(max_iter):
+        err = sum(st.sweep() for st in states) / len(states)
         errors.append(err)
         if verbose:
             print("iter: {} | eps: {:.8f}".format(it, err))
         if len(errors) >= 2 and errors[-2] - errors[-1] < tol:  # tensor.py:380-381
             break
-    return A, errors
+    if batch:
+        N = states[0].N
+        return [torch.stack([st.A[n] for st in states]) for n in range(N)], errors
+    return states[0].A, errors
 
 
 # ---------------------------------------------------------------------------------------------- producers (SURVEY 8f-3)

@@ -286,24 +286,31 @@ def dense_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------- CP-ALS
-def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False):
-    """tensor.py:210-400 (non-batch, HOSVD init), the reference's operator sequence on the CPU."""
+def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = False, batch: bool = False, init=None):
+    """tensor.py:210-400, the reference's operator sequence on the CPU.  ``init=None``: HOSVD initialisation
+    (tensor.py:228-277); otherwise the given factors (CP on a Tucker core starts from ``randn``, tensor.py:282-300).
+    ``batch``: X is [B, I_1..I_N], factors are [B, I_n, R], ONE convergence decision on the batch-mean error."""
+    if batch:
+        return _cp_als_batch(X, R, max_iter, tol, verbose, init)
     N = X.dim()
 
     def unf(n):
         return X.permute([n] + list(range(n)) + list(range(n + 1, N))).reshape(X.shape[n], -1)
 
-    A = []
-    for n in range(N):  # tensor.py:228-277
-        g = unf(n)
-        g = g @ _t(g)
-        w, V = torch.linalg.eigh(g)
-        reverse = torch.arange(len(w) - 1, -1, -1)
-        idx = torch.argsort(w)[reverse[:R]]
-        c = V[:, idx]
-        if c.shape[1] < R:
-            c = torch.cat((c, torch.randn(c.shape[0], R - c.shape[1], dtype=c.dtype, device=c.device)), dim=1)
-        A.append(c)
+    if init is not None:
+        A = list(init)
+    else:
+        A = []
+        for n in range(N):  # tensor.py:228-277
+            g = unf(n)
+            g = g @ _t(g)
+            w, V = torch.linalg.eigh(g)
+            reverse = torch.arange(len(w) - 1, -1, -1)
+            idx = torch.argsort(w)[reverse[:R]]
+            c = V[:, idx]
+            if c.shape[1] < R:
+                c = torch.cat((c, torch.randn(c.shape[0], R - c.shape[1], dtype=c.dtype, device=c.device)), dim=1)
+            A.append(c)
     xnorm = torch.norm(X)
     grams = [None] + [_t(A[n]) @ A[n] for n in range(1, N)]
     errors = []
@@ -321,6 +328,53 @@ def cp_als(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool = F
         for c in A[1:]:
             acc = torch.einsum("ar,ir->air", acc, c).reshape(-1, R)
         errors.append(float(torch.norm(X - acc.sum(dim=1).reshape(X.shape)) / xnorm))
+        if verbose:
+            print("iter: {} | eps: {:.8f}".format(it, errors[-1]))
+        if len(errors) >= 2 and errors[-2] - errors[-1] < tol:
+            break
+    return A, errors
+
+
+def _cp_als_batch(X: torch.Tensor, R: int, max_iter: int, tol: float, verbose: bool, init):
+    """The ``batch=True`` branches of tensor.py:214-400: every product is a ``bmm`` over the leading axis; the error of an
+    iteration is the MEAN of the items' relative errors (tensor.py:362-372) and convergence is decided once for all."""
+    Bt, N = X.shape[0], X.dim() - 1
+
+    def unf(n):
+        return X.permute([0, n + 1] + list(range(1, n + 1)) + list(range(n + 2, N + 1))).reshape(Bt, X.shape[n + 1], -1)
+
+    if init is not None:
+        A = list(init)
+    else:
+        A = []
+        for n in range(N):  # tensor.py:228-258
+            g = unf(n)
+            g = g @ _t(g)
+            w, V = torch.linalg.eigh(g)
+            reverse = torch.arange(w.shape[1] - 1, -1, -1)
+            idx = torch.argsort(w)[:, reverse[:R]]
+            c = V[[[i] for i in range(len(idx))], :, idx].transpose(-1, -2)
+            if c.shape[2] < R:
+                c = torch.cat((c, torch.randn(c.shape[0], c.shape[1], R - c.shape[2], dtype=c.dtype, device=c.device)), dim=2)
+            A.append(c)
+    xnorms = torch.sqrt(torch.sum(X**2, dim=list(range(1, X.dim()))))
+    grams = [None] + [_t(A[n]) @ A[n] for n in range(1, N)]
+    errors = []
+    for it in range(max_iter):
+        for n in range(N):
+            khatri = torch.ones(Bt, 1, R, dtype=X.dtype, device=X.device)
+            prod = torch.ones(Bt, R, R, dtype=X.dtype, device=X.device)
+            for m in range(N - 1, -1, -1):
+                if m != n:
+                    prod *= grams[m]
+                    khatri = torch.reshape(torch.einsum("bir,bjr->bijr", (A[m], khatri)), [Bt, -1, R])
+            A[n] = _t(torch.linalg.lstsq(prod, _t(unf(n) @ khatri)).solution)
+            grams[n] = _t(A[n]) @ A[n]
+        acc = A[0]
+        for c in A[1:]:
+            acc = torch.einsum("bar,bir->bair", acc, c).reshape(Bt, -1, R)
+        err = X - acc.sum(dim=2).reshape(X.shape)
+        errors.append(float((torch.sqrt(torch.sum(err**2, dim=list(range(1, err.dim())))) / xnorms).mean()))
         if verbose:
             print("iter: {} | eps: {:.8f}".format(it, errors[-1]))
         if len(errors) >= 2 and errors[-2] - errors[-1] < tol:

@@ -87,9 +87,21 @@ class Tensor(object):
                 if ranks_tt is not None:
                     raise ValueError("ALS for CP-TT is not yet supported")
                 assert not hasattr(ranks_cp, "__len__")
-                if self.batch or ranks_tucker is not None:
-                    _not_in_scope("batched CP-ALS / CP-ALS on a Tucker core")
-                self.cores, self.cp_errors = ops_for(data).cp_als(data, int(ranks_cp), max_iter, tol, verbose)
+                ops = ops_for(data)
+                if ranks_tucker is None:  # HOSVD-initialised ALS on the tensor itself (tensor.py:219-277)
+                    self.cores, self.cp_errors = ops.cp_als(data, int(ranks_cp), max_iter, tol, verbose, batch=self.batch)
+                else:  # CP on the Tucker core (tensor.py:278-300): Tucker-round first, ALS from a random start
+                    X = data if self.batch else data[None]
+                    N = X.dim() - 1
+                    rtk = list(ranks_tucker) if hasattr(ranks_tucker, "__len__") else [ranks_tucker] * N
+                    assert len(rtk) == N
+                    c4, Us3 = ops.dense_tucker_tt(X, rtk, None, algorithm, self.batch)
+                    core = ops.decompress(c4)  # the dense Tucker core [B, S_1..S_N] (tensor.py:1702-1715)
+                    lead = [core.shape[0]] if self.batch else []
+                    init = [torch.randn(lead + [sh, int(ranks_cp)], dtype=core.dtype, device=core.device) for sh in core.shape[1:]]
+                    self.cores, self.cp_errors = ops.cp_als(core if self.batch else core[0], int(ranks_cp), max_iter, tol,
+                                                            verbose, batch=self.batch, init=init)
+                    dense_Us = [U if self.batch else U[0] for U in Us3]
             elif ranks_tucker is not None:
                 self.cores, dense_Us = self._from_dense_tucker(data, ranks_tucker, ranks_tt, algorithm)
             else:
