@@ -999,3 +999,25 @@ def test_golden_cp_variants_on_device():
     Xb = torch.stack([X, X.flip(0)])
     tbt = tn.Tensor(Xb.cuda(), ranks_cp=3, ranks_tucker=[4, 4, 4], batch=True, max_iter=8)
     assert tbt.batch and [tuple(c.shape) for c in tbt.cores] == [(2, 4, 3)] * 3 and rel_diff(tbt.torch().cpu(), Xb) < 0.7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_dense_tt_svd_inplace_carry_rotation(dt, monkeypatch):
+    """Config-scale carries (> 4 GiB) are rotated in place, chunk by chunk (no second tensor of the carry's size): forced
+    here at a small size, the result must equal the out-of-place path and the oracle."""
+    from tntorch_amd import _hipops
+    torch.manual_seed(47)
+    X = torch.randn(14, 12, 9, 11, dtype=dt)
+    ref = tn.Tensor(X.cuda(), ranks_tt=8)
+    monkeypatch.setattr(_hipops, "_INPLACE_ROTATE_BYTES", 0)
+    monkeypatch.setattr(_hipops, "_INPLACE_CHUNK_BYTES", 4096)
+    Xd = X.cuda()
+    keep = Xd.clone()
+    got = tn.Tensor(Xd, ranks_tt=8)
+    assert torch.equal(Xd, keep)  # the user's tensor is never the scratch
+    assert got.ranks_tt.tolist() == ref.ranks_tt.tolist() == [1, 8, 8, 8, 1]
+    tol = 1e-5 if dt == torch.float32 else 1e-12
+    assert rel_diff(got.torch().cpu(), ref.torch().cpu()) <= tol
+    want = oracle.tt_to_dense([c.double() for c in oracle.dense_to_tt(X, 8)])
+    assert abs(rel_diff(got.torch().cpu(), X) - rel_diff(want, X)) <= (1e-5 if dt == torch.float32 else 1e-10)

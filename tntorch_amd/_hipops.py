@@ -283,6 +283,10 @@ def _select_rank(info: torch.Tensor, batch: bool, rmax: Optional[int], k: int) -
     return int(info[0].item())  # one readback per truncation, as round.py:150-158
 
 
+_INPLACE_ROTATE_BYTES = 1 << 32   # carries above 4 GiB are rotated in place ...
+_INPLACE_CHUNK_BYTES = 1 << 30    # ... through a 1 GiB buffer
+
+
 def truncate(
     M: torch.Tensor,
     delta: Optional[float],
@@ -291,9 +295,12 @@ def truncate(
     algorithm: str,
     batch: bool,
     right_alloc=None,
+    scratch_ok: bool = False,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
+    ``scratch_ok``: M is a temporary of the caller (the carry of a dense TT-SVD) and may be overwritten: a tall M with
+    more than 64 columns is then rotated IN PLACE (row chunks) instead of into a second tensor of its size.
 
     ``left_ortho=False`` (the branch round_tt uses): ``right`` has orthonormal rows,
     ``left * colscale`` carries the singular values.  ``left_ortho=True``: ``left`` is
@@ -361,7 +368,16 @@ def truncate(
         else:
             G = _hip.gemm(M, M, transA=True)
             V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG)
-            Mw = _hip.gemm(M, V1)                        # M V1
+            if scratch_ok and M.is_contiguous() and M.numel() * M.element_size() > _INPLACE_ROTATE_BYTES:
+                # config-scale carries (C1 class: tens of GiB): every row of M V1 depends on the same row of M only, so
+                # the rotation runs chunk by chunk into a bounded buffer that is copied back over its source rows
+                rows_per = max(1, _INPLACE_CHUNK_BYTES // (n * M.element_size() * Bt))
+                for r0 in range(0, m, rows_per):
+                    blk = M[:, r0:r0 + rows_per]
+                    blk.copy_(_hip.gemm(blk, V1))
+                Mw = M
+            else:
+                Mw = _hip.gemm(M, V1)                    # M V1
             G = _hip.gemm(Mw, Mw, transA=True)
     else:
         V1 = None
@@ -424,7 +440,15 @@ def _range_guard(X: torch.Tensor):
     normalises its own operands; this is for the entries that receive user data directly."""
     if X.dtype != torch.float32:
         return None
-    _, e = _hip.pow2_normalize(X, exponent_only=True)
+    return _range_guard_from_norms(_hip.norm(X.reshape(X.shape[0], -1)))
+
+
+def _range_guard_from_norms(nr: torch.Tensor):
+    """The exponents of ``_range_guard`` from the items' Frobenius norms [B] (ttr_norm streams a long item with the
+    whole chip; ttr_pow2_normalize is one workgroup per item -- on a 192 GiB tensor that was 80 s)."""
+    if nr.dtype != torch.float32:
+        return None
+    _, e = _hip.pow2_normalize(nr.reshape(-1, 1), exponent_only=True)
     if int(e.abs().max().item()) < 40:  # (readback: control flow only)
         return None
     return e
@@ -847,12 +871,12 @@ def dense_tt_svd(
     N = len(shape)
     if N == 1:
         return [X.reshape(Bt, 1, shape[0], 1).clone()]
+    nr = _hip.norm(X.reshape(Bt, -1))  # ONE pass over the input: delta and the fp32 range guard both come from it
     if batch:
         delta = None
     else:
-        nrm = float(_hip.norm(X.reshape(1, -1))[0].item())
-        delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
-    e = _range_guard(X)
+        delta = eps / max(1.0, math.sqrt(N - 1)) * float(nr[0].item())
+    e = _range_guard_from_norms(nr)
     if e is not None:  # ||X|| outside 2^+-40 in fp32: every bond's Gram matrix would leave the range
         X = _scale_batch(X, e, -1)
         if delta is not None:
@@ -862,7 +886,7 @@ def dense_tt_svd(
     rn = 1
     for kdim in range(N - 1, 0, -1):
         Mk = C.reshape(Bt, -1, shape[kdim] * rn)
-        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch)
+        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1)  # C is our own carry
         cores[kdim] = t.right.reshape(Bt, t.rank, shape[kdim], rn)
         C = t.left_scaled()
         rn = t.rank

@@ -47,10 +47,11 @@ def _c3(args, tn, dev):
 
 def _c1(args, tn, dev):
     free, _ = torch.cuda.mem_get_info()
-    k = 6
-    while k > 2 and 64 ** k * 4 * 1.35 > free:  # the input + its first carry (1/4) + Gram workspaces
-        k -= 1
-    shape = [64] * k
+    # the largest C1-class shape that fits: the input + its first carry (1/4 of it) + Gram workspaces.  64^6 (256 GiB)
+    # does not; the leading mode is shortened before a whole mode is dropped ([32] + [64]*5 = 128 GiB is resident).
+    cands = [[64] * 6, [48] + [64] * 5, [32] + [64] * 5, [16] + [64] * 5, [64] * 5, [64] * 4, [64] * 3]
+    shape = next(sh for sh in cands if math.prod(sh) * 4 * 1.35 <= free)
+    k = len(shape)
     gen = torch.Generator(device=dev).manual_seed(7)
     X = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
 
@@ -69,15 +70,15 @@ def _c1(args, tn, dev):
     flop = byts = 0.0
     r_next = 1
     for j in range(k - 1, 0, -1):
-        rows, n = 64.0 ** j, 64.0 * r_next
+        rows, n = float(math.prod(shape[:j])), 64.0 * r_next
         r = min(16.0, rows, n)
         flop += 2 * rows * n * n + 9 * min(rows, n) ** 3 + 2 * rows * n * r
         byts += 4 * (2 * rows * n + rows * r + r * n)
         r_next = r
     return {
-        "metric": f"TT-SVD of a dense 64^{k} fp32 tensor to ranks_tt=16 (BASELINE config C1 class; 64^6 = 256 GiB does not fit), s/tensor",
+        "metric": "TT-SVD of a dense " + "x".join(map(str, shape)) + " fp32 tensor to ranks_tt=16 (BASELINE config C1 class; 64^6 = 256 GiB does not fit), s/tensor",
         "value": el / args.steps, "unit": "s", "higher_is_better": False, "ms_per_step": el / args.steps * 1e3,
-        "config": {"workload": f"dense 64^{k} fp32 ({64 ** k * 4 / 2 ** 30:.1f} GiB) -> TT ranks 16", "algorithm": args.algorithm,
+        "config": {"workload": "dense " + "x".join(map(str, shape)) + f" fp32 ({math.prod(shape) * 4 / 2 ** 30:.1f} GiB) -> TT ranks 16", "algorithm": args.algorithm,
                    "ranks": out.ranks_tt.tolist()},
         "gflops": flop * args.steps / el / 1e9,
         "roofline": {"bound": "hbm", "achieved": byts * args.steps / el / 1e9, "peak": 8000.0, "unit": "GB/s",
