@@ -1,3 +1,4 @@
+
 // Batched symmetric eigensolver + truncated_svd's rank rule, on device (gfx950).
 //
 // One workgroup per matrix runs a parallel-order cyclic two-sided Jacobi iteration on
@@ -402,16 +403,14 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 // VALU-issue-bound), so fp32 uses the hardware rsq + one Newton step (full fp32 accuracy, 7 instructions) instead
 // of the IEEE sqrt and divide expansions (~25).
 __device__ __forceinline__ void givens_norm(float f, float g, float& r, float& rinv) {
+  // branch-free: the matrix is scaled to max |G_ii| = 1, so x cannot overflow; below the normal range (x == 0 included)
+  // the rotation is the "underflow" case of the QL sweep (r = 0)
   const float x = f * f + g * g;
-  if (x < 1e-36f || x > 1e36f) {  // out of the fast path's range: exact fallback (also x == 0)
-    r = sqrtf(x);
-    rinv = r > 0.f ? 1.0f / r : 0.f;
-    return;
-  }
   float y = __builtin_amdgcn_rsqf(x);
   y = y * (1.5f - 0.5f * x * y * y);
-  rinv = y;
-  r = x * y;
+  const bool ok = x > 1e-36f;
+  rinv = ok ? y : 0.f;
+  r = ok ? x * y : 0.f;
 }
 __device__ __forceinline__ void givens_norm(double f, double g, double& r, double& rinv) {
   r = sqrt(f * f + g * g);
@@ -445,8 +444,13 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   }
   __syncthreads();
   const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);
-  T gd = fabs(gdiag);
-  T gmax = gd;
+  // scale by the largest |entry| (= the largest diagonal entry for a Gram matrix): afterwards every entry is <= 1 and
+  // ||A||_F <= n, so the squares formed by the QL rotations cannot overflow (their fast path has no range branch)
+  T gmax = T(0);
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int i = idx / n, j = idx - i * n;
+    gmax = fmax(gmax, fabs(A[i * ld + j]));
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
   const T ginv = gmax > T(0) ? T(1) / gmax : T(0);
@@ -456,11 +460,26 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   }
   __syncthreads();
 
-  // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k]
+  // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k].
+  // lane = row, and every lane only ever touches ITS OWN row of A here: the reflector v and the vector w stay in
+  // registers (one entry per lane) and are broadcast with v_readlane instead of through LDS arrays, the row is walked in
+  // chunks of eight (loads, arithmetic, stores -- the element-by-element read-modify-write through LDS was serialised at
+  // the full LDS latency by the possible aliasing of A with the broadcast arrays), and the step needs no barrier.
+#ifdef TTR_EIGH_STAMPS
+  long long* const dbg = reinterpret_cast<long long*>(p.ws);  // diagnostics build: cycle stamps of matrix 0
+  int dbgi = 0;
+#define TTR_ESTAMP() do { if (dbg && bt == 0 && lane == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
+#else
+#define TTR_ESTAMP() do {} while (0)
+#endif
+  TTR_ESTAMP();
+  T* const rowp = A + lane * ld;
+  constexpr int CH = 8;
   for (int k = 0; k + 1 < n; ++k) {
     const bool below = lane >= k + 2 && lane < n;
-    const T x = below ? A[lane * ld + k] : T(0);
-    const T alpha = A[(k + 1) * ld + k];
+    const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
+    const T x = below ? xr : T(0);
+    const T alpha = lane_get(xr, k + 1);
     const T xn2 = wave_sum_dpp(x * x);
     T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
     if (xn2 != T(0)) {
@@ -470,109 +489,191 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       if (below) v = x * scale;
     }
     if (lane == 0) { ev[k] = beta; tauv[k] = t; }
-    vs[lane] = v;
-    __syncthreads();
     if (t != T(0)) {
       const bool act = lane >= k + 1 && lane < n;
       T pr = 0;
-      if (act) {
-        for (int j = k + 1; j < n; ++j) pr += A[lane * ld + j] * vs[j];
-        pr *= t;
+      {
+        int j = k + 1;
+        for (; j + CH <= n; j += CH) {
+          T a8[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) pr += a8[u] * lane_get(v, j + u);
+        }
+        for (; j < n; ++j) pr += rowp[j] * lane_get(v, j);
       }
+      pr = act ? pr * t : T(0);
       const T dot = wave_sum_dpp(pr * v);
       const T w = pr - T(0.5) * t * dot * v;
-      wsv[lane] = w;
-      __syncthreads();
-      if (act) {
-        for (int j = k + 1; j < n; ++j) A[lane * ld + j] -= v * wsv[j] + w * vs[j];
+      {
+        int j = k + 1;
+        for (; j + CH <= n; j += CH) {
+          T a8[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) a8[u] -= v * lane_get(w, j + u) + w * lane_get(v, j + u);
+          if (act) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) rowp[j + u] = a8[u];
+          }
+        }
+        for (; j < n; ++j) {
+          const T a1 = rowp[j] - (v * lane_get(w, j) + w * lane_get(v, j));
+          if (act) rowp[j] = a1;
+        }
       }
     }
-    if (below) A[lane * ld + k] = v;  // keep the reflector below the sub-diagonal
-    __syncthreads();
-    if (lane == 0) dv[k] = A[k * ld + k];
+    if (below) rowp[k] = v;  // keep the reflector below the sub-diagonal
+    if (lane == k) dv[k] = rowp[k];
   }
-  if (lane == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = T(0); if (n == 1) tauv[0] = T(0); }
+  if (lane == n - 1) { dv[n - 1] = rowp[n - 1]; ev[n - 1] = T(0); if (n == 1) tauv[0] = T(0); }
   __syncthreads();
 
+  TTR_ESTAMP();
   // ---- 2. Q = H_0 ... H_{n-2} in place: column c of the trailing (n-1)x(n-1) block of Q lands in column c+1,
-  //         reflector k sits in A[k+2:, k]; processed k = n-2 .. 0 with lane = column
+  //         reflector k sits in A[k+2:, k]; processed k = n-2 .. 0 with lane = column (own column only; the reflector is
+  //         broadcast with v_readlane, the column is walked in chunks of eight)
+  T* const colp = A + lane;
   for (int k = n - 2; k >= 0; --k) {
-    const T v = (lane == k + 1) ? T(1) : ((lane >= k + 2 && lane < n) ? A[lane * ld + k] : T(0));
+    const T v = (lane == k + 1) ? T(1) : ((lane >= k + 2 && lane < n) ? rowp[k] : T(0));
     const T t = tauv[k];
-    vs[lane] = v;
-    __syncthreads();
-    if (lane >= k + 2 && lane < n && t != T(0)) {  // lane = column c
+    if (t != T(0)) {  // (wave-uniform)
+      const bool act = lane >= k + 2 && lane < n;  // lane = column c
       T sdot = 0;
-      for (int i = k + 1; i < n; ++i) sdot += vs[i] * A[i * ld + lane];
+      int i = k + 1;
+      for (; i + CH <= n; i += CH) {
+        T a8[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a8[u] = colp[(i + u) * ld];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) sdot += lane_get(v, i + u) * a8[u];
+      }
+      for (; i < n; ++i) sdot += lane_get(v, i) * colp[i * ld];
       const T f = t * sdot;
-      for (int i = k + 1; i < n; ++i) A[i * ld + lane] -= f * vs[i];
+      i = k + 1;
+      for (; i + CH <= n; i += CH) {
+        T a8[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a8[u] = colp[(i + u) * ld];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a8[u] -= f * lane_get(v, i + u);
+        if (act) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u) colp[(i + u) * ld] = a8[u];
+        }
+      }
+      for (; i < n; ++i) {
+        const T a1 = colp[i * ld] - f * lane_get(v, i);
+        if (act) colp[i * ld] = a1;
+      }
     }
-    __syncthreads();
-    if (lane < n) A[lane * ld + k + 1] = (lane == k + 1) ? T(1) - t : ((lane >= k + 2) ? -t * v : T(0));  // lane = row
+    // column k+1 of Q (nobody read or wrote it in this iteration), written by the row lanes
+    if (lane < n) rowp[k + 1] = (lane == k + 1) ? T(1) - t : ((lane >= k + 2) ? -t * v : T(0));
     __syncthreads();
   }
   if (lane < n) { A[lane * ld + 0] = (lane == 0) ? T(1) : T(0); A[0 * ld + lane] = (lane == 0) ? T(1) : T(0); }
   __syncthreads();
 
-  // ---- 3. implicit-shift QL on (dv, ev); rotations applied to the columns of Q (lane = row)
+  TTR_ESTAMP();
+  // ---- 3. implicit-shift QL on (d, e); rotations applied to the columns of Q (lane = row).
+  // The recurrence is one serial chain per matrix (the wave repeats it in all lanes); cycle stamps put it at ~420 cycles
+  // per rotation for ~35 instructions, i.e. it runs at the latency of dependent instructions, LDS waits and branches.
+  // d[k] / e[k] and the recorded rotation (c, s)[k-1] therefore live in REGISTERS, one index per lane: operands are
+  // fetched with v_readlane (uniform index), results are merged with a lane-select -- no LDS access, no wait and no
+  // exec-masked store inside the rotation loop; d[i], d[i+1] are carried from rotation to rotation.
+  T ereg = (lane < n) ? ev[lane] : T(0), dreg = (lane < n) ? dv[lane] : T(0);
+  T creg = T(1), sreg = T(0);  // rotation i is kept in lane i + 1
   const T eps = Num<T>::eps();
-  T an = (lane < n) ? fmax(fabs(dv[lane]), fabs(ev[lane])) : T(0);
+  T an = fmax(fabs(dreg), fabs(ereg));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) an = fmax(an, __shfl_xor(an, off, 64));
   const T floor_abs = eps * an;
   int total_iter = 0;
+#ifdef TTR_EIGH_STAMPS
+  long long nrot_dbg = 0, qlrec_dbg = 0, qlapp_dbg = 0;
+#endif
   for (int l = 0; l < n; ++l) {
     for (int iter = 0; iter < 64; ++iter) {
       // m = first index >= l with a negligible sub-diagonal (n-1 if none)
+      const T dnext = __shfl_down(dreg, 1, 64);
       bool small = true;
       if (lane >= l && lane < n - 1) {
-        const T el = fabs(ev[lane]);
-        small = (el <= eps * (fabs(dv[lane]) + fabs(dv[lane + 1]))) || (el <= floor_abs);
+        const T el = fabs(ereg);
+        small = (el <= eps * (fabs(dreg) + fabs(dnext))) || (el <= floor_abs);
       }
       unsigned long long mask = __ballot(small && lane >= l);
       const int m = __ffsll((long long)mask) - 1;  // lanes >= n-1 always report "small"
       if (m <= l) break;
       ++total_iter;
-      T g = (dv[l + 1] - dv[l]) / (T(2) * ev[l]);
+      const T dl = lane_get(dreg, l), el0 = lane_get(ereg, l);
+      T g = (lane_get(dreg, l + 1) - dl) / (T(2) * el0);
       T r = sqrt(g * g + T(1));
-      g = dv[m] - dv[l] + ev[l] / (g + copysign(r, g));
+      g = lane_get(dreg, m) - dl + el0 / (g + copysign(r, g));
       T sn = T(1), cs = T(1), pp = T(0);
       bool underflow = false;
       int ilast = l;
+#ifdef TTR_EIGH_STAMPS
+      const long long tq0 = clock64();
+      nrot_dbg += m - l;
+#endif
+      T d_ip1 = lane_get(dreg, m);  // d[i + 1] (not yet touched by this sweep)
       for (int i = m - 1; i >= l; --i) {
-        const T f = sn * ev[i], b = cs * ev[i];
-        T rinv;
-        givens_norm(f, g, r, rinv);  // r = sqrt(f^2 + g^2), rinv = 1 / r
-        if (lane == 0) ev[i + 1] = r;
-        if (r == T(0)) {
-          if (lane == 0) { dv[i + 1] -= pp; ev[m] = T(0); }
+        const T e_i = lane_get(ereg, i), d_i = lane_get(dreg, i);  // lanes <= i are untouched by this sweep so far
+        const T f = sn * e_i, b = cs * e_i;
+        T rn, rinv;
+        givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2), rinv = 1 / rn (0 when rn == 0)
+        const bool here = lane == i + 1;
+        if (rn == T(0)) {
+          if (here) { ereg = T(0); dreg = d_ip1 - pp; }
+          if (lane == m) ereg = T(0);
           underflow = true;
           ilast = i + 1;
           break;
         }
         sn = f * rinv; cs = g * rinv;
-        g = dv[i + 1] - pp;
-        r = (dv[i] - g) * sn + T(2) * cs * b;
+        g = d_ip1 - pp;
+        r = (d_i - g) * sn + T(2) * cs * b;
         pp = sn * r;
-        if (lane == 0) { dv[i + 1] = g + pp; cv[i] = cs; sv[i] = sn; }
+        ereg = here ? rn : ereg;       // e[i + 1]
+        dreg = here ? g + pp : dreg;   // d[i + 1]
+        creg = here ? cs : creg;
+        sreg = here ? sn : sreg;
         g = cs * r - b;
+        d_ip1 = d_i;
       }
-      __syncthreads();
+      if (!underflow) {  // d_ip1 = d[l] here
+        if (lane == l) { dreg = d_ip1 - pp; ereg = g; }
+        if (lane == m) ereg = T(0);
+      }
+#ifdef TTR_EIGH_STAMPS
+      const long long tq1 = clock64();
+      qlrec_dbg += tq1 - tq0;
+#endif
       // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element
-      if (lane < n) {
-        T hi = A[lane * ld + m];
+      {
+        T hi = rowp[m];
         for (int i = m - 1; i >= ilast; --i) {
-          const T lo = A[lane * ld + i];
-          const T c2 = cv[i], s2 = sv[i];
-          A[lane * ld + i + 1] = s2 * lo + c2 * hi;
+          const T lo = rowp[i];
+          const T c2 = lane_get(creg, i + 1), s2 = lane_get(sreg, i + 1);
+          rowp[i + 1] = s2 * lo + c2 * hi;
           hi = c2 * lo - s2 * hi;
         }
-        A[lane * ld + ilast] = hi;
+        rowp[ilast] = hi;
       }
-      if (!underflow && lane == 0) { dv[l] -= pp; ev[l] = g; ev[m] = T(0); }
-      __syncthreads();
+#ifdef TTR_EIGH_STAMPS
+      qlapp_dbg += clock64() - tq1;
+#endif
     }
   }
+  __syncthreads();
+  if (lane < n) dv[lane] = dreg;  // eigenvalues for the epilogue
+  __syncthreads();
+  TTR_ESTAMP();
+#ifdef TTR_EIGH_STAMPS
+  if (dbg && bt == 0 && lane == 0) { dbg[dbgi++] = total_iter; dbg[dbgi++] = nrot_dbg; dbg[dbgi++] = qlrec_dbg; dbg[dbgi++] = qlapp_dbg; }
+#endif
 
   // ---- 4. epilogue: un-scale, clamp / sqrt / sort, permuted write, rank rule (round.py:118-158)
   T* sig = vs;          // reuse
