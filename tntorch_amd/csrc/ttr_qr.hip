@@ -676,24 +676,25 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     lds_barrier();
     stamp();
     if (trailing) {
-      // W2 = -T^T (sum of the partials)
+      // W2 = -T^T (sum of the partials), in two block-wide stages: every thread sums the NW partials of its elements
+      // (in place in the first partial), then forms its outputs -- it used to be 128 LDS reads per thread on a
+      // quarter of the block (~2 k cycles per panel)
       {
-        const int jc = tid & 63, i4 = tid >> 6;
-        if (i4 < 4 && jc < NP && jc >= (pnl + 1) * PW) {
-          T ws[PW];
+        constexpr int c0 = pnl * PW;             // first trailing column in Wp's column index
+        constexpr int ncols = NP - (pnl + 1) * PW > 0 ? NP - (pnl + 1) * PW : 1;  // (> 0 whenever `trailing`)
+        for (int e = tid; e < PW * ncols; e += NTH) {
+          const int k = e / ncols, jc = c0 + e % ncols;
+          T acc_w = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+          if constexpr (NW == 8) acc_w += (Wp[4][k][jc] + Wp[5][k][jc]) + (Wp[6][k][jc] + Wp[7][k][jc]);
+          Wp[0][k][jc] = acc_w;
+        }
+        lds_barrier();
+        for (int e = tid; e < PW * ncols; e += NTH) {
+          const int i = e / ncols, jc = c0 + e % ncols;
+          T a2 = 0;
 #pragma unroll
-          for (int k = 0; k < PW; ++k) {
-            ws[k] = (Wp[0][k][jc - PW] + Wp[1][k][jc - PW]) + (Wp[2][k][jc - PW] + Wp[3][k][jc - PW]);
-            if constexpr (NW == 8) ws[k] += (Wp[4][k][jc - PW] + Wp[5][k][jc - PW]) + (Wp[6][k][jc - PW] + Wp[7][k][jc - PW]);
-          }
-#pragma unroll
-          for (int ii = 0; ii < 4; ++ii) {
-            const int i = i4 * 4 + ii;
-            T a2 = 0;
-#pragma unroll
-            for (int k = 0; k < PW; ++k) a2 += Ts[k * VLD + i] * ws[k];
-            W2s[i][jc] = -a2;
-          }
+          for (int k = 0; k < PW; ++k) a2 += Ts[k * VLD + i] * Wp[0][k][jc];
+          W2s[i][jc + PW] = -a2;
         }
       }
       lds_barrier();
@@ -813,24 +814,21 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tc * PW + cl] = wa[r];
     }
     lds_barrier();
-    // W2 = -T W
+    // W2 = -T W, in two block-wide stages (partials summed in place in the first one, then one output per thread)
     {
-      const int jc = tid & 63, i4 = tid >> 6;
-      if (i4 < 4 && jc < NC) {
-        T ws[PW];
+      for (int e = tid; e < PW * NC; e += BR) {
+        const int k = e / NC, jc = e % NC;
+        T acc_w = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
+        if constexpr (NW == 8) acc_w += (Wp[4][k][jc] + Wp[5][k][jc]) + (Wp[6][k][jc] + Wp[7][k][jc]);
+        Wp[0][k][jc] = acc_w;
+      }
+      lds_barrier();
+      for (int e = tid; e < PW * NC; e += BR) {
+        const int i = e / NC, jc = e % NC;
+        T a2 = 0;
 #pragma unroll
-        for (int k = 0; k < PW; ++k) {
-          ws[k] = (Wp[0][k][jc] + Wp[1][k][jc]) + (Wp[2][k][jc] + Wp[3][k][jc]);
-          if constexpr (NW == 8) ws[k] += (Wp[4][k][jc] + Wp[5][k][jc]) + (Wp[6][k][jc] + Wp[7][k][jc]);
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int i = i4 * 4 + ii;
-          T a2 = 0;
-#pragma unroll
-          for (int k = 0; k < PW; ++k) a2 += Ts[i * VLD + k] * ws[k];
-          W2s[i][jc] = -a2;
-        }
+        for (int k = 0; k < PW; ++k) a2 += Ts[i * VLD + k] * Wp[0][k][jc];
+        W2s[i][jc] = -a2;
       }
     }
     lds_barrier();
