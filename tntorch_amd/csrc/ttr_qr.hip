@@ -148,10 +148,17 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     constexpr int RLD = 66;
     T* Rs = Vs;  // 64 x 66 <= 256 x 17
     const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
+    // Rm is the R factor of the previous core's QR in the rounding sweep, i.e. upper triangular: row tile tm of the product
+    // then only needs the K steps r0 >= 16 tm (10 of the 16 tile x K-group combinations).  Detected here, not assumed: the
+    // entry point takes any matrix.
+    bool lower_nz = false;
     for (int idx = tid; idx < 64 * 64; idx += NTH) {
       const int kk = idx >> 6, r0 = idx & 63;
-      Rs[kk * RLD + r0] = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
+      const T rv = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
+      lower_nz = lower_nz || (kk > r0 && rv != T(0));
+      Rs[kk * RLD + r0] = rv;
     }
+    if (lane == 0) pairt[wave] = __ballot(lower_nz) != 0ull ? T(1) : T(0);  // (pairt is free until the first panel)
     const int imode = b * NW + wave;
     const bool ivalid = imode < p.pI;
     const int ksteps = (p.pRin + 3) >> 2;
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             }
           }
         };
+        bool upper = false;
         auto mma_group = [&](int grp, const T (&bv)[KG][NT]) {
 #pragma unroll
           for (int kk = 0; kk < KG; ++kk) {
@@ -203,13 +211,22 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+            for (int tm = 0; tm < 4; ++tm) {
+              // upper-triangular Rm: rows 16 tm .. 16 tm + 15 are zero in the columns of K groups < tm (a K group = 16 columns)
+              if (upper && grp < tm) continue;  // wave-uniform
 #pragma unroll
               for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[kk][tn], acc[tm][tn]);
+            }
           }
         };
         load_group(0, bvA);  // in flight while Rs is being staged
         lds_barrier();
+        {
+          T any = pairt[0];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) any += pairt[w];
+          upper = any == T(0);
+        }
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
