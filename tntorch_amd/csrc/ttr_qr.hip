@@ -802,6 +802,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       }
 
   const int npanels = (kb + PW - 1) / PW;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
   T vreg[PW], treg = T(0);
   if (npanels > 0) {
 #pragma unroll
@@ -819,14 +820,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       if (tid < PW * PW) treg = Tg[(pnl - 1) * PW * PW + tid];
     }
     lds_barrier();
-    // W = V^T C (per-wave partial over its 64 rows)
+    // W = V^T C (per-wave partial over its 64 rows).  Before the first panel is applied C is [Top; 0]: a wave whose 64 rows
+    // lie below the n rows of Top contributes exactly zero and skips its MFMAs (7 of the 8 waves of a 512-row block).
+    const bool c_is_zero = pnl == npanels - 1 && wave_u * 64 >= n;  // wave-uniform
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc) {
       Acc wa = M::zero();
+      if (!c_is_zero) {
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], C[tm][tc][s], wa);
+          for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], C[tm][tc][s], wa);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tc * PW + cl] = wa[r];
     }
