@@ -156,8 +156,34 @@ __device__ __forceinline__ T row_sum_dpp(T v) {  // sum over the 16 lanes of eac
   v += dpp_mov<0x140>(v);
   return v;
 }
-// a, b <- their sums over the 64 lanes (wave-uniform)
+// Row-broadcast DPP steps of the classic GFX9 wave reduction: after the four row steps every lane holds its row's sum;
+// row_bcast:15 adds lane 15 of rows 0 / 2 into rows 1 / 3, row_bcast:31 adds lane 31 (rows 0 + 1) into rows 2 / 3, so that
+// lane 63 ends up with the sum over all 64 lanes.
+// (inline asm: with a partial row mask the compiler does not fuse update_dpp + add into one v_add_f32_dpp -- it emits
+// v_mov_dpp, v_add and a re-zeroing v_mov per step.  Rows outside the mask keep their value, which is what "+= 0" means.
+// The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see inside the asm.)
+__device__ __forceinline__ void dpp_add_bcast15(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void dpp_add_bcast31(float& a, float& b) {
+  asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// a, b <- their sums over the 64 lanes (wave-uniform).  Two interleaved DPP chains: an instruction of the other chain sits
+// in every DPP hazard slot (12 DPP + 2 v_readlane; the permlane-swap variant below needed ~27 issue slots with its s_nops --
+// on the serial Householder chain the issue slots ARE the latency).
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  a += dpp_mov<0xB1>(a);   b += dpp_mov<0xB1>(b);    // quad_perm [1,0,3,2]
+  a += dpp_mov<0x4E>(a);   b += dpp_mov<0x4E>(b);    // quad_perm [2,3,0,1]
+  a += dpp_mov<0x141>(a);  b += dpp_mov<0x141>(b);   // row_half_mirror
+  a += dpp_mov<0x140>(a);  b += dpp_mov<0x140>(b);   // row_mirror
+  dpp_add_bcast15(a, b);  // row_bcast:15 -> rows 1, 3
+  dpp_add_bcast31(a, b);  // row_bcast:31 -> rows 2, 3
+  a = lane_get(a, 63);
+  b = lane_get(b, 63);
+}
+__device__ __forceinline__ void wave_sum2_swap(float& a, float& b) {
   permswap32(a, b);            // a = [a.r0 a.r1 b.r0 b.r1], b = [a.r2 a.r3 b.r2 b.r3]
   float s = a + b, t = s;      // s = [a02 a13 b02 b13]
   permswap16(s, t);            // s = [a02 a02 b02 b02], t = [a13 a13 b13 b13]
@@ -169,8 +195,32 @@ __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   a = wave_sum_dpp(a);
   b = wave_sum_dpp(b);
 }
-// v[0..3] <- their sums over the 64 lanes (wave-uniform)
+// v[0..3] <- their sums over the 64 lanes (wave-uniform): four interleaved DPP chains, every hazard slot filled by the
+// other chains (24 DPP + 4 v_readlane, no s_nop)
 __device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0xB1>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x4E>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x141>(v[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x140>(v[c]);
+  asm volatile("s_nop 0\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = lane_get(v[c], 63);
+}
+__device__ __forceinline__ void wave_sum4_swap(float (&v)[4]) {
   permswap32(v[0], v[1]);
   permswap32(v[2], v[3]);
   float ab = v[0] + v[1], cd = v[2] + v[3];  // ab = [A02 A13 B02 B13], cd = [C02 C13 D02 D13]
