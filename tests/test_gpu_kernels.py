@@ -579,3 +579,23 @@ def test_qr_pushed_sum(dt, k, ra, rb, I, ca, cb, qr_variant):
     assert (Q @ R - P).abs().max() / P.abs().max() < tol(dt, 2e-5, 1e-12)
     f2 = h.qr_factor_pushed(Rm.cuda(), core.cuda())
     assert (f2.R.cpu().double().abs() - R.abs()).abs().max() / R.abs().max() < tol(dt, 3e-4, 1e-10)
+
+
+@pytest.mark.gpu
+def test_batch_above_grid_limit():
+    """More than 65535 batch items (the batch is a grid dimension): the entry points slice the batch themselves."""
+    torch.manual_seed(3)
+    B = 70001
+    _hip = globals()["_hip"]()
+    A = torch.randn(B, 5, 6, device="cuda")
+    Bm = torch.randn(B, 6, 3, device="cuda")
+    C = _hip.gemm(A, Bm)
+    assert (C - torch.bmm(A.double(), Bm.double()).float()).abs().max().item() < 1e-5
+    X = torch.randn(B, 12, 5, device="cuda")
+    Q, R = _hip.qr(X)
+    assert (torch.bmm(Q, R) - X).abs().max().item() < 1e-5
+    eye = torch.eye(5, device="cuda").expand(B, 5, 5)
+    assert (torch.bmm(Q.transpose(1, 2), Q) - eye).abs().max().item() < 1e-5
+    sc = torch.rand(B, 5, device="cuda") + 0.5
+    Y = _hip.scale_cols(X, sc, _hip.SCALE_MUL)
+    assert (Y - X * sc[:, None, :]).abs().max().item() < 1e-6

@@ -446,7 +446,17 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
   TTR_REQUIRE(mode == TTR_SCALE_MUL || mode == TTR_SCALE_DIV, TTR_E_INVALID, "ttr_scale_cols: bad mode");
   if (rows <= 0 || cols <= 0 || batch <= 0) return TTR_OK;
   TTR_REQUIRE(in && sc && out, TTR_E_INVALID, "ttr_scale_cols: null pointer");
-  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_scale_cols: batch > 65535");
+  if (batch > 65535) {  // the batch is a grid dimension: slices
+    const int64_t elem = dtype == TTR_F64 ? 8 : 4;
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+      const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+      const int rc = ttr_scale_cols(dtype, rows, cols, nb, (const char*)in + b0 * stride_in * elem, ldi, stride_in,
+                                    (const char*)sc + b0 * stride_s * elem, stride_s, mode, (char*)out + b0 * stride_out * elem, ldo,
+                                    stride_out, stream);
+      if (rc != TTR_OK) return rc;
+    }
+    return TTR_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   int64_t gx = ceil_div(rows * cols, kThreads);
   if (gx > 2048) gx = 2048;

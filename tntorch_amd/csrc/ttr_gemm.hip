@@ -273,6 +273,19 @@ int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
                   const void* rs, int64_t stride_rs, int rs_mode, const void* cs, int64_t stride_cs, int cs_mode,
                   int64_t batch, void* ws, int64_t ws_bytes, hipStream_t stream, int axpby, double alpha, double beta) {
+  if (batch > 65535) {  // the batch is a grid dimension: larger batches run in slices (the workspace of a slice fits the full one)
+    const int64_t elem = dtype == TTR_F64 ? 8 : 4;
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+      const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+      const int rc = gemm_dispatch(dtype, transA, transB, M, N, K, (const char*)A + b0 * strideA * elem, lda, strideA,
+                                   (const char*)B + b0 * strideB * elem, ldb, strideB, (char*)C + b0 * strideC * elem, ldc, strideC,
+                                   rs ? (const char*)rs + b0 * stride_rs * elem : nullptr, stride_rs, rs_mode,
+                                   cs ? (const char*)cs + b0 * stride_cs * elem : nullptr, stride_cs, cs_mode, nb, ws, ws_bytes,
+                                   stream, axpby, alpha, beta);
+      if (rc != TTR_OK) return rc;
+    }
+    return TTR_OK;
+  }
   if (dtype == TTR_F32)
     return gemm_impl<float>(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, rs, stride_rs,
                             rs_mode, cs, stride_cs, cs_mode, batch, ws, ws_bytes, stream, axpby, alpha, beta);

@@ -936,9 +936,18 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   return pl;
 }
 
+// The batch is a grid dimension (<= 65535): larger batches are processed in slices of kMaxBatchSlice items, each with its
+// own plan; the slices' workspaces follow each other, so the factor and the apply calls of one (m, n, batch) agree on the
+// layout without any extra state.
+constexpr int64_t kMaxBatchSlice = 65535;
+
 int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   if (m <= 0 || n <= 0 || batch <= 0) return 0;
-  return make_plan(m, n, batch).total * (dtype == TTR_F64 ? 8 : 4);
+  const int64_t elem = dtype == TTR_F64 ? 8 : 4;
+  int64_t total = 0;
+  for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice)
+    total += make_plan(m, n, batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice).total * elem;
+  return total;
 }
 
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
@@ -1020,10 +1029,27 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
 template <typename T>
 static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
                         int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, const Pushed& pu, hipStream_t stream) {
+  if (batch > kMaxBatchSlice) {  // slices of the batch, one after the other (see qr_workspace_bytes)
+    TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
+                "ttr_qr: workspace too small for batch %lld", (long long)batch);
+    char* wsp = (char*)ws;
+    for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice) {
+      const int64_t nb = batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice;
+      const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
+      Pushed ps = pu;
+      if (ps.Rm) ps.Rm = (const T*)ps.Rm + b0 * ps.strideRm;
+      if (ps.Cn) ps.Cn = (const T*)ps.Cn + b0 * ps.strideCn;
+      if (ps.Cn2) ps.Cn2 = (const T*)ps.Cn2 + b0 * ps.strideCn2;
+      const int rc = factor_typed<T>(m, n, nb, A ? (const void*)((const T*)A + b0 * strideA) : nullptr, lda, strideA,
+                                     (T*)R + b0 * strideR, ldr, strideR, wsp, wsb, ps, stream);
+      if (rc != TTR_OK) return rc;
+      wsp += wsb;
+    }
+    return TTR_OK;
+  }
   const QrPlan pl = make_plan(m, n, batch);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
-  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_qr: batch %lld > 65535", (long long)batch);
   switch (nt_for(n)) {
     case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
     case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
@@ -1043,10 +1069,23 @@ template <typename T>
 static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
                        int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI,
                        hipStream_t stream) {
+  if (batch > kMaxBatchSlice) {
+    TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
+                "ttr_qr_apply: workspace too small for batch %lld", (long long)batch);
+    char* wsp = (char*)ws;
+    for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice) {
+      const int64_t nb = batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice;
+      const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
+      const int rc = apply_typed<T>(m, n, nb, wsp, wsb, C ? (const void*)((const T*)C + b0 * strideC) : nullptr, ldc, strideC, kc,
+                                    (T*)Out + b0 * strideO, ldo, strideO, pk, pI, stream);
+      if (rc != TTR_OK) return rc;
+      wsp += wsb;
+    }
+    return TTR_OK;
+  }
   const QrPlan pl = make_plan(m, n, batch);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr_apply: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
-  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_qr_apply: batch %lld > 65535", (long long)batch);
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
               (long long)kc);
   switch (nt_for(n)) {
