@@ -615,7 +615,11 @@ def _stream_chunks(Bt: int, batch: bool) -> int:
 
 
 def _side_streams(dev: torch.device, n: int):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    """The sub-batch streams that belong to the CALLER's current stream: two calls issued from different streams (a
+    program that keeps several independent batches in flight) get different side streams and overlap freely -- the
+    latency-bound eigensolver periods of one call are filled by the QR kernels of the other."""
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (di, n, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _SIDE_STREAMS[key]
