@@ -85,9 +85,14 @@ def kernel_model():
     eig_flops = 2 * (N_CORES - 1) * 9.0 * Rr ** 3      # SURVEY 8d's 9 m^3 per eigenproblem
     gemm_flops = 2.0 * Rr * Rr * I                     # last-core push
     gemm_bytes = s * (Rr * Rr + 2 * Rr * I)
+    # flops the kernels actually EXECUTE (structure they exploit): the pushed R is upper triangular -- 10 of the 16
+    # (row tile, K group) products of R @ core; before its first panel the apply's C is [Top; 0] -- 7 of the 8 waves of
+    # a 512-row block skip that panel's W = V^T C
+    f_exec = f_flops - mid * 2.0 * Rr * Rr * I * n * (6.0 / 16.0)
+    a_exec = a_flops - mid * (leaf_blocks + 1) * (7.0 / 8.0) * 2.0 * 16 * leaf_rows * ro
     return {
-        "qr_factor": {"flops": f_flops, "bytes": f_bytes},
-        "qr_apply": {"flops": a_flops, "bytes": a_bytes},
+        "qr_factor": {"flops": f_flops, "bytes": f_bytes, "executed_flops": f_exec},
+        "qr_apply": {"flops": a_flops, "bytes": a_bytes, "executed_flops": a_exec},
         "rowgram": {"flops": rg_flops, "bytes": rg_bytes},
         "rotgram": {"flops": ro_flops, "bytes": rg_bytes},
         "project": {"flops": pj_flops, "bytes": pj_bytes},
@@ -344,6 +349,10 @@ def main():
                 "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                 "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_F32_PEAK_TF,
             }
+            if "executed_flops" in model[k]:  # (algorithmic flops count the dense products the kernels partly skip)
+                ex = model[k]["executed_flops"] * B * args.steps / sec / 1e12
+                entry["executed_TFLOPs"] = ex
+                entry["executed_frac_of_mfma_f32_peak"] = ex / MFMA_F32_PEAK_TF
             if pmc and k in pmc:
                 sc = B / pmc.get("_batch", B)
                 if pmc[k].get("hbm_bytes_per_step") is not None:
@@ -395,6 +404,7 @@ def main():
                 "traffic_note": pmc_note if traffic is None else "FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_latest.json, same kernel build)",
                 "mfma_util": d.get("mfma_util"),
                 "avg_launch_ms": prof[dom]["ms"] / launches,
+                "executed_frac": d.get("executed_frac_of_mfma_f32_peak"),
                 "algorithmic_flops_per_launch": d["flops_per_step"] * args.steps / launches,
                 "algorithmic_bytes_per_launch": d["bytes_per_step"] * args.steps / launches,
                 "arithmetic_intensity": d["arithmetic_intensity"],
