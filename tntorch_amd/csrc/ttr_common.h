@@ -133,29 +133,12 @@ __device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
   for (int c = 0; c < 4; ++c) v[c] = (lane_get(v[c], 0) + lane_get(v[c], 16)) + (lane_get(v[c], 32) + lane_get(v[c], 48));
 }
 
-// ------------------------------------------------------------------ multi-value wave reductions (v_permlane swaps)
-// gfx950's v_permlane32_swap / v_permlane16_swap exchange 32- / 16-lane blocks BETWEEN TWO REGISTERS (VALU only): one
-// swap + one add folds TWO values by half each, so four values are folded into the four 16-lane rows of ONE register
-// with 3 swaps + 3 adds, one DPP row reduction (4 steps) finishes all four, and four v_readlane broadcast them:
-// 14 instructions instead of the 44 of four interleaved DPP reductions.  That matters because a wave issues at most one
-// VALU instruction per ~8 cycles (measured: 8.0 cycles per independent v_fma for a wave alone on its SIMD, DPP 17.5), so
-// on the sequential Householder chain the instruction COUNT is the latency.
-// (Inline asm: the __builtin_amdgcn_permlane{16,32}_swap builtins of ROCm 7.2's clang return the same register for both
-// results -- verified in the ISA and on the device.)
-__device__ __forceinline__ void permswap32(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void permswap16(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-template <typename T>
-__device__ __forceinline__ T row_sum_dpp(T v) {  // sum over the 16 lanes of each row, result in every lane of the row
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  return v;
-}
+// ------------------------------------------------------------------ multi-value wave reductions
+// A wave issues at most one VALU instruction per ~8 cycles (measured: 8.0 cycles per independent v_fma for a wave alone on
+// its SIMD), so on the sequential Householder chain the number of issue slots of a reduction IS its latency.  Round 2
+// first folded several values into one register with gfx950's v_permlane32/16_swap (3 swaps + one DPP row reduction for four
+// values, ~27-32 slots with the hazard s_nops); the interleaved DPP chains below need 17 / 28.
+//
 // Row-broadcast DPP steps of the classic GFX9 wave reduction: after the four row steps every lane holds its row's sum;
 // row_bcast:15 adds lane 15 of rows 0 / 2 into rows 1 / 3, row_bcast:31 adds lane 31 (rows 0 + 1) into rows 2 / 3, so that
 // lane 63 ends up with the sum over all 64 lanes.
@@ -171,8 +154,7 @@ __device__ __forceinline__ void dpp_add_bcast31(float& a, float& b) {
                "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 // a, b <- their sums over the 64 lanes (wave-uniform).  Two interleaved DPP chains: an instruction of the other chain sits
-// in every DPP hazard slot (12 DPP + 2 v_readlane; the permlane-swap variant below needed ~27 issue slots with its s_nops --
-// on the serial Householder chain the issue slots ARE the latency).
+// in every DPP hazard slot (12 DPP + 2 v_readlane).
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
   a += dpp_mov<0xB1>(a);   b += dpp_mov<0xB1>(b);    // quad_perm [1,0,3,2]
   a += dpp_mov<0x4E>(a);   b += dpp_mov<0x4E>(b);    // quad_perm [2,3,0,1]
@@ -182,14 +164,6 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
   dpp_add_bcast31(a, b);  // row_bcast:31 -> rows 2, 3
   a = lane_get(a, 63);
   b = lane_get(b, 63);
-}
-__device__ __forceinline__ void wave_sum2_swap(float& a, float& b) {
-  permswap32(a, b);            // a = [a.r0 a.r1 b.r0 b.r1], b = [a.r2 a.r3 b.r2 b.r3]
-  float s = a + b, t = s;      // s = [a02 a13 b02 b13]
-  permswap16(s, t);            // s = [a02 a02 b02 b02], t = [a13 a13 b13 b13]
-  const float q = row_sum_dpp(s + t);
-  a = lane_get(q, 0);
-  b = lane_get(q, 32);
 }
 __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   a = wave_sum_dpp(a);
@@ -219,17 +193,6 @@ __device__ __forceinline__ void wave_sum4(float (&v)[4]) {
                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 #pragma unroll
   for (int c = 0; c < 4; ++c) v[c] = lane_get(v[c], 63);
-}
-__device__ __forceinline__ void wave_sum4_swap(float (&v)[4]) {
-  permswap32(v[0], v[1]);
-  permswap32(v[2], v[3]);
-  float ab = v[0] + v[1], cd = v[2] + v[3];  // ab = [A02 A13 B02 B13], cd = [C02 C13 D02 D13]
-  permswap16(ab, cd);                        // ab = [A02 C02 B02 D02], cd = [A13 C13 B13 D13]
-  const float q = row_sum_dpp(ab + cd);      // rows: A, C, B, D
-  v[0] = lane_get(q, 0);
-  v[1] = lane_get(q, 32);
-  v[2] = lane_get(q, 16);
-  v[3] = lane_get(q, 48);
 }
 __device__ __forceinline__ void wave_sum4(double (&v)[4]) { wave_sum_dpp4(v); }
 
