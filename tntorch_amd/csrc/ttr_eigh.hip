@@ -425,14 +425,15 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   const int n = p.n;
   const int ld = n + 1;
   T* A = reinterpret_cast<T*>(smem_raw);     // [n][ld]  G -> reflectors -> Q -> eigenvectors
-  T* vs = A + n * ld + 3;                    // [64] current reflector
-  T* wsv = vs + 64;                          // [64]
-  T* dv = wsv + 64;                          // [65] diagonal / eigenvalues
+  T* vs = A + n * ld + 3;                    // [64] epilogue scratch (sigma) ...
+  T* wsv = vs + 64;                          // [64] ... (sorted sigma)
+  T* cv = wsv + 64;                          // [64] ... (diagonal of G, TTR_EIG_MATCH_DIAG)
+  T* sv = cv + 64;                           // [64] ... (column order)
+  int* posv = reinterpret_cast<int*>(sv + 64);  // [64] ... (sort positions); vs .. posv together also hold S_b of the Q formation
+  T* dv = reinterpret_cast<T*>(posv + 64);   // [65] diagonal / eigenvalues
   T* ev = dv + 66;                           // [65] sub-diagonal (ev[i] couples i, i+1)
   T* tauv = ev + 66;                         // [64]
-  T* cv = tauv + 64;                         // [64] rotations of the current QL sweep
-  T* sv = cv + 64;                           // [64]
-  int* posv = reinterpret_cast<int*>(sv + 64);  // [64]
+  T* Tb = tauv + 64;                         // [16][17] compact-WY factor of a reflector block (Q formation)
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale
@@ -532,48 +533,115 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   __syncthreads();
 
   TTR_ESTAMP();
-  // ---- 2. Q = H_0 ... H_{n-2} in place: column c of the trailing (n-1)x(n-1) block of Q lands in column c+1,
-  //         reflector k sits in A[k+2:, k]; processed k = n-2 .. 0 with lane = column (own column only; the reflector is
-  //         broadcast with v_readlane, the column is walked in chunks of eight)
-  T* const colp = A + lane;
-  for (int k = n - 2; k >= 0; --k) {
-    const T v = (lane == k + 1) ? T(1) : ((lane >= k + 2 && lane < n) ? rowp[k] : T(0));
-    const T t = tauv[k];
-    if (t != T(0)) {  // (wave-uniform)
-      const bool act = lane >= k + 2 && lane < n;  // lane = column c
-      T sdot = 0;
-      int i = k + 1;
-      for (; i + CH <= n; i += CH) {
-        T a8[CH];
+  // ---- 2. Q = H_0 ... H_{n-2} on the matrix cores.  The reflectors (column k of A below the sub-diagonal) are grouped in
+  // blocks of 16: H_{16b} ... H_{16b+15} = I - V_b T_b V_b^T with T_b = (strict_upper(V_b^T V_b) + diag(1/tau))^-1 built by
+  // recursive doubling, and Z <- Z - V_b (T_b (V_b^T Z)) is applied for b = last .. 0 to Z = I, which lives in the wave's
+  // MFMA accumulators (16 tiles): the accumulator registers ARE the B operands of the next product (K-step s of a row
+  // tile = register s of every lane group), V_b is read straight from the reflector storage with its implicit unit /
+  // zeros.  ~150 MFMAs per block instead of two O(n^2) LDS walks per reflector (cycle stamps: 245 k of the kernel's
+  // 1.26 M cycles for n = 64).
+  {
+    using MF = Mfma<T>;
+    using Acc = typename MF::Acc;
+    const int cl = lane & 15;
+    T* const Ss = vs;  // [16][17] V_b^T V_b; its unused lower-left blocks are the scratch of the T construction
+    constexpr int SLD = 17;
+    auto vb = [&](int row, int c) -> T {  // V[row][c], c = reflector index
+      if (row >= n || c >= n - 1 || row <= c) return T(0);
+      return row == c + 1 ? T(1) : A[row * ld + c];
+    };
+    Acc Z[4][4];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) a8[u] = colp[(i + u) * ld];
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int u = 0; u < CH; ++u) sdot += lane_get(v, i + u) * a8[u];
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[tm][tn][r] = (16 * tm + MF::row(lane, r) == 16 * tn + cl) ? T(1) : T(0);
+    const int nblk = (n - 1 + 15) / 16;
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int c0 = 16 * b;
+      {  // S = V_b^T V_b (rows <= c0 of V_b are zero: K starts at the block's first row tile)
+        Acc s4[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+        for (int tm = b; tm < 4; ++tm)
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) {
+            const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
+            s4[sI] = MF::mma(a, a, s4[sI]);
+          }
+        const Acc sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ss[MF::row(lane, r) * SLD + cl] = sacc[r];
       }
-      for (; i < n; ++i) sdot += lane_get(v, i) * colp[i * ld];
-      const T f = t * sdot;
-      i = k + 1;
-      for (; i + CH <= n; i += CH) {
-        T a8[CH];
+      for (int e = lane; e < 256; e += kWave) {
+        const int i = e >> 4, k = e & 15;
+        Tb[i * SLD + k] = (i == k && c0 + i < n - 1) ? tauv[c0 + i] : T(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < CH; ++u) a8[u] = colp[(i + u) * ld];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) a8[u] -= f * lane_get(v, i + u);
+      for (int h = 1; h < 16; h <<= 1) {  // T12 = -T11 S12 T22 (see the QR kernel); X = S12 T22 goes to S's lower-left block
+        const int hh = h * h;
+        const int bq = lane / hh, rr2 = lane % hh, i = rr2 / h, jx = rr2 % h;
+        const int o = bq * 2 * h;
+        const bool act = lane < 8 * h;
         if (act) {
+          T x = T(0);
 #pragma unroll
-          for (int u = 0; u < CH; ++u) colp[(i + u) * ld] = a8[u];
+          for (int k = 0; k < h; ++k) x += Ss[(o + i) * SLD + o + h + k] * Tb[(o + h + k) * SLD + o + h + jx];
+          Ss[(o + h + i) * SLD + o + jx] = x;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (act) {
+          T t = T(0);
+#pragma unroll
+          for (int k = 0; k < h; ++k) t += Tb[(o + i) * SLD + o + k] * Ss[(o + h + k) * SLD + o + jx];
+          Tb[(o + i) * SLD + o + h + jx] = -t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      // W = V_b^T Z (16 x 64): A[i][k] = V_b[row k][i], B = Z tiles from the accumulators
+      Acc W[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+      for (int tm = b; tm < 4; ++tm)
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+          const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            // (static register index for Z: tm is a runtime loop variable, so select the tile explicitly)
+            const T zb = tm == 0 ? Z[0][tn][sI] : (tm == 1 ? Z[1][tn][sI] : (tm == 2 ? Z[2][tn][sI] : Z[3][tn][sI]));
+            W[tn] = MF::mma(a, zb, W[tn]);
+          }
+        }
+      // W2 = T_b W
+      Acc W2[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        const T a = Tb[cl * SLD + MF::row(lane, sI)];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) W2[tn] = MF::mma(a, W[tn][sI], W2[tn]);
+      }
+      // Z -= V_b W2 (row tiles above the block's first row are untouched: V_b is zero there)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        if (tm < b) continue;  // wave-uniform
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+          const T a = -vb(16 * tm + cl, c0 + MF::row(lane, sI));
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
         }
       }
-      for (; i < n; ++i) {
-        const T a1 = colp[i * ld] - f * lane_get(v, i);
-        if (act) colp[i * ld] = a1;
-      }
     }
-    // column k+1 of Q (nobody read or wrote it in this iteration), written by the row lanes
-    if (lane < n) rowp[k + 1] = (lane == k + 1) ? T(1) - t : ((lane >= k + 2) ? -t * v : T(0));
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tm + MF::row(lane, r), col = 16 * tn + cl;
+          if (row < n && col < n) A[row * ld + col] = Z[tm][tn][r];
+        }
   }
-  if (lane < n) { A[lane * ld + 0] = (lane == 0) ? T(1) : T(0); A[0 * ld + lane] = (lane == 0) ? T(1) : T(0); }
   __syncthreads();
 
   TTR_ESTAMP();
@@ -653,8 +721,24 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
 #endif
       // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element
       {
+        // (chunks of eight: the row elements are loaded ahead and stored behind the dependent chain through `hi`, which
+        // then consists of two FMAs per rotation instead of an LDS round trip)
         T hi = rowp[m];
-        for (int i = m - 1; i >= ilast; --i) {
+        int i = m - 1;
+        for (; i - (CH - 1) >= ilast; i -= CH) {
+          T lo8[CH], o8[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) lo8[u] = rowp[i - u];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const T c2 = lane_get(creg, i - u + 1), s2 = lane_get(sreg, i - u + 1);
+            o8[u] = s2 * lo8[u] + c2 * hi;
+            hi = c2 * lo8[u] - s2 * hi;
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) rowp[i - u + 1] = o8[u];
+        }
+        for (; i >= ilast; --i) {
           const T lo = rowp[i];
           const T c2 = lane_get(creg, i + 1), s2 = lane_get(sreg, i + 1);
           rowp[i + 1] = s2 * lo + c2 * hi;
@@ -753,7 +837,7 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
 }
 
 static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {
-  return (((size_t)n * (n + 1) + 3 + 64 * 5 + 66 * 2) * elem + 64 * sizeof(int) + 15) & ~size_t(15);
+  return (((size_t)n * (n + 1) + 3 + 64 * 5 + 66 * 2 + 16 * 17) * elem + 64 * sizeof(int) + 15) & ~size_t(15);
 }
 
 static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
