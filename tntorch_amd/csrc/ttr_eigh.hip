@@ -417,6 +417,27 @@ __device__ __forceinline__ void givens_norm(double f, double g, double& r, doubl
   rinv = r > 0. ? 1.0 / r : 0.;
 }
 
+// beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha) / beta, scale = 1 / (alpha - beta) (LAPACK larfg).  fp32: the
+// 1-ulp hardware sqrt / reciprocal -- the IEEE expansions are ~45 dependent instructions per reflector on the wave's serial
+// chain; H = I - tau v v^T stays orthogonal to O(eps) (same choice as in the QR kernels).
+__device__ __forceinline__ void householder_scalars(float alpha, float ss, float& beta, float& tau, float& scale) {
+  const float n2 = alpha * alpha + ss;
+  if (n2 > 1e-30f && n2 < 1e30f) {  // (wave-uniform) the hardware sqrt / rcp flush denormals: graded matrices get there
+    beta = -copysignf(__builtin_amdgcn_sqrtf(n2), alpha);
+    tau = (beta - alpha) * __builtin_amdgcn_rcpf(beta);
+    scale = __builtin_amdgcn_rcpf(alpha - beta);
+  } else {
+    beta = -copysignf(sqrtf(n2), alpha);
+    tau = (beta - alpha) / beta;
+    scale = 1.0f / (alpha - beta);
+  }
+}
+__device__ __forceinline__ void householder_scalars(double alpha, double ss, double& beta, double& tau, double& scale) {
+  beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+  tau = (beta - alpha) / beta;
+  scale = 1.0 / (alpha - beta);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -484,9 +505,8 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
     const T xn2 = wave_sum_dpp(x * x);
     T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
     if (xn2 != T(0)) {
-      beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-      t = (beta - alpha) / beta;
-      const T scale = T(1) / (alpha - beta);
+      T scale;
+      householder_scalars(alpha, xn2, beta, t, scale);
       if (below) v = x * scale;
     }
     if (lane == 0) { ev[k] = beta; tauv[k] = t; }
@@ -494,15 +514,20 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       const bool act = lane >= k + 1 && lane < n;
       T pr = 0;
       {
+        T pr1 = 0;  // two chains: a dependent add / fma costs ~8 cycles for a wave alone on its SIMD
         int j = k + 1;
         for (; j + CH <= n; j += CH) {
           T a8[CH];
 #pragma unroll
           for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
 #pragma unroll
-          for (int u = 0; u < CH; ++u) pr += a8[u] * lane_get(v, j + u);
+          for (int u = 0; u < CH; u += 2) {
+            pr = fma(a8[u], lane_get(v, j + u), pr);
+            pr1 = fma(a8[u + 1], lane_get(v, j + u + 1), pr1);
+          }
         }
         for (; j < n; ++j) pr += rowp[j] * lane_get(v, j);
+        pr += pr1;
       }
       pr = act ? pr * t : T(0);
       const T dot = wave_sum_dpp(pr * v);
