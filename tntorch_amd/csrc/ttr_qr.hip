@@ -355,7 +355,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // operation of a Householder step is then a packed two-row instruction -- the step chain is bound by the number of
     // instructions the one active wave has to issue (~8 cycles each, measured), not by their width
     V2 pcv[2][NW / 2];
-    if (pnl > 0) lds_barrier();  // the previous panel's MFMA update may still be reading Vs
+    // PAIR: no barrier before this store -- the previous panel's update only reads the wave's OWN rows of Vs (A operand of
+    // A2 += V W2), which are the rows it rewrites here; the single-step variant's owners write other waves' rows early
+    if constexpr (!PAIR) { if (pnl > 0) lds_barrier(); }  // the previous panel's MFMA update may still be reading Vs
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
         for (int q = 0; q < NW; ++q) pc[cc][q] = Vs[(lane + 64 * q) * VLD + wave * CPW + cc];
     }
-    lds_barrier();  // all columns are in registers before reflectors start overwriting Vs
+    // (PAIR: the owners store their reflectors to Vs only after their phase barrier, which every wave reaches after this read)
+    if constexpr (!PAIR) lds_barrier();  // all columns are in registers before reflectors start overwriting Vs
     stamp();
     if (nsteps < PW) {  // unused reflectors of this panel are H = I: v = 0, tau = 0
       for (int j = nsteps; j < PW; ++j) Vs[tid * VLD + j] = T(0);

@@ -9,7 +9,7 @@ from tntorch_amd import _hip
 L = _hip.lib()
 for B in [int(a) for a in sys.argv[1:]] or [1, 2048]:
     torch.manual_seed(0)
-    Rm = torch.randn(B, 64, 64, device="cuda"); core = torch.randn(B, 64, 64, 64, device="cuda")
+    Rm = torch.triu(torch.randn(B, 64, 64, device="cuda")); core = torch.randn(B, 64, 64, 64, device="cuda")
     buf = torch.zeros(64 + 40 * 8, dtype=torch.int64, device="cuda")
     _hip.qr_factor_pushed(Rm, core); torch.cuda.synchronize()
     L.ttr_debug_set_qr_stamps(buf.data_ptr()); buf.zero_()
