@@ -362,6 +362,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Vs[rowl(tm, r) * VLD + cl] = acc[tm][pnl][r];
+    if constexpr (PAIR) {  // S and T of this panel are assembled during the phases (below): start from zero
+      if (tid < PW * PW) { Ts[(tid >> 4) * VLD + (tid & 15)] = T(0); Ss[(tid >> 4) * VLD + (tid & 15)] = T(0); }
+    }
     lds_barrier();
     if constexpr (PAIR) {
 #pragma unroll
@@ -384,6 +387,35 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // apply it to its remaining columns, ... -- all wave-local, no barrier), publishes the reflectors, and after
     // ONE barrier the waves to its right apply them to their own columns.  A panel costs NW barrier phases
     // instead of 16 (the fully unrolled 16-step version also thrashed the instruction cache).
+    // columns 2p, 2p + 1 of the panel's T (wave 0, lanes = rows i < 2p; T and S in LDS, zero where not yet / never set):
+    //   T[i][c] = -tau_c sum_{l < c} T[i][l] S[l][c]   (larft, forward columnwise; T[i][l] = 0 for l < i)
+    auto t_columns = [&](int pp) {
+      const int c0 = 2 * pp, c1 = c0 + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own earlier T columns
+      if (lane < c0) {
+        // fully unrolled over l = 0 .. 13 (entries at l >= c0 of the T row are still zero: no predicate needed) so that all
+        // reads are in flight at once: as a counted loop every iteration waited for its own LDS round trip and wave 0
+        // arrived last at the phase barriers
+        T tl[PW - 2], s0[PW - 2], s1[PW - 2];
+#pragma unroll
+        for (int l = 0; l < PW - 2; ++l) {
+          tl[l] = Ts[lane * VLD + l];
+          s0[l] = Ss[l * VLD + c0];
+          s1[l] = Ss[l * VLD + c1];
+        }
+        T a = T(0), bsum = T(0), a2 = T(0), b2 = T(0);
+#pragma unroll
+        for (int l = 0; l < PW - 2; l += 2) {
+          a += tl[l] * s0[l]; bsum += tl[l] * s1[l];
+          a2 += tl[l + 1] * s0[l + 1]; b2 += tl[l + 1] * s1[l + 1];
+        }
+        a += a2; bsum += b2;
+        const T ti0 = -taus[j0 + c0] * a;
+        bsum += ti0 * Ss[c0 * VLD + c1];
+        Ts[lane * VLD + c0] = ti0;
+        Ts[lane * VLD + c1] = -taus[j0 + c1] * bsum;
+      }
+    };
     if constexpr (PAIR) {
       // Every wave runs its OWN sequence of phases (same number of barriers for all): first the phases of the owners to
       // its left (barrier, apply their pair), then its own (factor, publish, barrier, deferred stores), then only the
@@ -395,6 +427,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       const bool mine = wave_id < nph;
       const int napply = mine ? wave_id : nph;
       const bool live = j0 + wave_id * 2 < n;       // the wave's columns exist
+      // Waves that still have their phase ahead are on the critical chain of the panel (owner k -> barrier -> owner k + 1
+      // applies, factors -> ...): they issue at raised priority; a wave whose phase is over drops to priority 0 for the
+      // S / T assembly below, so that it only takes issue slots the chain leaves free (its SIMD partner may be the
+      // current owner; without this the chain slowed from ~1600 to ~1900 cycles per phase, cycle stamps).
+      __builtin_amdgcn_s_setprio(3);
       for (int owv = 0; owv < napply; ++owv) {
         const int jj = j0 + owv * 2, jj1 = jj + 1;
         T* const xb = Xp + (owv & 1) * (64 * XLD) + lane * XLD;
@@ -506,10 +543,51 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
               Vt[(int64_t)jj * BR + lane + 64 * q] = a;
               Vt[(int64_t)jj1 * BR + lane + 64 * q] = c;
             }
-            if (lane == 0) { tau[jj] = taus[jj]; tau[jj1] = taus[jj1]; }
+            if (lane == 0) {
+              const T t0 = taus[jj], t1 = taus[jj1], t12 = pairt[owv];
+              tau[jj] = t0; tau[jj1] = t1;
+              // the pair's own block of T = (strict_upper(V^T V) + diag(1 / tau))^-1 and of S = V^T V
+              Ts[j * VLD + j] = t0; Ts[(j + 1) * VLD + j + 1] = t1; Ts[j * VLD + j + 1] = -t0 * t12 * t1;
+              Ss[j * VLD + j + 1] = t12;
+            }
         }
-        for (int k = owv + 1; k < nph; ++k) lds_barrier();
+        __builtin_amdgcn_s_setprio(0);
+        // The phases of the owners to the right.  This wave's columns are final; instead of idling at the barriers it
+        // assembles the panel's compact-WY factor: after barrier k it forms the 2 x 2 block S[own pair][pair k] = V_own^T V_k
+        // (own reflectors from the panel image, pair k from the exchange slot; one 4-value reduction), and wave 0
+        // extends T by the two columns of pair k - 1 (larft column recurrence on 16 lanes, both columns in one pass).
+        // The separate S = V^T V stage (MFMA partials + block-wide reduction, two barriers) and the T construction after
+        // the phases are gone from the critical path.
+        for (int k = owv + 1; k < nph; ++k) {
+          lds_barrier();
+          {
+            const V4* const xr = reinterpret_cast<const V4*>(Xp + (k & 1) * (64 * XLD) + lane * XLD);
+            const V4 r0 = xr[0], r1 = xr[1], r2 = xr[2], r3 = xr[3];
+            const V2 w0[NH] = {V2{r0.x, r0.y}, V2{r0.z, r0.w}, V2{r1.x, r1.y}, V2{r1.z, r1.w}};
+            const V2 w1[NH] = {V2{r2.x, r2.y}, V2{r2.z, r2.w}, V2{r3.x, r3.y}, V2{r3.z, r3.w}};
+            V2 u0[NH], u1[NH];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+              u0[q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + j];
+              u1[q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + j + 1];
+            }
+            V2 e0 = u0[0] * w0[0], e1 = u0[0] * w1[0], e2 = u1[0] * w0[0], e3 = u1[0] * w1[0];
+#pragma unroll
+            for (int h = 1; h < NH; ++h) {
+              e0 = u0[h] * w0[h] + e0; e1 = u0[h] * w1[h] + e1;
+              e2 = u1[h] * w0[h] + e2; e3 = u1[h] * w1[h] + e3;
+            }
+            T d4[4] = {e0.x + e0.y, e1.x + e1.y, e2.x + e2.y, e3.x + e3.y};
+            wave_sum4(d4);
+            if (lane == 0) {
+              Ss[j * VLD + 2 * k] = d4[0]; Ss[j * VLD + 2 * k + 1] = d4[1];
+              Ss[(j + 1) * VLD + 2 * k] = d4[2]; Ss[(j + 1) * VLD + 2 * k + 1] = d4[3];
+            }
+          }
+          if (owv == 0 && k >= 2) t_columns(k - 1);
+        }
       }
+      __builtin_amdgcn_s_setprio(0);
     } else {
     for (int owv = 0; owv < NW; ++owv) {
       if (owv * CPW < nsteps) {  // block-uniform
@@ -624,7 +702,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       }
     }
     lds_barrier();
-    // (5) S = V^T V over the block (MFMA, K = BR split over the waves), then the triangular factor T
+    // (5) the triangular factor T of the panel
+    if constexpr (PAIR) {
+      // S and T were assembled during the phases; what is left are the two columns of the LAST pair (their S blocks were
+      // written after the last phase barrier, i.e. before the barrier above) and the copy for the apply kernel
+      if (wave_id == 0) {
+        const int nph = (nsteps + 1) >> 1;
+        if (nph >= 2) t_columns(nph - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = lane; e < PW * PW; e += 64) Tg[pnl * PW * PW + e] = Ts[(e >> 4) * VLD + (e & 15)];
+      }
+    } else {
+    // S = V^T V over the block (MFMA, K = BR split over the waves), then T
     {
       Acc s4[4] = {M::zero(), M::zero(), M::zero(), M::zero()};  // four chains: a dependent MFMA waits ~40 cycles
 #pragma unroll
@@ -676,6 +765,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       for (int e = lane; e < PW * PW; e += 64) Tg[pnl * PW * PW + e] = Ts[(e >> 4) * VLD + (e & 15)];
+    }
     }
     // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand.  W does not
     // depend on T: it is formed in the same barrier interval as the (serial, 16-lane) larft recurrence above, so
