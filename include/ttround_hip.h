@@ -158,6 +158,19 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
                         void* workspace, int64_t workspace_bytes,
                         const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
                         void* Out, int64_t ldo, int64_t strideO, void* stream);
+/*
+ * ttr_qr_apply_pushed that ALSO emits the row Gram matrix of its output, G = M M^T of the k x (I*kcols) right unfolding M of
+ * Out (round.py:104-109: what the truncation of the next bond computes first), accumulated from the output tiles while
+ * they are still in registers -- the right-to-left sweep reads the new carry twice instead of three times.
+ * G: [batch][parts][k][k] contiguous split partials (both triangles), parts = ttr_qr_apply_pushed_gram_parts(...); the
+ * eigensolver sums them on load (ttr_eigh_trunc's gparts).  parts == 0: this shape is not covered (fp32, k = 64, kcols = 32,
+ * I a multiple of 8 are), call ttr_qr_apply_pushed + ttr_rowgram instead.  ldo must equal kcols.
+ */
+int64_t ttr_qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kcols);
+int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch,
+                             void* workspace, int64_t workspace_bytes,
+                             const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
+                             void* Out, int64_t ldo, int64_t strideO, void* G, void* stream);
 
 /*
  * Symmetric eigen-decomposition + the rank rule of truncated_svd, batched, on device.

@@ -599,3 +599,32 @@ def test_batch_above_grid_limit():
     sc = torch.rand(B, 5, device="cuda") + 0.5
     Y = _hip.scale_cols(X, sc, _hip.SCALE_MUL)
     assert (Y - X * sc[:, None, :]).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("Rin,I,n", [(64, 64, 64), (64, 8, 64), (40, 24, 32), (64, 16, 48)])
+def test_qr_apply_pushed_gram(Rin, I, n):
+    """ttr_qr_apply_pushed_gram: the apply kernel's own row Gram matrix of its output (round.py:104-109 fused into the
+    push-left of tensor.py:2081-2083) -- same Out bit for bit, partials sum to M M^T of the k x (I kcols) unfolding."""
+    h = _hip()
+    g = torch.Generator().manual_seed(Rin + 10 * I + n)
+    B, k, kc = 3, 64, 32
+    Rm = torch.randn(B, k, Rin, generator=g).cuda()
+    core = torch.randn(B, Rin, I, n, generator=g).cuda()
+    C = torch.randn(B, n, kc, generator=g).cuda()
+    f = h.qr_factor_pushed(Rm, core)
+    plain = h.qr_apply(f, C)
+    out, G = h.qr_apply(f, C, want_gram=True)
+    assert G is not None and G.shape == (B, I // 8, k, k)
+    assert torch.equal(out, plain)
+    M = out.double().reshape(B, k, I * kc)
+    ref = M @ M.transpose(1, 2)
+    got = G.double().sum(dim=1)
+    assert (got - ref).abs().max() / ref.abs().max() < 2e-6
+    assert torch.equal(G, G.transpose(2, 3))  # both triangles written from the same accumulators
+    # the eigensolver takes the partials as they are (gparts)
+    V, sig, _ = h.eigh_trunc(G, h.EIG_RAW, False, 0.0, k, abs_floor=h.SOLVER_TRIDIAG)
+    sv = torch.linalg.svdvals(M)
+    assert (sig.double() ** 2 - sv ** 2).abs().max() / sv.max() ** 2 < 1e-5  # eigenvalues of a Gram matrix: absolute accuracy
+    # shapes the fused epilogue does not cover fall back to (Out, None)
+    out5, G5 = h.qr_apply(f, C[:, :, :5].contiguous(), want_gram=True)
+    assert G5 is None and out5.shape == (B, k * I, 5)

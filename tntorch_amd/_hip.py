@@ -82,6 +82,12 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
          c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_qr_apply_pushed_gram_parts": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "ttr_qr_apply_pushed_gram": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p],
+    ),
     "ttr_eigh_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
     "ttr_eigh_trunc": (
         c_int,
@@ -414,9 +420,12 @@ def qr_factor_pushed_sum(Rm: torch.Tensor, a4: torch.Tensor, b4: torch.Tensor) -
 
 @_on_device
 def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, want_gram: bool = False):
     """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q).
-    ``out``: optional contiguous destination (e.g. a batch slice of a larger result)."""
+    ``out``: optional contiguous destination (e.g. a batch slice of a larger result).
+    ``want_gram``: return ``(Out, G)``; G = split partials [batch, parts, k, k] of the row Gram matrix of Out's
+    k x (I kcols) right unfolding, accumulated by the apply kernel itself (ttr_qr_apply_pushed_gram), or None when
+    the shape is not covered (the caller then runs ``rowgram``)."""
     L = lib()
     dt = dtype_code(f.dtype)
     if C is not None:
@@ -432,18 +441,26 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
         Out = out
     else:
         Out = torch.empty((f.batch, f.m, kcols), dtype=f.dtype, device=f.ws.device)
+    G = None
     if f.batch == 0:
-        return Out
+        return (Out, G) if want_gram else Out
     if f.pushed is not None:
         k, I = f.pushed
-        code = L.ttr_qr_apply_pushed(dt, k, I, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
-                                     Out.data_ptr(), kcols, f.m * kcols, _stream())
-        _check(code, "ttr_qr_apply_pushed")
-        return Out
+        parts = int(L.ttr_qr_apply_pushed_gram_parts(dt, k, I, f.n, kcols)) if want_gram else 0
+        if parts > 0:
+            G = torch.empty((f.batch, parts, k, k), dtype=f.dtype, device=f.ws.device)
+            code = L.ttr_qr_apply_pushed_gram(dt, k, I, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
+                                              Out.data_ptr(), kcols, f.m * kcols, G.data_ptr(), _stream())
+            _check(code, "ttr_qr_apply_pushed_gram")
+        else:
+            code = L.ttr_qr_apply_pushed(dt, k, I, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
+                                         Out.data_ptr(), kcols, f.m * kcols, _stream())
+            _check(code, "ttr_qr_apply_pushed")
+        return (Out, G) if want_gram else Out
     code = L.ttr_qr_apply(dt, f.m, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
                           Out.data_ptr(), kcols, f.m * kcols, _stream())
     _check(code, "ttr_qr_apply")
-    return Out
+    return (Out, G) if want_gram else Out
 
 
 @_on_device

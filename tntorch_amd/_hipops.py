@@ -33,6 +33,7 @@ Algorithms (reference call sites in brackets):
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -296,11 +297,14 @@ def truncate(
     batch: bool,
     right_alloc=None,
     scratch_ok: bool = False,
+    gram: Optional[torch.Tensor] = None,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
     ``scratch_ok``: M is a temporary of the caller (the carry of a dense TT-SVD) and may be overwritten: a tall M with
     more than 64 columns is then rotated IN PLACE (row chunks) instead of into a second tensor of its size.
+    ``gram``: split partials of M M^T already accumulated by the kernel that produced M (``qr_apply(want_gram=True)``);
+    saves the first of the three passes over M.
 
     ``left_ortho=False`` (the branch round_tt uses): ``right`` has orthonormal rows,
     ``left * colscale`` carries the singular values.  ``left_ortho=True``: ``left`` is
@@ -320,12 +324,13 @@ def truncate(
         # -> Gram of the ROTATED rows (ttr_rotgram: the rotated matrix only exists 16 columns at a time in registers)
         # -> Jacobi -> projection with U = V1 V2 formed in the kernel's prologue, which also emits left = U sigma.
         V1 = None
+        G = gram if gram is not None else _hip.rowgram(M)
         if algorithm == "svd":
-            V1, _, _ = _hip.eigh_trunc(_hip.rowgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE)
         else:
-            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M), _hip.EIG_REF, use_delta, delta2, cap,
+            V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG)
         r = _select_rank(info, batch, rmax, k)
         if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
@@ -594,8 +599,18 @@ class _ExplicitQ:
         self.Q, self.R, self.batch = Q, R, Q.shape[0]
 
 
-def _apply_q(f, C: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return _hip.gemm(f.Q, C, out=out) if isinstance(f, _ExplicitQ) else _hip.qr_apply(f, C, out=out)
+# The apply kernel can accumulate the row Gram matrix of its output itself (ttr_qr_apply_pushed_gram: one pass over the new
+# carry less, -6 GB of HBM traffic per metric step).  Measured on MI355X it is 1.6 % SLOWER end to end (32.1 vs 31.6 ms/step:
+# the +140 us of MFMA work per apply launch do not overlap, while the stand-alone HBM-bound rowgram launch overlaps with the
+# other sub-batch's eigensolver), so it is opt-in.
+_FUSE_APPLY_GRAM = os.environ.get("TTR_FUSE_APPLY_GRAM", "0") == "1"
+
+
+def _apply_q(f, C: torch.Tensor, out: Optional[torch.Tensor] = None, want_gram: bool = False):
+    if isinstance(f, _ExplicitQ):
+        Q = _hip.gemm(f.Q, C, out=out)
+        return (Q, None) if want_gram else Q
+    return _hip.qr_apply(f, C, out=out, want_gram=want_gram)
 
 
 # Sub-batch streams.  Within one tensor train the sweeps are a dependency chain, and some of its kernels are
@@ -770,17 +785,22 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
         delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
     left = None  # (U sigma) of the bond to the right, to be absorbed by the current core
     for mu in range(N - 1, 0, -1):  # R2L: tensor.py:2053-2083
+        gram = None
         if mu == N - 1:
             M4 = c[mu]
         else:
             f, r0, I = facs[mu]
-            M4 = _apply_q(f, left).reshape(f.batch, r0, I, left.shape[2])
+            if _FUSE_APPLY_GRAM:
+                M4, gram = _apply_q(f, left, want_gram=True)  # the apply kernel also accumulates M M^T where it can
+            else:
+                M4 = _apply_q(f, left)
+            M4 = M4.reshape(f.batch, r0, I, left.shape[2])
         Bt, R, I, rn = M4.shape
         alloc = None
         if arena is not None:
             def alloc(r, mu=mu, n=I * rn):
                 return arena.slice(mu, chunk, (r, n))
-        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc)
+        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram)
         right = t.right
         if arena is not None:
             dst = alloc(t.rank)

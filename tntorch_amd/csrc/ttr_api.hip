@@ -252,7 +252,8 @@ int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch
                                   int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
 int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
-                             int64_t strideO, hipStream_t stream);
+                             int64_t strideO, void* G, hipStream_t stream);
+int64_t qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kc);
 int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                   int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
@@ -400,7 +401,23 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(Out && workspace, TTR_E_INVALID, "ttr_qr_apply_pushed: null pointer");
   return qr_apply_pushed_dispatch(dtype, k, I, n, batch, workspace, workspace_bytes, C, ldc, strideC, kcols, Out, ldo,
-                                  strideO, (hipStream_t)stream);
+                                  strideO, nullptr, (hipStream_t)stream);
+}
+
+int64_t ttr_qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kcols) {
+  if (!dtype_ok(dtype)) return 0;
+  return qr_apply_pushed_gram_parts(dtype, k, I, n, kcols);
+}
+
+int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* workspace,
+                             int64_t workspace_bytes, const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
+                             void* Out, int64_t ldo, int64_t strideO, void* G, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_apply_pushed_gram: bad dtype %d", dtype);
+  TTR_REQUIRE(batch >= 0 && kcols >= 1 && kcols <= n, TTR_E_INVALID, "ttr_qr_apply_pushed_gram: bad arguments");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Out && workspace && G, TTR_E_INVALID, "ttr_qr_apply_pushed_gram: null pointer");
+  return qr_apply_pushed_dispatch(dtype, k, I, n, batch, workspace, workspace_bytes, C, ldc, strideC, kcols, Out, ldo,
+                                  strideO, G, (hipStream_t)stream);
 }
 
 int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return eigh_workspace_bytes(dtype, n, batch); }

@@ -458,11 +458,34 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale
-  for (int idx = lane; idx < n * n; idx += kWave) {
-    const int i = idx / n, j = idx - i * n;
-    T gv = G[(int64_t)i * p.ldg + j];
-    for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
-    A[i * ld + j] = gv;
+  if (n == 64 && p.ldg == 64 && (p.stride_gpart & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
+    // a contiguous 64 x 64 matrix (+ split partials, e.g. the 8 per-block Gram partials of ttr_qr_apply_pushed_gram): four
+    // elements per lane and load, the partials' loads of one position issued four at a time -- the element-wise loop below has
+    // one dependent load in flight per lane, which costs 20 us per partial and launch at B = 2048
+    typedef T VT __attribute__((ext_vector_type(4)));
+    for (int it = 0; it < 16; ++it) {
+      const int e = (it * kWave + lane) * 4;
+      const T* __restrict__ src = G + e;
+      VT acc = *reinterpret_cast<const VT*>(src);
+      int pt = 1;
+      for (; pt + 3 < p.gparts; pt += 4) {
+        const VT x0 = *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
+        const VT x1 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 1) * p.stride_gpart);
+        const VT x2 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 2) * p.stride_gpart);
+        const VT x3 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 3) * p.stride_gpart);
+        acc += x0; acc += x1; acc += x2; acc += x3;  // same summation order as the element-wise loop
+      }
+      for (; pt < p.gparts; ++pt) acc += *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
+      T* dst = &A[(e >> 6) * ld + (e & 63)];
+      dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+    }
+  } else {
+    for (int idx = lane; idx < n * n; idx += kWave) {
+      const int i = idx / n, j = idx - i * n;
+      T gv = G[(int64_t)i * p.ldg + j];
+      for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
+      A[i * ld + j] = gv;
+    }
   }
   __syncthreads();
   const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);

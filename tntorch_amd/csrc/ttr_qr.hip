@@ -843,6 +843,9 @@ struct QrApply {
   T* Out;
   int64_t ldout, strideOut;
   int pk, pI;    // > 0: level 0 of a PUSHED factorisation, local row (wave, kk) <-> global row kk * pI + NW*b + wave
+  T* Gp;           // optional (level 0 of a pushed factorisation, fp32, pk = 64, kcols = 32, whole blocks): the block's share of the
+                   // ROW GRAM matrix of Out as a pk x pk unfolding, Gp[(bt * nb + b)][pk][pk] = sum_i Out_i Out_i^T over the block's mode indices
+  long long* dbg;  // optional: cycle stamps of block (0, 0) (diagnostics)
 };
 
 template <typename T, int NT, int NTC, int NW>
@@ -853,7 +856,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   constexpr int NP = PW * NT;
   constexpr int NC = PW * NTC;
   constexpr int BR = 64 * NW;
-  __shared__ __attribute__((aligned(16))) T Vs[BR * VLD];
+  // reflector panel [row][j]; fp32: leading dimension 20 -- the 16 values of a row go in as four 16-byte writes, and the
+  // A-operand reads of both products (rows 4 g + s at column cl: banks 16 g + cl; row cl at column 4 ks + g: banks 20 cl + g)
+  // are conflict-free (17 leaves the W product's reads 4-way conflicted: 68 g + cl)
+  constexpr int AVLD = sizeof(T) == 4 ? 20 : VLD;
+  __shared__ __attribute__((aligned(16))) T Vs[BR * AVLD];
   __shared__ T Ts[PW * VLD];   // compact-WY factor T of the current panel
   __shared__ T Wp[NW][PW][NC];
   __shared__ T W2s[PW][NC + 1];
@@ -875,6 +882,22 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   const T* __restrict__ Vt = p.Vt + blk * (int64_t)NP * BR;
   const T* __restrict__ Tg = p.Tg + blk * (int64_t)NT * PW * PW;
 
+#ifdef TTR_QR_WSTAMPS
+  int dbgi = 0;
+  auto astamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+#else
+  auto astamp = [&]() {};
+#endif
+  astamp();
+  // the first panel's reflectors are requested before C is initialised: their HBM latency hides the Top loads
+  const int npanels = (kb + PW - 1) / PW;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  T vreg[PW], treg = T(0);
+  if (npanels > 0) {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
+    if (tid < PW * PW) treg = Tg[(npanels - 1) * PW * PW + tid];
+  }
   Acc C[4][NTC];
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
@@ -894,18 +917,10 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
         C[tm][tc][r] = v;
       }
 
-  const int npanels = (kb + PW - 1) / PW;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
-  T vreg[PW], treg = T(0);
-  if (npanels > 0) {
-#pragma unroll
-    for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
-    if (tid < PW * PW) treg = Tg[(npanels - 1) * PW * PW + tid];
-  }
   for (int pnl = npanels - 1; pnl >= 0; --pnl) {
     // stage the panel's reflectors ([row][j]) and its T factor; the next panel's loads fly under the MFMAs
 #pragma unroll
-    for (int j = 0; j < PW; ++j) Vs[tid * VLD + j] = vreg[j];
+    for (int j = 0; j < PW; ++j) Vs[tid * AVLD + j] = vreg[j];
     if (tid < PW * PW) Ts[(tid >> 4) * VLD + (tid & 15)] = treg;
     if (pnl > 0) {
 #pragma unroll
@@ -913,6 +928,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       if (tid < PW * PW) treg = Tg[(pnl - 1) * PW * PW + tid];
     }
     lds_barrier();
+    astamp();
     // W = V^T C (per-wave partial over its 64 rows).  Before the first panel is applied C is [Top; 0]: a wave whose 64 rows
     // lie below the n rows of Top contributes exactly zero and skips its MFMAs (7 of the 8 waves of a 512-row block).
     const bool c_is_zero = pnl == npanels - 1 && wave_u * 64 >= n;  // wave-uniform
@@ -923,12 +939,13 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * VLD + cl], C[tm][tc][s], wa);
+          for (int s = 0; s < 4; ++s) wa = M::mma(Vs[rowl(tm, s) * AVLD + cl], C[tm][tc][s], wa);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wp[wave][M::row(lane, r)][tc * PW + cl] = wa[r];
     }
     lds_barrier();
+    astamp();
     // W2 = -T W, in two block-wide stages (partials summed in place in the first one, then one output per thread)
     {
       for (int e = tid; e < PW * NC; e += BR) {
@@ -947,6 +964,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       }
     }
     lds_barrier();
+    astamp();
     // C += V W2
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc)
@@ -954,14 +972,83 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * VLD + ks * 4 + g], W2s[ks * 4 + g][tc * PW + cl],
+          C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * AVLD + ks * 4 + g], W2s[ks * 4 + g][tc * PW + cl],
                              C[tm][tc]);
     lds_barrier();  // Vs / Ts / W2s are rewritten by the next panel
+    astamp();
   }
 
   if (p.pI > 0) {
     T* __restrict__ Out = p.Out + bt * p.strideOut;
     const int imode = b * NW + wave;
+    const bool full_tile = p.pk == 64 && kc == NC && (b + 1) * NW <= p.pI;  // block-uniform
+    if (full_tile) {
+      // every store valid: one lane pointer, wave-uniform row offsets (the guarded element-wise loop below costs 3x the cycles)
+      const int64_t kstride = (int64_t)p.pI * p.ldout;
+      T* __restrict__ o = Out + (int64_t)imode * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tc = 0; tc < NTC; ++tc) o[(int64_t)(tm * 16 + M::row(0, r)) * kstride + tc * PW] = C[tm][tc][r];
+      if constexpr (sizeof(T) == 4 && NTC == 2 && NW == 8) {
+        if (p.Gp) {
+          // Row Gram matrix of the block's output while it is still in registers: G_b = sum over the 8 waves (mode indices) of
+          // C_w C_w^T (64 x 64, K = 8 x 32).  The C tiles hold columns on the lanes; both MFMA operands of a Gram tile want
+          // ROWS on the lanes, so each wave writes its tile to an LDS image [64 rows][16 columns] (stride 20: conflict-free b32
+          // writes, 16-byte aligned conflict-free b128 reads), 16 columns at a time; the 10 upper-triangle tiles are owned by
+          // waves (wave w: tile w, waves 0 and 1 also tiles 8 and 9) and summed over all 8 images -- no cross-wave reduction.
+          constexpr int GLD = 20, IMG = 64 * GLD;
+          static_assert(6 * IMG <= BR * AVLD && 2 * IMG <= NW * PW * NC, "Gram images must fit Vs / Wp");
+          auto image = [&](int w) -> T* { return w < 6 ? &Vs[w * IMG] : &Wp[0][0][0] + (w - 6) * IMG; };
+          auto tile_of = [](int idx, int& ti, int& tj) {  // row-major over the upper triangle of the 4 x 4 tile grid
+            ti = 0;
+            while (idx >= 4 - ti) { idx -= 4 - ti; ++ti; }
+            tj = ti + idx;
+          };
+          int ti0, tj0, ti1 = 0, tj1 = 0;
+          tile_of(wave_u, ti0, tj0);
+          const bool two = wave_u < 2;
+          if (two) tile_of(wave_u + 8, ti1, tj1);
+          Acc ga = M::zero(), gb = M::zero();
+          T* mine = image(wave_u);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (h) lds_barrier();  // every reader of the first column half is done (h = 0: the panel loop ended on a barrier)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mine[(tm * 16 + 4 * g + r) * GLD + cl] = C[tm][h][r];
+            lds_barrier();
+            for (int w = 0; w < NW; ++w) {
+              const T* im = image(w);
+              const float4 a = *reinterpret_cast<const float4*>(&im[(16 * ti0 + cl) * GLD + 4 * g]);
+              const float4 bb = *reinterpret_cast<const float4*>(&im[(16 * tj0 + cl) * GLD + 4 * g]);
+              ga = M::mma(a.x, bb.x, ga); ga = M::mma(a.y, bb.y, ga); ga = M::mma(a.z, bb.z, ga); ga = M::mma(a.w, bb.w, ga);
+              if (two) {
+                const float4 a1 = *reinterpret_cast<const float4*>(&im[(16 * ti1 + cl) * GLD + 4 * g]);
+                const float4 b1 = *reinterpret_cast<const float4*>(&im[(16 * tj1 + cl) * GLD + 4 * g]);
+                gb = M::mma(a1.x, b1.x, gb); gb = M::mma(a1.y, b1.y, gb); gb = M::mma(a1.z, b1.z, gb); gb = M::mma(a1.w, b1.w, gb);
+              }
+            }
+          }
+          T* __restrict__ Go = p.Gp + (bt * p.nb + b) * (int64_t)(64 * 64);
+          auto put = [&](const Acc& t, int ti, int tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * ti + 4 * g + r, col = 16 * tj + cl;
+              Go[row * 64 + col] = t[r];
+              if (ti != tj) Go[col * 64 + row] = t[r];
+            }
+          };
+          put(ga, ti0, tj0);
+          if (two) put(gb, ti1, tj1);
+        }
+      }
+      astamp();
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -983,6 +1070,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
           if (row < rows && col < kc) Out[(int64_t)row * p.ldout + col] = C[tm][tc][r];
         }
   }
+  astamp();
 }
 
 // ---------------------------------------------------------------- host-side tree
@@ -1097,7 +1185,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
 
 template <typename T, int NT, int NTC>
 static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const QrPlan& pl, const T* C, int64_t ldc,
-                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, hipStream_t stream) {
+                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream) {
   const int L = pl.levels;
   for (int l = L - 1; l >= 0; --l) {
     QrApply<T> p;
@@ -1110,6 +1198,8 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     if (l == 0) { p.Out = Out; p.ldout = ldo; p.strideOut = strideO; }
     else { p.Out = wsw + pl.off_out[l]; p.ldout = kc; p.strideOut = pl.m[l] * n; }
     p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
+    p.Gp = (l == 0) ? Gp : nullptr;
+    p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
     const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
     if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
@@ -1152,15 +1242,15 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
 
 template <typename T, int NT>
 static int apply_nt(int64_t m, int n, int64_t batch, T* ws, const QrPlan& pl, const T* C, int64_t ldc, int64_t strideC,
-                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, hipStream_t stream) {
-  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
-  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
-  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, stream);
+                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream) {
+  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
+  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
+  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
 }
 
 template <typename T>
 static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
-                       int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI,
+                       int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI, void* Gp,
                        hipStream_t stream) {
   if (batch > kMaxBatchSlice) {
     TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
@@ -1170,7 +1260,8 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
       const int64_t nb = batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice;
       const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
       const int rc = apply_typed<T>(m, n, nb, wsp, wsb, C ? (const void*)((const T*)C + b0 * strideC) : nullptr, ldc, strideC, kc,
-                                    (T*)Out + b0 * strideO, ldo, strideO, pk, pI, stream);
+                                    (T*)Out + b0 * strideO, ldo, strideO, pk, pI,
+                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb).nb[0] * (int64_t)(64 * 64)) : nullptr, stream);
       if (rc != TTR_OK) return rc;
       wsp += wsb;
     }
@@ -1182,9 +1273,9 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
               (long long)kc);
   switch (nt_for(n)) {
-    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
-    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
-    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, stream);
+    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
+    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
+    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
   }
 }
 
@@ -1204,8 +1295,8 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
                       hipStream_t stream) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr_apply: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, stream);
-  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, stream);
+  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream);
 }
 
 // Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/NW)
@@ -1257,15 +1348,23 @@ int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch
   return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
 }
 
+// Number of row-Gram partials ttr_qr_apply_pushed_gram writes per batch item (0: the fused Gram epilogue does not cover this shape)
+int64_t qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kc) {
+  if (dtype != TTR_F32 || k != 64 || kc != 32 || n < 32 || n > 64 || I < 8 || (I % 8) != 0) return 0;
+  return I / 8;  // one 512-row level-0 block per 8 mode indices
+}
+
 int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
-                             int64_t strideO, hipStream_t stream) {
+                             int64_t strideO, void* G, hipStream_t stream) {
   const int rc = pushed_ok(dtype, k, 1, I, n);
   if (rc != TTR_OK) return rc;
+  TTR_REQUIRE(!G || (qr_apply_pushed_gram_parts(dtype, k, I, n, kc) > 0 && ldo == kc), TTR_E_UNSUPPORTED,
+              "ttr_qr_apply_pushed_gram: shape not covered by the fused Gram epilogue (see ttr_qr_apply_pushed_gram_parts)");
   const int64_t m = pushed_rows(I);
   if (dtype == TTR_F32)
-    return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, stream);
-  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, stream);
+    return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, G, stream);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, nullptr, stream);
 }
 
 }  // namespace ttr
