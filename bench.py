@@ -201,17 +201,33 @@ def parity_check(inp, out, items):
 
 
 def timed_steps(step, drain, fence, warmup, steps):
+    out = None
     for _ in range(warmup):
-        step()
+        # the result is held exactly as in the timed loop (the previous step's rounded train stays alive while the next step
+        # runs): otherwise the second TIMED step is the first to need a second 3.3 GB result arena, and that hipMalloc stalls
+        # the host for 0.3 ms on most boxes but ~95 ms on some (measured: step_ms [31.5, 32.3, 95.7, 31.6, ...] with
+        # host_enqueue_ms 94.4 for that step = 44 instead of 31.6 ms/step over 5 steps).  `allocator` in the JSON line
+        # reports the device allocations inside the timed region (0 with W >= 2).
+        out = step()
     drain()
     fence()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
-    out = None
     for _ in range(steps):
         out = step()
     gathered = drain()  # every step's gather has completed inside the timed region
     fence()
-    return time.perf_counter() - t0, out, gathered
+    elapsed = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    # device allocations INSIDE the timed region (hipMalloc of a multi-GB segment costs milliseconds): 0 in steady state
+    timed_steps.allocator = {
+        "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+        "device_frees_in_timed_region": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+        "alloc_retries": int(ms1.get("num_alloc_retries", 0)),
+        "reserved_GB_before": ms0.get("reserved_bytes.all.current", 0) / 1e9,
+        "reserved_GB_after": ms1.get("reserved_bytes.all.current", 0) / 1e9,
+    }
+    return elapsed, out, gathered
 
 
 def main():
@@ -266,6 +282,8 @@ def main():
     sizes = [B] * world
     pending = [None]
     inflight = []  # completion events of the steps enqueued so far
+    step_events = []  # all of them, for the per-step device times reported in the JSON line
+    host_ms = []      # host time spent enqueuing each step
 
     def step():
         """Round the local batch; for N > 1 hand the rounded cores to the (asynchronous) gather.  The gather
@@ -273,13 +291,16 @@ def main():
         The host runs at most two steps ahead of the device (enqueuing a step costs < 1 ms of host time): with an
         unbounded run-ahead every step in flight holds its own ~30 GB of QR workspaces, and the first process on a
         fresh box then spends the timed region in hipMalloc (measured: 49 instead of 38 ms per step)."""
-        if len(inflight) >= 2:
+        if len(inflight) >= int(os.environ.get("TTR_BENCH_RUNAHEAD", "2")):
             inflight.pop(0).synchronize()
+        h0 = time.perf_counter()
         t = tn.Tensor(inp, batch=True)
         t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
-        ev = torch.cuda.Event()
+        host_ms.append(round((time.perf_counter() - h0) * 1e3, 2))
+        ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         inflight.append(ev)
+        step_events.append(ev)
         if world > 1:
             if pending[0] is not None:
                 pending[0].wait()
@@ -389,6 +410,10 @@ def main():
                 "parallelism": f"batch-sharded x{world}, one async RCCL gather of packed cores per step (overlapped with the next step)" if world > 1 else "single GPU",
             },
             "nccl_ranks": nccl_ranks,
+            "allocator": getattr(timed_steps, "allocator", None),
+            # device time between the completion events of consecutive steps (warm-up steps included, first one omitted)
+            "host_enqueue_ms": host_ms,
+            "step_ms": [round(step_events[i - 1].elapsed_time(step_events[i]), 2) for i in range(1, len(step_events))],
             "tensors_per_s": tensors / elapsed,
             "gflops": FLOP_PER_TENSOR * tensors / elapsed / 1e9,
             "whole_sweep_frac_of_mfma_f32_peak": FLOP_PER_TENSOR * tensors / elapsed / 1e12 / MFMA_F32_PEAK_TF,
