@@ -520,6 +520,13 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   TTR_ESTAMP();
   T* const rowp = A + lane * ld;
   constexpr int CH = 8;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  // broadcast arrays of the tridiagonalisation (v, w), 16-byte aligned inside the vs .. cv scratch (free until the Q formation)
+  // (offset arithmetic on the LDS pointer: a round trip through uintptr_t loses the address space and turns the reads into flat loads)
+  constexpr int kPer16 = 16 / (int)sizeof(T);
+  T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;
+  T* const wsh = vsh + 64;
   for (int k = 0; k + 1 < n; ++k) {
     const bool below = lane >= k + 2 && lane < n;
     const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
@@ -535,41 +542,75 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
     if (lane == 0) { ev[k] = beta; tauv[k] = t; }
     if (t != T(0)) {
       const bool act = lane >= k + 1 && lane < n;
+      // v (and below w) are broadcast through two 16-byte aligned LDS arrays: one ds_write per lane, then every lane reads
+      // the values of a chunk of eight columns with two 16-byte broadcast reads -- v_readlane costs one instruction (plus a
+      // hazard slot) per VALUE, 24 per chunk of the rank-2 update.  Chunks start at a multiple of eight at or below k + 1:
+      // v and w are exactly zero in the columns <= k, which are therefore re-written unchanged.
+      vsh[lane] = v;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int j0 = (k + 1) & ~(CH - 1), nfull = n & ~(CH - 1);
       T pr = 0;
       {
-        T pr1 = 0;  // two chains: a dependent add / fma costs ~8 cycles for a wave alone on its SIMD
-        int j = k + 1;
-        for (; j + CH <= n; j += CH) {
+        T2 p0 = {T(0), T(0)}, p1 = {T(0), T(0)};  // four chains
+        int j = j0;
+        for (; j < nfull; j += CH) {
           T a8[CH];
 #pragma unroll
           for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
-#pragma unroll
-          for (int u = 0; u < CH; u += 2) {
-            pr = fma(a8[u], lane_get(v, j + u), pr);
-            pr1 = fma(a8[u + 1], lane_get(v, j + u + 1), pr1);
-          }
+          const T4 va = *reinterpret_cast<const T4*>(&vsh[j]), vb = *reinterpret_cast<const T4*>(&vsh[j + 4]);
+          p0 += T2{a8[0], a8[1]} * T2{va[0], va[1]};
+          p1 += T2{a8[2], a8[3]} * T2{va[2], va[3]};
+          p0 += T2{a8[4], a8[5]} * T2{vb[0], vb[1]};
+          p1 += T2{a8[6], a8[7]} * T2{vb[2], vb[3]};
         }
-        for (; j < n; ++j) pr += rowp[j] * lane_get(v, j);
-        pr += pr1;
+        for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) pr += rowp[j] * vsh[j];
+        pr += (p0[0] + p0[1]) + (p1[0] + p1[1]);
       }
       pr = act ? pr * t : T(0);
       const T dot = wave_sum_dpp(pr * v);
       const T w = pr - T(0.5) * t * dot * v;
+      wsh[lane] = w;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       {
-        int j = k + 1;
-        for (; j + CH <= n; j += CH) {
-          T a8[CH];
+        // a[j] -= v w_j + w v_j
+        struct Chunk { T a[CH]; T4 v0, v1, w0, w1; };
+        auto load = [&](int jj, Chunk& c) {
 #pragma unroll
-          for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
-#pragma unroll
-          for (int u = 0; u < CH; ++u) a8[u] -= v * lane_get(w, j + u) + w * lane_get(v, j + u);
+          for (int u = 0; u < CH; ++u) c.a[u] = rowp[jj + u];
+          c.v0 = *reinterpret_cast<const T4*>(&vsh[jj]); c.v1 = *reinterpret_cast<const T4*>(&vsh[jj + 4]);
+          c.w0 = *reinterpret_cast<const T4*>(&wsh[jj]); c.w1 = *reinterpret_cast<const T4*>(&wsh[jj + 4]);
+        };
+        const T2 mv = {-v, -v}, mw = {-w, -w};
+        auto proc = [&](int jj, Chunk& c) {
+          T2 r0 = T2{c.a[0], c.a[1]} + mv * T2{c.w0[0], c.w0[1]};
+          T2 r1 = T2{c.a[2], c.a[3]} + mv * T2{c.w0[2], c.w0[3]};
+          T2 r2 = T2{c.a[4], c.a[5]} + mv * T2{c.w1[0], c.w1[1]};
+          T2 r3 = T2{c.a[6], c.a[7]} + mv * T2{c.w1[2], c.w1[3]};
+          r0 += mw * T2{c.v0[0], c.v0[1]};
+          r1 += mw * T2{c.v0[2], c.v0[3]};
+          r2 += mw * T2{c.v1[0], c.v1[1]};
+          r3 += mw * T2{c.v1[2], c.v1[3]};
           if (act) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) rowp[j + u] = a8[u];
+            rowp[jj + 0] = r0[0]; rowp[jj + 1] = r0[1]; rowp[jj + 2] = r1[0]; rowp[jj + 3] = r1[1];
+            rowp[jj + 4] = r2[0]; rowp[jj + 5] = r2[1]; rowp[jj + 6] = r3[0]; rowp[jj + 7] = r3[1];
           }
+        };
+        int j = j0;
+        for (; j + 2 * CH <= nfull; j += 2 * CH) {  // sixteen columns per trip: all loads before the first store
+          Chunk ca, cb;
+          load(j, ca);
+          load(j + CH, cb);
+          proc(j, ca);
+          proc(j + CH, cb);
         }
-        for (; j < n; ++j) {
-          const T a1 = rowp[j] - (v * lane_get(w, j) + w * lane_get(v, j));
+        if (j < nfull) {
+          Chunk ca;
+          load(j, ca);
+          proc(j, ca);
+          j += CH;
+        }
+        for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) {
+          const T a1 = rowp[j] - (v * wsh[j] + w * vsh[j]);
           if (act) rowp[j] = a1;
         }
       }
@@ -735,19 +776,19 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       nrot_dbg += m - l;
 #endif
       T d_ip1 = lane_get(dreg, m);  // d[i + 1] (not yet touched by this sweep)
-      for (int i = m - 1; i >= l; --i) {
+      // Branch-free body, ONE exit test at the end.  Underflow (rn == 0: givens_norm then returns rinv = 0) needs no repair
+      // code: with sn = cs = 0 the body itself produces r = pp = 0, e[i+1] = rn = 0 and d[i+1] = g + pp = d[i+1] - p_old --
+      // exactly tql2's "d[i+1] -= p, e[m] = 0, abandon the sweep"; the (0, 0) rotation it records is never replayed
+      // (ilast = i + 1).  With the repair on an early exit every carried value went through a copy at the back edge and the
+      // rotation took three branches: 48 instructions; now ~36.
+      int i = m - 1;
+      bool zero;
+      for (;;) {
         const T e_i = lane_get(ereg, i), d_i = lane_get(dreg, i);  // lanes <= i are untouched by this sweep so far
         const T f = sn * e_i, b = cs * e_i;
         T rn, rinv;
         givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2), rinv = 1 / rn (0 when rn == 0)
         const bool here = lane == i + 1;
-        if (rn == T(0)) {
-          if (here) { ereg = T(0); dreg = d_ip1 - pp; }
-          if (lane == m) ereg = T(0);
-          underflow = true;
-          ilast = i + 1;
-          break;
-        }
         sn = f * rinv; cs = g * rinv;
         g = d_ip1 - pp;
         r = (d_i - g) * sn + T(2) * cs * b;
@@ -758,8 +799,15 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
         sreg = here ? sn : sreg;
         g = cs * r - b;
         d_ip1 = d_i;
+        zero = rn == T(0);
+        if (zero || i == l) break;
+        --i;
       }
-      if (!underflow) {  // d_ip1 = d[l] here
+      if (zero) {
+        if (lane == m) ereg = T(0);
+        underflow = true;
+        ilast = i + 1;
+      } else {  // d_ip1 = d[l] here
         if (lane == l) { dreg = d_ip1 - pp; ereg = g; }
         if (lane == m) ereg = T(0);
       }
