@@ -400,14 +400,14 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 // squares overflow) and the eigenvalues are scaled back at the end.
 // r = sqrt(f^2 + g^2) and 1/r for the QL rotations.  The recurrence is computed redundantly by all 64 lanes and
 // is ~60 % of the kernel's VALU instructions (PMC: 254 k VALU instructions per 64 x 64 matrix, the kernel is
-// VALU-issue-bound), so fp32 uses the hardware rsq + one Newton step (full fp32 accuracy, 7 instructions) instead
+// VALU-issue-bound), so fp32 uses the hardware rsq (1 ulp, 3 instructions) instead
 // of the IEEE sqrt and divide expansions (~25).
 __device__ __forceinline__ void givens_norm(float f, float g, float& r, float& rinv) {
   // branch-free: the matrix is scaled to max |G_ii| = 1, so x cannot overflow; below the normal range (x == 0 included)
   // the rotation is the "underflow" case of the QL sweep (r = 0)
   const float x = f * f + g * g;
-  float y = __builtin_amdgcn_rsqf(x);
-  y = y * (1.5f - 0.5f * x * y * y);
+  const float y = __builtin_amdgcn_rsqf(x);  // 1 ulp; a Newton step on top (4 more instructions ON the chain) did not improve
+                                             // |V^T V - I|, the residual or the eigenvalues (tools/eigh_orth_probe.py: 5e-6 / 1e-6 / 1.5e-6 either way)
   const bool ok = x > 1e-36f;
   rinv = ok ? y : 0.f;
   r = ok ? x * y : 0.f;
@@ -527,6 +527,7 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   constexpr int kPer16 = 16 / (int)sizeof(T);
   T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;
   T* const wsh = vsh + 64;
+  T2* const csh = reinterpret_cast<T2*>(vsh);  // [64] (c, s) of the QL sweep being replayed (vsh / wsh are free by then)
   for (int k = 0; k + 1 < n; ++k) {
     const bool below = lane >= k + 2 && lane < n;
     const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
@@ -815,30 +816,37 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       const long long tq1 = clock64();
       qlrec_dbg += tq1 - tq0;
 #endif
-      // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element
-      {
+      // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element.  The sweep's
+      // rotations are published once ((c, s) of rotation i sits in lane i + 1: one 8-byte store per lane) and read back as
+      // broadcast pairs -- v_readlane costs two instructions plus hazard slots per rotation and feeds SGPR operands, which
+      // the packed FMAs cannot take in pairs without extra moves.
+      if (lane < n) {  // (lanes >= n own no row: their `rowp` points into the scratch arrays that hold csh)
+        csh[lane] = T2{creg, sreg};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // (chunks of eight: the row elements are loaded ahead and stored behind the dependent chain through `hi`, which
-        // then consists of two FMAs per rotation instead of an LDS round trip)
+        // then consists of one FMA per rotation instead of an LDS round trip)
         T hi = rowp[m];
         int i = m - 1;
         for (; i - (CH - 1) >= ilast; i -= CH) {
           T lo8[CH], o8[CH];
+          T2 cs8[CH];
 #pragma unroll
-          for (int u = 0; u < CH; ++u) lo8[u] = rowp[i - u];
+          for (int u = 0; u < CH; ++u) { lo8[u] = rowp[i - u]; cs8[u] = csh[i - u + 1]; }
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const T c2 = lane_get(creg, i - u + 1), s2 = lane_get(sreg, i - u + 1);
-            o8[u] = s2 * lo8[u] + c2 * hi;
-            hi = c2 * lo8[u] - s2 * hi;
+            const T c2 = cs8[u][0], s2 = cs8[u][1];
+            const T cl = c2 * lo8[u], sl = s2 * lo8[u];  // off the chain
+            o8[u] = fma(c2, hi, sl);
+            hi = fma(-s2, hi, cl);                        // the chain: one FMA per rotation
           }
 #pragma unroll
           for (int u = 0; u < CH; ++u) rowp[i - u + 1] = o8[u];
         }
         for (; i >= ilast; --i) {
           const T lo = rowp[i];
-          const T c2 = lane_get(creg, i + 1), s2 = lane_get(sreg, i + 1);
-          rowp[i + 1] = s2 * lo + c2 * hi;
-          hi = c2 * lo - s2 * hi;
+          const T2 cs2 = csh[i + 1];
+          rowp[i + 1] = cs2[1] * lo + cs2[0] * hi;
+          hi = cs2[0] * lo - cs2[1] * hi;
         }
         rowp[ilast] = hi;
       }
