@@ -402,19 +402,22 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 // is ~60 % of the kernel's VALU instructions (PMC: 254 k VALU instructions per 64 x 64 matrix, the kernel is
 // VALU-issue-bound), so fp32 uses the hardware rsq (1 ulp, 3 instructions) instead
 // of the IEEE sqrt and divide expansions (~25).
-__device__ __forceinline__ void givens_norm(float f, float g, float& r, float& rinv) {
-  // branch-free: the matrix is scaled to max |G_ii| = 1, so x cannot overflow; below the normal range (x == 0 included)
-  // the rotation is the "underflow" case of the QL sweep (r = 0)
+__device__ __forceinline__ bool givens_norm(float f, float g, float& r, float& rinv) {
+  // The matrix is scaled to max |G_ii| = 1, so x cannot overflow; below the normal range (x == 0 included) the rotation is
+  // the "underflow" case of the QL sweep: returns false, r = 0, and rinv is NOT usable (inf / garbage: the caller leaves
+  // the sweep after this rotation and must not let values derived from rinv reach d / e).
   const float x = f * f + g * g;
-  const float y = __builtin_amdgcn_rsqf(x);  // 1 ulp; a Newton step on top (4 more instructions ON the chain) did not improve
-                                             // |V^T V - I|, the residual or the eigenvalues (tools/eigh_orth_probe.py: 5e-6 / 1e-6 / 1.5e-6 either way)
+  rinv = __builtin_amdgcn_rsqf(x);  // 1 ulp; a Newton step on top (4 more instructions ON the chain) did not improve
+                                    // |V^T V - I|, the residual or the eigenvalues (tools/eigh_orth_probe.py: 5e-6 / 1e-6 / 1.5e-6 either way)
   const bool ok = x > 1e-36f;
-  rinv = ok ? y : 0.f;
-  r = ok ? x * y : 0.f;
+  r = ok ? x * rinv : 0.f;
+  return ok;
 }
-__device__ __forceinline__ void givens_norm(double f, double g, double& r, double& rinv) {
+__device__ __forceinline__ bool givens_norm(double f, double g, double& r, double& rinv) {
   r = sqrt(f * f + g * g);
-  rinv = r > 0. ? 1.0 / r : 0.;
+  const bool ok = r > 0.;
+  rinv = ok ? 1.0 / r : 0.;
+  return ok;
 }
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha) / beta, scale = 1 / (alpha - beta) (LAPACK larfg).  fp32: the
@@ -777,31 +780,32 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
       nrot_dbg += m - l;
 #endif
       T d_ip1 = lane_get(dreg, m);  // d[i + 1] (not yet touched by this sweep)
-      // Branch-free body, ONE exit test at the end.  Underflow (rn == 0: givens_norm then returns rinv = 0) needs no repair
-      // code: with sn = cs = 0 the body itself produces r = pp = 0, e[i+1] = rn = 0 and d[i+1] = g + pp = d[i+1] - p_old --
-      // exactly tql2's "d[i+1] -= p, e[m] = 0, abandon the sweep"; the (0, 0) rotation it records is never replayed
-      // (ilast = i + 1).  With the repair on an early exit every carried value went through a copy at the back edge and the
-      // rotation took three branches: 48 instructions; now ~36.
+      // Branch-free body, exit tests at the end.  Underflow (givens_norm returns false, rn = 0) needs no repair code: the body
+      // itself stores e[i+1] = rn = 0 and d[i+1] = g = d[i+1] - p_old -- exactly tql2's "d[i+1] -= p, e[m] = 0, abandon the
+      // sweep"; the garbage rotation it records is never replayed (ilast = i + 1) and the carried values die with the sweep.
+      // With the repair on an early exit every carried value went through a copy at the back edge and the rotation took
+      // three branches: 48 instructions; now ~36.
       int i = m - 1;
       bool zero;
       for (;;) {
         const T e_i = lane_get(ereg, i), d_i = lane_get(dreg, i);  // lanes <= i are untouched by this sweep so far
         const T f = sn * e_i, b = cs * e_i;
         T rn, rinv;
-        givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2), rinv = 1 / rn (0 when rn == 0)
+        const bool ok = givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2) (0 in the underflow case), rinv ~ 1 / rn
         const bool here = lane == i + 1;
         sn = f * rinv; cs = g * rinv;
         g = d_ip1 - pp;
-        r = (d_i - g) * sn + T(2) * cs * b;
+        r = fma(cs, b + b, (d_i - g) * sn);   // (d_i - g) s + 2 c b with 2 b off the chain
         pp = sn * r;
-        ereg = here ? rn : ereg;       // e[i + 1]
-        dreg = here ? g + pp : dreg;   // d[i + 1]
+        ereg = here ? rn : ereg;                         // e[i + 1]
+        dreg = here ? (ok ? g + pp : g) : dreg;          // d[i + 1]   (underflow: d[i + 1] - p_old, nothing derived from rinv)
         creg = here ? cs : creg;
         sreg = here ? sn : sreg;
-        g = cs * r - b;
+        g = fma(cs, r, -b);
         d_ip1 = d_i;
-        zero = rn == T(0);
-        if (zero || i == l) break;
+        zero = !ok;
+        if (zero) break;
+        if (i == l) break;
         --i;
       }
       if (zero) {
