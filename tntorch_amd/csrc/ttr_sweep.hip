@@ -113,9 +113,10 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
     const bool al = ((p.ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0);
     int64_t cb, ce;
     split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
-    for (int64_t c = cb + wave; c < ce; c += 4) {
+    // (the next step's loads are issued before the current step's MFMAs: with 4 waves per SIMD the 40 MFMAs of a step do not
+    // cover an HBM round trip)
+    auto load_slab = [&](int64_t c, Acc (&mw)[4]) {
       const int64_t col = c * 16 + 4 * g;
-      Acc mw[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = 16 * t + cl;
@@ -123,21 +124,38 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) mw[t][r] = x.v[r];
       }
-      gram_update(mw);
+    };
+    Acc cur[4], nxt[4];
+    int64_t c = cb + wave;
+    if (c < ce) load_slab(c, cur);
+    for (; c < ce; c += 4) {
+      const bool more = c + 4 < ce;
+      if (more) load_slab(c + 4, nxt);
+      gram_update(cur);
+      if (more) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+      }
     }
   } else {
     // 16 columns per step; A operand = 16 x 4 pieces of M straight from global memory (four 64-byte row segments per
     // load).  The kernel runs at ~80 % of the fp32 MFMA rate like this (measured): wider loads only cost registers.
     int64_t cb, ce;
     split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
-    for (int64_t c = cb + wave; c < ce; c += 4) {
+    auto load_cols = [&](int64_t c, T (&a)[16]) {
       const int64_t c0 = c * 16;
-      T a[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const int k = 4 * ks + g;
         a[ks] = (k < R && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
       }
+    };
+    T a[16], an[16];
+    int64_t c = cb + wave;
+    if (c < ce) load_cols(c, a);
+    for (; c < ce; c += 4) {
+      const bool more = c + 4 < ce;
+      if (more) load_cols(c + 4, an);  // in flight under this step's 104 MFMAs (two waves per SIMD do not cover an HBM round trip)
       Acc mw[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -146,6 +164,10 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
         for (int ks = 0; ks < 16; ++ks) mw[t] = M::mma(a[ks], Vl[(4 * ks + g) * KLD + 16 * t + cl], mw[t]);
       }
       gram_update(mw);
+      if (more) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) a[ks] = an[ks];
+      }
     }
   }
   // reduce the four waves' partial tiles and write the block's partial Gram matrix (both triangles)
