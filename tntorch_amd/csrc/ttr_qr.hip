@@ -558,6 +558,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         // extends T by the two columns of pair k - 1 (larft column recurrence on 16 lanes, both columns in one pass).
         // The separate S = V^T V stage (MFMA partials + block-wide reduction, two barriers) and the T construction after
         // the phases are gone from the critical path.
+        // (the wave's own pair stays in registers for the S blocks: its columns are final, so the registers are free -- re-reading
+        // it from the panel image cost 16 LDS reads per phase)
+        V2 u0[NH], u1[NH];
+        {
+          const V4* const xo = reinterpret_cast<const V4*>(xb);
+          const V4 o0 = xo[0], o1 = xo[1], o2 = xo[2], o3 = xo[3];
+          u0[0] = V2{o0.x, o0.y}; u0[1] = V2{o0.z, o0.w}; u0[2] = V2{o1.x, o1.y}; u0[3] = V2{o1.z, o1.w};
+          u1[0] = V2{o2.x, o2.y}; u1[1] = V2{o2.z, o2.w}; u1[2] = V2{o3.x, o3.y}; u1[3] = V2{o3.z, o3.w};
+        }
         for (int k = owv + 1; k < nph; ++k) {
           lds_barrier();
           {
@@ -565,12 +574,6 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             const V4 r0 = xr[0], r1 = xr[1], r2 = xr[2], r3 = xr[3];
             const V2 w0[NH] = {V2{r0.x, r0.y}, V2{r0.z, r0.w}, V2{r1.x, r1.y}, V2{r1.z, r1.w}};
             const V2 w1[NH] = {V2{r2.x, r2.y}, V2{r2.z, r2.w}, V2{r3.x, r3.y}, V2{r3.z, r3.w}};
-            V2 u0[NH], u1[NH];
-#pragma unroll
-            for (int q = 0; q < NW; ++q) {
-              u0[q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + j];
-              u1[q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + j + 1];
-            }
             V2 e0 = u0[0] * w0[0], e1 = u0[0] * w1[0], e2 = u1[0] * w0[0], e3 = u1[0] * w1[0];
 #pragma unroll
             for (int h = 1; h < NH; ++h) {
