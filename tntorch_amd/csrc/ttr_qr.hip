@@ -866,7 +866,6 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   __shared__ __attribute__((aligned(16))) T Vs[BR * AVLD];
   __shared__ T Ts[PW * VLD];   // compact-WY factor T of the current panel
   __shared__ T Wp[NW][PW][NC];
-  __shared__ T W2s[PW][NC + 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -949,7 +948,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     }
     lds_barrier();
     astamp();
-    // W2 = -T W, in two block-wide stages (partials summed in place in the first one, then one output per thread)
+    // the waves' partial W's are summed in place (one entry per thread)
     {
       for (int e = tid; e < PW * NC; e += BR) {
         const int k = e / NC, jc = e % NC;
@@ -957,27 +956,29 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
         if constexpr (NW == 8) acc_w += (Wp[4][k][jc] + Wp[5][k][jc]) + (Wp[6][k][jc] + Wp[7][k][jc]);
         Wp[0][k][jc] = acc_w;
       }
-      lds_barrier();
-      for (int e = tid; e < PW * NC; e += BR) {
-        const int i = e / NC, jc = e % NC;
-        T a2 = 0;
-#pragma unroll
-        for (int k = 0; k < PW; ++k) a2 += Ts[i * VLD + k] * Wp[0][k][jc];
-        W2s[i][jc] = -a2;
-      }
     }
     lds_barrier();
     astamp();
-    // C += V W2
+    // W2 = -T W on the matrix cores, by every wave for itself (8 MFMAs), and C += V W2 with the W2 accumulators as the B operand
+    // of the update (K step s = register s of every lane group, i.e. reflector index M::row(lane, s): V is read at that column).
+    // The block-wide second stage (16 FMAs and 32 LDS reads per thread), the W2 image and one barrier per panel are gone.
+    {
+      T ta[4];
 #pragma unroll
-    for (int tc = 0; tc < NTC; ++tc)
+      for (int ks = 0; ks < 4; ++ks) ta[ks] = -Ts[cl * VLD + ks * 4 + g];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int tc = 0; tc < NTC; ++tc) {
+        Acc w2 = M::zero();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * AVLD + ks * 4 + g], W2s[ks * 4 + g][tc * PW + cl],
-                             C[tm][tc]);
-    lds_barrier();  // Vs / Ts / W2s are rewritten by the next panel
+        for (int ks = 0; ks < 4; ++ks) w2 = M::mma(ta[ks], Wp[0][ks * 4 + g][tc * PW + cl], w2);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI)
+            C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * AVLD + M::row(lane, sI)], w2[sI], C[tm][tc]);
+      }
+    }
+    lds_barrier();  // Vs / Ts / Wp are rewritten by the next panel
     astamp();
   }
 
