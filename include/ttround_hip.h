@@ -51,6 +51,10 @@ extern "C" {
                                 (rotation angles <= pi/4 never swap).  Building block of the block-Jacobi
                                 driver for n above the single-workgroup limit. */
 
+/* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
+   ttr_eigh_trunc = 2; round 3 additions = 3).  ttr_version() returns the value the library was built with; the Python
+   binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
+#define TTR_ABI_VERSION 3
 int ttr_version(void);
 const char* ttr_last_error(void);
 

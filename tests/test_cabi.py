@@ -39,7 +39,10 @@ def test_binding_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     lib.ttr_version.restype = ctypes.c_int
-    assert lib.ttr_version() == 1
+    from tntorch_amd import _hip
+
+    m = re.search(r"#define\s+TTR_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and lib.ttr_version() == int(m.group(1)) == _hip.ABI_VERSION  # header, library and binding agree
     lib.ttr_qr_max_cols.restype = ctypes.c_int
     assert lib.ttr_qr_max_cols(0) >= 64 and lib.ttr_qr_max_cols(1) >= 64
     lib.ttr_eigh_max_n_lds.restype = ctypes.c_int

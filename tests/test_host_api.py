@@ -367,3 +367,29 @@ def test_host_cp_variants_golden():
     assert (tt.torch() - g["tucker_dense"]).abs().max() < 1e-8
     with pytest.raises(ValueError):
         tn.Tensor(g["tucker_inp"], ranks_cp=3, ranks_tt=2)
+
+
+def test_rand_tucker_only_gets_full_tt_ranks():
+    """create.py:243-272: `ranks_tucker` without `ranks_tt` builds a TT-Tucker tensor whose core has full TT ranks (round-2
+    advisor finding: this used to raise)."""
+    for shape, rk, want in (([5, 6, 7, 4], 3, [1, 3, 9, 3, 1]), ([5, 6, 7, 4], [2, 3, 4, 2], [1, 2, 6, 2, 1]),
+                            ([8, 8, 8], [None, 3, 2], [1, 6, 2, 1])):
+        t = tn.rand(shape, ranks_tucker=rk)
+        assert t.ranks_tt.tolist() == want and tuple(t.shape) == tuple(shape)
+        rks = rk if hasattr(rk, "__len__") else [rk] * len(shape)
+        assert [None if u is None else u.shape[1] for u in t.Us] == rks
+    tb = tn.randn([3, 5, 6, 7], ranks_tucker=2, batch=True)
+    assert [tuple(c.shape) for c in tb.cores] == [(3, 1, 2, 2), (3, 2, 2, 2), (3, 2, 2, 1)]
+
+
+def test_ttmatrix_trace_sums_a_leading_rank():
+    """matrix.py:160-175: the reference contracts from `ones(1)`, which einsum broadcasts over a leading boundary rank > 1,
+    i.e. that rank is summed (round-2 advisor finding: row 0 only was taken)."""
+    from tntorch_amd.matrix import TTMatrix
+
+    torch.manual_seed(0)
+    cores = [torch.randn(2, 3, 3, 4, dtype=torch.float64), torch.randn(4, 3, 3, 1, dtype=torch.float64)]
+    m = TTMatrix.__new__(TTMatrix)
+    m.cores, m.batch = cores, False
+    want = torch.einsum("iaaj,jbbk->ik", cores[0], cores[1]).sum(dim=0)[0]
+    assert abs(float(m.trace()) - float(want)) <= 1e-12

@@ -35,10 +35,18 @@ def ref_tn():
 def test_patch_installs_and_uninstalls(ref_tn):
     tn = ref_tn
     assert hasattr(tn.Tensor.round_tt, "_tntorch_amd_original") and tn.truncated_svd is tna.truncated_svd
-    undo2 = tna.patch(tn)  # idempotent: the true originals survive a second patch
+    first = tn.Tensor.round_tt
+    undo2 = tna.patch(tn)  # idempotent: an already patched module is left alone and the SAME undo comes back
+    assert tn.Tensor.round_tt is first
     undo2()
+    assert not hasattr(tn.Tensor.round_tt, "_tntorch_amd_original") and tn.truncated_svd is not tna.truncated_svd
+    undo2()  # a second undo is a no-op
     assert not hasattr(tn.Tensor.round_tt, "_tntorch_amd_original")
-    tna.patch(tn)  # (the fixture's undo restores again)
+    undo3 = tna.patch(tn)  # (the fixture's undo is the first one: a no-op by now, so restore here)
+    assert hasattr(tn.Tensor.round_tt, "_tntorch_amd_original")
+    undo3()
+    tna.patch(tn)  # leave the module patched for the fixture's teardown ... which holds the FIRST undo (no-op): undo below
+    tna._patch._ACTIVE[id(tn)][1]()
 
 
 def test_reference_orthogonalization_body(ref_tn):

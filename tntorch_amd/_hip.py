@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
+ABI_VERSION = 3  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -162,6 +163,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.ttr_version() != ABI_VERSION:
+            raise RuntimeError(
+                f"{LIB_PATH} was built for ABI version {L.ttr_version()}, this binding expects {ABI_VERSION} "
+                "(include/ttround_hip.h: TTR_ABI_VERSION): rebuild with `python __graft_entry__.py --force`.")
         _lib = L
     return _lib
 

@@ -267,15 +267,33 @@ def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, ca
 class Truncation:
     """Result of ``truncate``: ``left_core`` (m x r), optional column scale, ``right`` (r x n)."""
 
-    __slots__ = ("left", "colscale", "right", "rank", "zero")
+    __slots__ = ("left", "colscale", "right", "rank", "zero", "info")
 
-    def __init__(self, left, colscale, right, rank, zero=False):
+    def __init__(self, left, colscale, right, rank, zero=False, info=None):
         self.left, self.colscale, self.right, self.rank, self.zero = left, colscale, right, rank, zero
+        self.info = info  # [B] int32 from the eigensolver epilogue: the item's rank by the rank rule, 0 = zero guard (round.py:137-145)
 
     def left_scaled(self) -> torch.Tensor:
         if self.colscale is None:
             return self.left
         return _hip.scale_cols(self.left, self.colscale, _hip.SCALE_MUL)
+
+
+def _deferred_readback(x: torch.Tensor):
+    """Start an asynchronous copy of a small device tensor to pinned host memory on the current stream and return a
+    callable that waits for THAT copy (an event -- not a stream or device synchronisation) and hands back the host
+    tensor.  For control-flow scalars that are only needed once everything else has been enqueued: the host blocks,
+    the device never idles."""
+    host = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+    host.copy_(x, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def wait() -> torch.Tensor:
+        ev.synchronize()
+        return host
+
+    return wait
 
 
 def _select_rank(info: torch.Tensor, batch: bool, rmax: Optional[int], k: int) -> int:
@@ -340,7 +358,7 @@ def truncate(
         right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst)
         if algorithm == "svd" and not left_ortho:
             _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
-        return Truncation(left, None, right, r)
+        return Truncation(left, None, right, r, info=info)
 
     if not left_side and _hip.colsweep_fused_ok(M):
         # Tall matrix with up to 64 columns (the first, largest steps of a dense right-to-left TT-SVD): the same fused
@@ -361,7 +379,7 @@ def truncate(
         left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
         if algorithm == "svd" and left_ortho:
             _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
-        return Truncation(left, None, right, r)
+        return Truncation(left, None, right, r, info=info)
 
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
@@ -415,7 +433,7 @@ def truncate(
             if dead_rel is not None:
                 _hip.orth_fixup(right, sig, r, dead_rel)
         U = _hip.gemm(V1, Vr) if V1 is not None else Vr
-        return Truncation(U, None if left_ortho else sig, right, r)
+        return Truncation(U, None if left_ortho else sig, right, r, info=info)
     # right side: left = Mw Vr (= U sigma); right = (V1 Vr)^T
     if left_ortho:
         left = _hip.gemm(Mw, Vr, colscale=sig, colscale_mode=_hip.SCALE_DIV)
@@ -431,7 +449,7 @@ def truncate(
             right = _hip.gemm(Vr, V1, transA=True, transB=True)
         else:
             right = Vr.transpose(1, 2).contiguous()
-    return Truncation(left, None, right, r)
+    return Truncation(left, None, right, r, info=info)
 
 
 def _scale_batch(X: torch.Tensor, e: torch.Tensor, sign: int) -> torch.Tensor:
@@ -459,8 +477,37 @@ def _range_guard_from_norms(nr: torch.Tensor):
     return e
 
 
+def _zero_factors(M3):
+    Bt, m, n = M3.shape
+    return (torch.zeros((Bt, m, 1), dtype=M3.dtype, device=M3.device), torch.zeros((Bt, 1, n), dtype=M3.dtype, device=M3.device))
+
+
+def _truncated_svd_batch(M3, rmax, left_ortho, algorithm):
+    """Batch mode of ``truncated_svd``: the rank is not data dependent (round.py:149-150), so the kernels are enqueued
+    optimistically and the two data-dependent exceptions -- an fp32 item outside the 2^+-40 exponent window (the range
+    guard: redo with scaled inputs) and an all-zero batch (round.py:138-141: rank-1 zeros) -- are decided from flags read
+    back ONCE, after everything has been enqueued (no host wait in front of any kernel)."""
+    Bt = M3.shape[0]
+    range_flag = None
+    if M3.dtype == torch.float32:
+        _, e = _hip.pow2_normalize(_hip.norm(M3.reshape(Bt, -1)).reshape(-1, 1), exponent_only=True)
+        range_flag = _deferred_readback(e.abs().amax())
+    t = truncate(M3, None, rmax, left_ortho, algorithm, True)
+    zero_flag = _deferred_readback(t.info.amax()) if t.info is not None else None
+    if range_flag is not None and int(range_flag().item()) >= 40:
+        return None  # (rare) the caller takes the scaled path
+    if zero_flag is not None and int(zero_flag().item()) == 0:
+        return _zero_factors(M3)
+    left = t.left_scaled()
+    return (left if left.is_contiguous() else left.contiguous()), t.right
+
+
 def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
     """round.py:52-187 on a [B, m, n] device tensor -> (left [B, m, r], M2 [B, r, n])."""
+    if batch:
+        res = _truncated_svd_batch(M3, rmax, left_ortho, algorithm)
+        if res is not None:
+            return res
     e = _range_guard(M3)
     if e is not None:  # out-of-range fp32 scale: work on M 2^-e, give the exponent back to the non-orthonormal factor
         M3 = _scale_batch(M3, e, -1)
@@ -471,6 +518,8 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
     if delta is None:
         delta = 0.0
     t = truncate(M3, delta, rmax, left_ortho, algorithm, batch)
+    if batch and t.info is not None and int(t.info.amax().item()) == 0:  # round.py:138-141 (scaled path: exact zeros only)
+        return _zero_factors(M3)
     left = t.left_scaled()
     if not left.is_contiguous():
         left = left.contiguous()
@@ -705,8 +754,24 @@ def round_tt(
         factor_orthogonalize(c, Us, i)
     Bt = c[0].shape[0]
     nchunk = _stream_chunks(Bt, batch)
+    # Batch mode, zero guard of round.py:137-141: when EVERY item's sigma_max lies below 1e-13 at the first truncation the
+    # reference returns rank-1 zeros for the whole batch (and then for every further bond: the carry is zero).  The ranks
+    # of a batch are otherwise not data dependent, so the sweep is enqueued for them without waiting; the per-item flags
+    # the eigensolver epilogue leaves behind (info == 0) are reduced on the device, copied to pinned host memory and only
+    # looked at after the last kernel of the sweep has been enqueued.
+    zflags: Optional[list] = [] if batch else None
+    shapes = [tuple(x.shape[1:]) for x in c]
+
+    def all_zero_batch() -> bool:
+        return bool(zflags) and all(int(w().item()) == 0 for w in zflags)
+
+    def zero_train():
+        return [torch.zeros((Bt, shapes[0][0] if mu == 0 else 1, shapes[mu][1], shapes[N - 1][2] if mu == N - 1 else 1),
+                            dtype=c[0].dtype, device=c[0].device) for mu in range(N)]
+
     if nchunk == 1:
-        return _round_tt_sweep(c, eps, rmax, algorithm, batch, None, 0)
+        out = _round_tt_sweep(c, eps, rmax, algorithm, batch, None, 0, zflags)
+        return zero_train() if all_zero_batch() else out
     dev = c[0].device
     main = torch.cuda.current_stream(dev)
     streams = _side_streams(dev, nchunk)
@@ -716,21 +781,24 @@ def round_tt(
         hi = lo + q + (1 if ci < rem else 0)
         bounds.append((lo, hi))
         lo = hi
-    shapes = [tuple(x.shape[1:]) for x in c]
     tails, out_r = _rounded_tails(shapes, rmax)
     arena = _OutArena(Bt, bounds, main, tails, c[0])
     for ci, st in enumerate(streams):
         st.wait_stream(main)
         with torch.cuda.stream(st):
             lo, hi = bounds[ci]
-            _round_tt_sweep([x[lo:hi] for x in c], eps, rmax, algorithm, batch, arena, ci)
+            _round_tt_sweep([x[lo:hi] for x in c], eps, rmax, algorithm, batch, arena, ci, zflags)
     for st in streams:
         main.wait_stream(st)
+    if all_zero_batch():
+        return zero_train()
     return [arena.full[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
 
 
-def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.Tensor]:
-    """The two sweeps on one (sub-)batch; with an ``arena`` the resulting cores are written into its slices."""
+def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -> List[torch.Tensor]:
+    """The two sweeps on one (sub-)batch; with an ``arena`` the resulting cores are written into its slices.
+    ``zflags``: list that receives the deferred readback of "largest rank-rule result of the first truncation" (0 = every
+    item of this sub-batch hit the zero guard); see ``round_tt``."""
     N = len(c)
     facs = []
     Rprev = None  # R factor still to be pushed into the current core
@@ -801,6 +869,8 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk) -> List[torch.
             def alloc(r, mu=mu, n=I * rn):
                 return arena.slice(mu, chunk, (r, n))
         t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram)
+        if zflags is not None and mu == N - 1 and t.info is not None:
+            zflags.append(_deferred_readback(t.info.amax()))  # ([B] int32 -> one scalar: control flow only)
         right = t.right
         if arena is not None:
             dst = alloc(t.rank)

@@ -35,15 +35,28 @@ def _wrap(ref_cls, name: str, cpu: bool):
     return method
 
 
+_ACTIVE = {}  # id(module) -> (module, undo): a module is patched at most once
+
+
 def patch(tn_module, cpu: bool = True) -> Callable[[], None]:
     """Rebind the orthogonalisation / rounding methods of ``tn_module.Tensor`` and ``tn_module.truncated_svd`` to this
-    package.  ``cpu=False`` leaves CPU tensors to the reference's own code.  Returns a function that undoes the patch."""
+    package.  ``cpu=False`` leaves CPU tensors to the reference's own code.  Returns a function that undoes the patch.
+
+    Idempotent: patching an already patched module returns the SAME undo function (the first patch stays in force, its
+    ``cpu`` setting included), so nested ``patch`` / ``undo`` pairs cannot restore half of the originals.
+    Rebound names: the methods in ``_METHODS`` on ``tn_module.Tensor``, ``tn_module.truncated_svd`` and
+    ``tn_module.round.truncated_svd``.  Modules that bound the function at import time with ``from .round import
+    truncated_svd`` (the reference has none besides its ``__init__`` star import, which is the first of the two names)
+    keep the original."""
+    key = id(tn_module)
+    if key in _ACTIVE and _ACTIVE[key][0] is tn_module:
+        return _ACTIVE[key][1]
     ref_cls = tn_module.Tensor
     saved = {}
     for name in _METHODS:
         if hasattr(ref_cls, name):
             saved[name] = getattr(ref_cls, name)
-            if hasattr(saved[name], "_tntorch_amd_original"):  # already patched: keep the true original
+            if hasattr(saved[name], "_tntorch_amd_original"):  # patched through another module object: keep the true original
                 saved[name] = saved[name]._tntorch_amd_original
             setattr(ref_cls, name, _wrap(ref_cls, name, cpu))
     targets = [tn_module] + [m for m in (getattr(tn_module, "round", None),) if hasattr(m, "truncated_svd")]
@@ -52,9 +65,12 @@ def patch(tn_module, cpu: bool = True) -> Callable[[], None]:
         m.truncated_svd = _truncated_svd
 
     def unpatch():
+        if _ACTIVE.pop(key, None) is None:
+            return  # already undone
         for name, fn in saved.items():
             setattr(ref_cls, name, fn)
         for m, fn in saved_fn:
             m.truncated_svd = fn
 
+    _ACTIVE[key] = (tn_module, unpatch)
     return unpatch

@@ -28,7 +28,18 @@ def _create(function, *shape, ranks_tt=None, ranks_cp=None, ranks_tucker=None, r
     if ranks_tt is None and ranks_tucker is None:
         raise ValueError("Specify at least one of: ranks_tt ranks_cp, ranks_tucker")
     if ranks_tt is None:
-        raise NotImplementedError("tntorch_amd: a pure Tucker tensor (ranks_tucker without ranks_tt) is a CP-cored format, out of scope")
+        # create.py:243-272: "we imitate a Tucker decomposition: we set full TT-ranks" -- bond n of the Tucker core gets the
+        # smaller side of its unfolding (core modes: the Tucker rank where one is given, else the mode size)
+        rt = ranks_tucker if hasattr(ranks_tucker, "__len__") else [ranks_tucker] * N
+        cs = [int(spatial[n] if rt[n] is None else rt[n]) for n in range(N)]
+        left, right = 1, 1
+        for c in cs:
+            right *= c
+        ranks_tt = []
+        for n in range(N - 1):
+            left *= cs[n]
+            right //= cs[n]
+            ranks_tt.append(min(left, right))
     if not hasattr(ranks_tt, "__len__"):
         ranks_tt = [ranks_tt] * (N - 1)
     ranks = [1] + [int(r) for r in ranks_tt] + [1]

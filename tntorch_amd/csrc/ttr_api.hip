@@ -290,7 +290,7 @@ using namespace ttr;
 
 extern "C" {
 
-int ttr_version(void) { return 1; }
+int ttr_version(void) { return TTR_ABI_VERSION; }
 
 const char* ttr_last_error(void) { return g_err.c_str(); }
 

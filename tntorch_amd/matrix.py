@@ -105,7 +105,14 @@ class TTMatrix:
                 acc = _hip.gemm(acc, D)
             else:
                 acc = torch.bmm(acc, D)
-        if acc.shape[1] > 1:  # boundary ranks > 1 are summed away like the reference's ones-vector start (factor = ones(1))
-            acc = acc[:, :1]
+        if acc.shape[1] > 1:
+            # a leading boundary rank > 1 is summed away: the reference starts from factor = ones(1), which einsum broadcasts
+            # over the first rank index (matrix.py:160-175)
+            if acc.is_cuda:
+                from . import _hip
+
+                acc = _hip.gemm(torch.ones((acc.shape[0], 1, acc.shape[1]), dtype=acc.dtype, device=acc.device), acc)
+            else:
+                acc = acc.sum(dim=1, keepdim=True)
         out = acc[:, 0, 0]
         return out if self.batch else out[0]

@@ -487,12 +487,16 @@ class Tensor(object):
         rm = list(rmax) if hasattr(rmax, "__len__") else [rmax] * (N - 1)
         out = ops_for(ca[0]).round_tt(_hipops.sum_cores(ca, cb), eps, rm, algorithm, a.batch, None)
         res = Tensor(a._denorm(out), batch=a.batch)
-        if not a.batch and eps > 0:  # second half of round(): Tucker stage with the remaining budget
+        # second half of round(): Tucker stage with the remaining budget and the same kwargs Tensor.round passes on (rmax
+        # included).  Batch tensors: the reference's round() cannot evaluate `reached` on a batch at all (relative_error ->
+        # dot raises, metrics.py:28-116), and neither can this package's generic path; the fused sum is an extension there and,
+        # like round_tt in batch mode (tensor.py:2036-2037), ignores eps: TT stage only.
+        if not a.batch and eps > 0:
             gg = dot(a, a) + 2 * dot(a, b) + dot(b, b)
             err2 = (gg + dot(res, res) - 2 * (dot(a, res) + dot(b, res))).clamp(0)
             reached = float(torch.sqrt(err2) / torch.sqrt(gg.clamp(0)))
             if reached < eps:
-                res.round_tucker((1 + eps) / (1 + reached) - 1, algorithm=algorithm)
+                res.round_tucker((1 + eps) / (1 + reached) - 1, rmax=rmax, algorithm=algorithm)
         return res
 
     def round_tucker(
