@@ -170,7 +170,10 @@ def cpu_baseline(budget_s=25.0):
         "cores": nt,
         "kind": "port",
         "sample": f"oracle.round_tt(rmax=32) of ONE 64^8 rank-64 float32 TT (the metric's unit), median of <=3 runs per "
-                  f"(algorithm, thread count) over threads {cands}; reported: fastest = algorithm='{fast_alg}' at {nt} threads",
+                  f"(algorithm, thread count) over threads {cands}; reported: fastest = algorithm='{fast_alg}' at {nt} threads.  "
+                  "kind 'port': /root/reference does not travel to the GPU box; in the build container the reference itself takes "
+                  "39 ms per tensor ('eig', 8 threads) against the oracle's 48 ms (same LAPACK calls, bit-identical output), "
+                  "i.e. the port flatters the GPU by ~1.2x",
         "algorithm": fast_alg,
         "sec_per_tensor": {a: best[a][0] for a in best},
         "threads": {a: best[a][1] for a in best},
@@ -238,18 +241,37 @@ def main():
     ap.add_argument("--batch", type=int, default=2048,
                     help="tensors per GPU per step (2048 = eight single-wave 64x64 eigenproblems per CU; 13 GB of cores)")
     ap.add_argument("--algorithm", default="svd", choices=["svd", "eig"])
-    ap.add_argument("--config", default="metric", choices=["metric", "c1", "c3"],
-                    help="metric (default): the headline workload; c1 / c3: BASELINE's dense configs (tools/bench_dense.py)")
+    ap.add_argument("--config", default="metric", choices=["metric", "c1", "c2", "c3", "c4"],
+                    help="metric (default): the headline workload (its line also carries `configs`: one entry per BASELINE config); "
+                         "c1 .. c4: one of BASELINE's other configs alone (tools/bench_configs.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch / single-tensor extra measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 .. C4 entries of the default line (`configs`)")
+    ap.add_argument("--gather", default=os.environ.get("TTR_BENCH_GATHER", "step"), choices=["step", "end", "none"],
+                    help="N > 1: `step` (default) = every step's rounded cores are gathered on rank 0 (asynchronously, under the next "
+                         "step's compute); `end` = ONE gather after the last timed step (north_star: 'a single RCCL gather ... at the "
+                         "end'), inside the timed region; `none` = no gather (compute-only scaling)")
     ap.add_argument("--single-stream", action="store_true",
                     help="issue the timed region on one stream too (for rocprofv3 kernel traces: with sub-batch "
                          "streams the traced kernel durations overlap)")
     args = ap.parse_args()
     if args.config != "metric":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_dense
-        return bench_dense.main(args)
+        import bench_configs
+        return bench_configs.main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run with the
+        # loopback rendezvous the driver would use); rank 0 of the child job prints the JSON line
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        return sys.exit(subprocess.call(cmd, env=env))
 
     import torch.distributed as dist
 
@@ -301,13 +323,19 @@ def main():
         ev.record()
         inflight.append(ev)
         step_events.append(ev)
-        if world > 1:
+        last_step[0] = t
+        if world > 1 and args.gather == "step":
             if pending[0] is not None:
                 pending[0].wait()
             pending[0] = gather_batch(t, dst=0, sizes=sizes, async_op=True)
         return t
 
+    last_step = [None]
+
     def drain():
+        """Everything the root is owed has arrived when this returns (called inside the timed region)."""
+        if world > 1 and args.gather == "end" and last_step[0] is not None:
+            return gather_batch(last_step[0], dst=0, sizes=sizes, async_op=False).wait()
         if pending[0] is not None:
             res = pending[0].wait()
             pending[0] = None
@@ -325,10 +353,23 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        if rank == 0:  # the root really holds every rank's rounded cores
+        if rank == 0 and args.gather != "none":  # the root really holds every rank's rounded cores
             assert gathered is not None and len(gathered) == world
             assert all(list(g.ranks_tt) == [1] + [R_OUT] * (N_CORES - 1) + [1] and g.cores[0].shape[0] == B for g in gathered)
             assert torch.isfinite(gathered[-1].cores[3]).all()
+
+    # ---- N > 1: the gather of one step's result ALONE (nothing else running), so that a scaling line shows which side
+    # binds: `gather.alone_ms` against `ms_per_step`.  Every peer sends its packed cores over its own xGMI link to rank 0.
+    gather_info = None
+    if world > 1:
+        per_peer = sum(c.numel() * c.element_size() for c in out.cores)
+        fence()
+        g0 = time.perf_counter()
+        gather_batch(out, dst=0, sizes=sizes, async_op=False).wait()
+        fence()
+        g_ms = (time.perf_counter() - g0) * 1e3
+        gather_info = {"mode": args.gather, "bytes_per_peer_per_step": per_peer, "peers": world - 1, "alone_ms": g_ms,
+                       "root_inbound_GBs": per_peer * (world - 1) / g_ms / 1e6, "per_link_GBs": per_peer / g_ms / 1e6}
 
     # ---- per-kernel device time over an identical pass (HIP events on the launch stream).  The timed region
     # above runs sub-batches on several streams so that kernels overlap; here every kernel must run alone for
@@ -407,9 +448,13 @@ def main():
                 "tensors_per_gpu_per_step": B,
                 "algorithm": args.algorithm,
                 "streams_per_gpu": 1 if args.single_stream else 2,
-                "parallelism": f"batch-sharded x{world}, one async RCCL gather of packed cores per step (overlapped with the next step)" if world > 1 else "single GPU",
+                "parallelism": (f"batch-sharded x{world}, " + {
+                    "step": "one async RCCL gather of packed cores per step (overlapped with the next step)",
+                    "end": "ONE RCCL gather of the packed cores after the last step (inside the timed region)",
+                    "none": "no gather"}[args.gather]) if world > 1 else "single GPU",
             },
             "nccl_ranks": nccl_ranks,
+            "gather": gather_info,
             "allocator": getattr(timed_steps, "allocator", None),
             # device time between the completion events of consecutive steps (warm-up steps included, first one omitted)
             "host_enqueue_ms": host_ms,
@@ -457,6 +502,14 @@ def main():
                 el, _, _ = timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)
                 extras[label] = {"tensors_per_step": Bx, "ms_per_step": el / st * 1e3, "cores_per_s": Bx * N_CORES * st / el}
             res["extras"] = extras
+        if world == 1 and not args.no_extras and not args.no_configs:
+            # BASELINE's other configs (C1 .. C4), one entry each: time, SURVEY 8d flops / bytes, roofline fraction, CPU
+            # baseline on the config or its largest feasible proxy, oracle check (tools/bench_configs.py)
+            del inp, out, t
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            res["configs"] = bench_configs.config_extras(tn, dev, algorithm=args.algorithm, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             res["cpu_baseline"] = cb

@@ -211,9 +211,41 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
                    void* V, int64_t ldv, int64_t strideV,
                    void* sigma, int64_t stride_sigma,
                    int32_t* info,
-                   int eig_mode, int use_delta, double delta2, int64_t rmax,
+                   int eig_mode, int use_delta, double delta2, const double* delta2_dev, int64_t rmax,
                    int abs_floor, int32_t* sweeps,
                    void* workspace, int64_t workspace_bytes, void* stream);
+/* `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
+ * of `delta2` -- tensor.py:2039-2051 computes delta from the norm of the last core and reads it back (`.item()`); an
+ * eps-mode sweep that keeps it on the device enqueues every bond without a host synchronisation. */
+
+/*
+ * Block-Jacobi driver for symmetric eigenproblems above the single-workgroup limit -- torch.linalg.eigh / svd of
+ * round.py:96, 115 on the n = I r Gram matrices of a dense TT-SVD (BASELINE configs C1: n = 1024, C3: n = 256).
+ * G[item] (n x n, n = 2 b npairs, b <= 32) and the accumulated eigenvector matrix V[item] are updated IN PLACE, one
+ * round = ttr_bj_solve + ttr_bj_apply with the round's pairing `pair_tab` (device int32 [npairs][2]: block indices of
+ * every pair; over nbk - 1 rounds of a round-robin tournament every two blocks meet once = one sweep):
+ *   ttr_bj_solve    W[item * npairs + p] (w x w, w = 2 b) = eigenvectors of the pair's diagonal problem
+ *                   [[G_ii, G_ij], [G_ji, G_jj]], diagonal-matched column order (W -> I as the problem -> diagonal);
+ *                   `scratch`: ttr_bj_scratch_bytes(...).
+ *   ttr_bj_apply    G[P, Q] <- W_p^T G[P, Q] W_q for all pairs of pairs, V[:, Q] <- V[:, Q] W_q; with `offsq` (device
+ *                   double [items], optional) the squared off-diagonal entries of the updated G are added to offsq[item].
+ *   ttr_bj_control  once per sweep: sets ctrl[0] = 1 ("converged") when no pair problem of the sweep rotated anything
+ *                   (relative != 0) or when max_item sqrt(offsq[item]) / gnorm[item] <= tol or stagnates (relative == 0;
+ *                   gnorm = ||G[item]||_F of the input, element type of `dtype`); resets ctrl[1] and offsq.
+ * ctrl: device int32 [4] = {converged, pair problems that rotated in the current sweep, sweeps performed, unused}, zeroed
+ * by the caller; state: device double [items + 1] = offsq followed by the previous sweep's ratio (initialise to -1).
+ * Once ctrl[0] is set every later ttr_bj_* launch returns at its first instruction: the caller enqueues the maximum
+ * number of sweeps and never reads anything back.
+ */
+int64_t ttr_bj_scratch_bytes(int dtype, int64_t b, int64_t npairs, int64_t items);
+int ttr_bj_solve(int dtype, int64_t b, int64_t npairs, int64_t items,
+                 const void* G, int64_t ldg, int64_t strideG, const int32_t* pair_tab,
+                 void* W, void* scratch, int32_t* ctrl, void* stream);
+int ttr_bj_apply(int dtype, int64_t b, int64_t npairs, int64_t items,
+                 void* G, int64_t ldg, int64_t strideG, void* V, int64_t ldv, int64_t strideV,
+                 const int32_t* pair_tab, const void* W, const int32_t* ctrl, double* offsq, void* stream);
+int ttr_bj_control(int dtype, int64_t items, int32_t* ctrl, double* state, const void* gnorm, int relative, double tol,
+                   void* stream);
 
 /*
  * CP-ALS building blocks (tn.Tensor(X, ranks_cp=R), tensor.py:279-394; BASELINE config C4).

@@ -208,6 +208,40 @@ def test_eigh_block_jacobi(dt, n, B, solver):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("relative", [False, True])
+@pytest.mark.parametrize("n,B", [(256, 3), (1024, 1), (48, 5)])
+def test_block_jacobi_device_loop_matches_host_loop(dt, relative, n, B):
+    """The device-resident sweep loop (ttr_bj_solve / ttr_bj_apply / ttr_bj_control: pair table instead of moved blocks,
+    convergence word on the device, nothing read back) against the round-2 host-driven loop on the same matrices: same
+    eigenvalues, orthogonal V, small residual; C3's bond size (256, batched), C1's (1024) and a small block width (b = 24)."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(n + B)
+    Mx = torch.randn(B, n, n + 7, generator=g, dtype=torch.float64) * torch.logspace(0, -2, n, dtype=torch.float64)[None, :, None]
+    G = (Mx @ Mx.transpose(1, 2))
+    if relative:   # pass 2 of 'svd': nearly diagonal, graded
+        w, Q = torch.linalg.eigh(G)
+        E = 1e-4 * torch.randn(B, n, n, generator=g, dtype=torch.float64)
+        G = torch.diag_embed(w) + (E + E.transpose(1, 2)) * w.sqrt()[:, :, None] * w.sqrt()[:, None, :]
+    G = G.to(dt).cuda()
+    out = {}
+    for on_dev in (True, False):
+        _hipops.BLOCK_JACOBI_ON_DEVICE = on_dev
+        try:
+            V, d = _hipops.eigh_block_jacobi(G, relative=relative)
+        finally:
+            _hipops.BLOCK_JACOBI_ON_DEVICE = True
+        out[on_dev] = (V.cpu().double(), d.cpu().double())
+    wref = torch.linalg.eigvalsh(G.cpu().double())
+    grow = max(1.0, (n / 512) ** 0.5)
+    for on_dev, (V, d) in out.items():
+        ds = d.sort(dim=1).values
+        assert ((ds - wref).abs().max(dim=1).values / wref[:, -1]).max() < grow * tol(dt, 4e-6, 1e-13), on_dev
+        assert (V.transpose(1, 2) @ V - torch.eye(n, dtype=torch.float64)).abs().max() < grow * tol(dt, 3e-5, 1e-12), on_dev
+        resid = (G.cpu().double() @ V - V * d[:, None, :]).abs().max() / wref.max()
+        assert resid < grow * tol(dt, 3e-5, 1e-12), on_dev
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_eigh_rank_rule(dt):
     """Rank rule of round.py:147-158 on a diagonal matrix with known sigma."""
     h = _hip()

@@ -94,8 +94,16 @@ _SIGNATURES = {
         c_int,
         [c_int, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
-         c_int, c_int, c_double, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+         c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     ),
+    "ttr_bj_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "ttr_bj_solve": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ttr_bj_apply": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "ttr_bj_control": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "ttr_sweep_gram_parts": (c_int64, [c_int64, c_int64]),
     "ttr_rowgram": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "ttr_rotgram": (
@@ -471,7 +479,7 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
 @_on_device
 def eigh_trunc(
     G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: int = 1,
-    sweeps: Optional[torch.Tensor] = None,
+    sweeps: Optional[torch.Tensor] = None, delta2_dev: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
     decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard).
@@ -496,12 +504,63 @@ def eigh_trunc(
     rmax = int(min(max(int(rmax), 1), 2**31 - 1))
     code = L.ttr_eigh_trunc(
         dt, n, batch, G.data_ptr(), ldg, sG, gparts, sGp, V.data_ptr(), n, n * n, sigma.data_ptr(), n, info.data_ptr(),
-        eig_mode, int(bool(use_delta)), float(delta2), rmax, int(abs_floor),
+        eig_mode, int(bool(use_delta)), float(delta2),
+        delta2_dev.data_ptr() if delta2_dev is not None else None, rmax, int(abs_floor),
         sweeps.data_ptr() if sweeps is not None else None,
         ws.data_ptr() if ws is not None else None, wsb, _stream(),
     )
     _check(code, "ttr_eigh_trunc")
     return V, sigma, info
+
+
+_BJ_TABLES: dict = {}
+
+
+def bj_pair_tables(nbk: int, device) -> torch.Tensor:
+    """Round-robin tournament over an even number of blocks: int32 [nbk - 1, nbk / 2, 2] on the device (cached)."""
+    key = (nbk, str(device))
+    if key not in _BJ_TABLES:
+        assert nbk % 2 == 0 and nbk >= 2
+        circle = list(range(nbk))
+        rounds = []
+        for _ in range(nbk - 1):
+            rounds.append([[circle[i], circle[-1 - i]] for i in range(nbk // 2)])
+            circle = [circle[0], circle[-1]] + circle[1:-1]
+        _BJ_TABLES[key] = torch.tensor(rounds, dtype=torch.int32).to(device)
+    return _BJ_TABLES[key]
+
+
+@_on_device
+def bj_sweeps(G: torch.Tensor, V: torch.Tensor, b: int, relative: bool, tol: float, max_sweeps: int) -> torch.Tensor:
+    """Block-Jacobi sweeps on G [B, n, n] / V [B, n, n] IN PLACE (ttr_bj_solve / ttr_bj_apply / ttr_bj_control), nothing
+    read back: every launch after convergence returns at once.  Returns the device control block (int32 [4]:
+    converged, -, sweeps performed, -) for diagnostics."""
+    L = lib()
+    dt = dtype_code(G.dtype)
+    Bt, n, _ = G.shape
+    nbk = n // b
+    assert n == nbk * b and nbk % 2 == 0 and G.is_contiguous() and V.is_contiguous()
+    npairs, w = nbk // 2, 2 * b
+    tabs = bj_pair_tables(nbk, G.device)
+    ctrl = torch.zeros(4, dtype=torch.int32, device=G.device)
+    state = torch.zeros(Bt + 1, dtype=torch.float64, device=G.device)
+    state[Bt:].fill_(-1.0)
+    gn = norm(G.reshape(Bt, -1)) if not relative else None
+    W = torch.empty((Bt * npairs, w, w), dtype=G.dtype, device=G.device)
+    scratch = torch.empty(max(int(L.ttr_bj_scratch_bytes(dt, b, npairs, Bt)), 16), dtype=torch.uint8, device=G.device)
+    st = _stream()
+    rounds = nbk - 1
+    for _ in range(max_sweeps):
+        for r in range(rounds):
+            tab = tabs[r].data_ptr()
+            _check(L.ttr_bj_solve(dt, b, npairs, Bt, G.data_ptr(), n, n * n, tab, W.data_ptr(), scratch.data_ptr(),
+                                  ctrl.data_ptr(), st), "ttr_bj_solve")
+            off = state.data_ptr() if (not relative and r == rounds - 1) else None
+            _check(L.ttr_bj_apply(dt, b, npairs, Bt, G.data_ptr(), n, n * n, V.data_ptr(), n, n * n, tab, W.data_ptr(),
+                                  ctrl.data_ptr(), off, st), "ttr_bj_apply")
+        _check(L.ttr_bj_control(dt, Bt, ctrl.data_ptr(), state.data_ptr(), gn.data_ptr() if gn is not None else None,
+                                int(relative), float(tol), st), "ttr_bj_control")
+    return ctrl
 
 
 @_on_device

@@ -168,6 +168,11 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
     G0 = G
     G = G.clone()
     V = torch.eye(n, dtype=dt, device=dev).repeat(Bt, 1, 1)
+    if nbk % 2 == 0 and BLOCK_JACOBI_ON_DEVICE:
+        # the whole sweep loop on the device: two launches per round, one control launch per sweep, no readback -- the
+        # maximum number of sweeps is enqueued and everything after convergence returns at its first instruction
+        _hip.bj_sweeps(G, V, b, relative, 0.5 * math.sqrt(n) * torch.finfo(dt).eps, _BJ_MAX_SWEEPS)
+        return _bj_finish(G0, G, V, relative)
     circle = list(range(nbk)) + ([-1] if nbk % 2 else [])  # -1: bye
     phys = list(range(nbk))
     ar = torch.arange(b, device=dev)
@@ -215,6 +220,13 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
         if ratio <= tol or (prev is not None and sweep >= 3 and ratio > 0.5 * prev):
             break
         prev = ratio
+    return _bj_finish(G0, G, V, relative)
+
+
+BLOCK_JACOBI_ON_DEVICE = True   # False: the round-2 host-driven loop (kept for odd block counts and as a cross-check in tests)
+
+
+def _bj_finish(G0, G, V, relative):
     d = torch.diagonal(G, dim1=1, dim2=2).contiguous()
     # one Newton-Schulz step removes the orthogonality drift of the ~100 accumulated block rotations
     # (3e-6 in fp32, 1e-13 in fp64 -- the Rayleigh quotients below assume unit columns)
@@ -1079,10 +1091,19 @@ def _cp_solve(prod: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     """A = Y prod^+ for the symmetric PSD R x R Hadamard-of-Grams matrix (``torch.linalg.lstsq(prod, Y^T)``,
     tensor.py:339-341): eigen-decomposition prod = V diag(s^2) V^T, A = ((Y V) / s / s) V^T."""
     R = prod.shape[-1]
+    # The Hadamard product of the Gram matrices is badly conditioned during the first sweeps after the HOSVD start (measured
+    # 2.4e6 for R = 32 on 48^4): an fp32 eigen-decomposition resolves its small eigenvalues to ~15 %, and the ALS trajectory
+    # then leaves the reference's (lstsq, tensor.py:339-341) by 1e-3 .. 4e-3 in the error after five sweeps -- LAPACK's
+    # fp32 eigh does the same (measured on the CPU), so it is the method, not the kernel.  The R x R system and the
+    # I x R right-hand side are tiny: fp32 inputs are solved in fp64 (conversion copies + the fp64 kernels).
+    out_dt = prod.dtype
+    if out_dt == torch.float32:
+        prod, Y = prod.double(), Y.double()
     V, sg, _ = _eigh_any(prod.reshape(1, R, R), _hip.EIG_RAW, False, 0.0, R, _hip.SOLVER_TRIDIAG)
     Z = _hip.gemm(Y[None], V, colscale=sg, colscale_mode=_hip.SCALE_DIV)
     Z = _hip.scale_cols(Z, sg, _hip.SCALE_DIV)
-    return _hip.gemm(Z, V, transB=True)[0]
+    A = _hip.gemm(Z, V, transB=True)[0]
+    return A if A.dtype == out_dt else A.to(out_dt)
 
 
 class _CpState:

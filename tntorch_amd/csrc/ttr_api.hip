@@ -258,7 +258,15 @@ int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                   int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                  int64_t ws_bytes, hipStream_t stream);
+                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr);
+int eigh_pairs_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, const void* G, int64_t ldg, int64_t strideG,
+                        const int32_t* pair_tab, void* W, void* scratch, const int32_t* skip_flag, int32_t* rot_count,
+                        hipStream_t stream);
+int bj_apply_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, void* G, int64_t ldg, int64_t strideG, void* V,
+                      int64_t ldv, int64_t strideV, const int32_t* pair_tab, const void* W, const int32_t* ctrl, double* offsq,
+                      hipStream_t stream);
+int bj_control_dispatch(int dtype, int64_t items, int32_t* ctrl, double* state, const void* gnorm, int relative, double tol,
+                        hipStream_t stream);
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int eigh_max_n(int dtype);
 int eigh_max_n_lds(int dtype);
@@ -424,8 +432,8 @@ int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return e
 
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                    int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma,
-                   int32_t* info, int eig_mode, int use_delta, double delta2, int64_t rmax, int abs_floor,
-                   int32_t* sweeps, void* workspace, int64_t workspace_bytes, void* stream) {
+                   int32_t* info, int eig_mode, int use_delta, double delta2, const double* delta2_dev, int64_t rmax,
+                   int abs_floor, int32_t* sweeps, void* workspace, int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_trunc: bad dtype %d", dtype);
   TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1 && gparts >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
   TTR_REQUIRE(abs_floor >= TTR_SOLVER_JACOBI_REL && abs_floor <= TTR_SOLVER_JACOBI_LIVE, TTR_E_INVALID,
@@ -436,7 +444,47 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t l
               eig_mode);
   return eigh_dispatch(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info,
                        eig_mode, use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, delta2_dev);
+}
+
+int64_t ttr_bj_scratch_bytes(int dtype, int64_t b, int64_t npairs, int64_t items) {
+  const int64_t elem = dtype == TTR_F64 ? 8 : 4;
+  return items * npairs * (2 * b + 1) * elem;
+}
+
+static int bj_ok(const char* who, int dtype, int64_t b, int64_t npairs, int64_t items) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "%s: bad dtype %d", who, dtype);
+  TTR_REQUIRE(b >= 1 && b <= 32 && npairs >= 1 && npairs <= 65535 && items >= 0, TTR_E_UNSUPPORTED,
+              "%s: block width %lld outside [1, 32] or %lld pairs outside [1, 65535]", who, (long long)b, (long long)npairs);
+  return TTR_OK;
+}
+
+int ttr_bj_solve(int dtype, int64_t b, int64_t npairs, int64_t items, const void* G, int64_t ldg, int64_t strideG,
+                 const int32_t* pair_tab, void* W, void* scratch, int32_t* ctrl, void* stream) {
+  const int rc = bj_ok("ttr_bj_solve", dtype, b, npairs, items);
+  if (rc != TTR_OK) return rc;
+  if (items == 0) return TTR_OK;
+  TTR_REQUIRE(G && pair_tab && W && scratch && ctrl, TTR_E_INVALID, "ttr_bj_solve: null pointer");
+  TTR_REQUIRE(items * npairs < (int64_t(1) << 31), TTR_E_UNSUPPORTED, "ttr_bj_solve: %lld pair problems exceed the grid",
+              (long long)(items * npairs));
+  return eigh_pairs_dispatch(dtype, b, npairs, items, G, ldg, strideG, pair_tab, W, scratch, ctrl, ctrl + 1, (hipStream_t)stream);
+}
+
+int ttr_bj_apply(int dtype, int64_t b, int64_t npairs, int64_t items, void* G, int64_t ldg, int64_t strideG, void* V,
+                 int64_t ldv, int64_t strideV, const int32_t* pair_tab, const void* W, const int32_t* ctrl, double* offsq,
+                 void* stream) {
+  const int rc = bj_ok("ttr_bj_apply", dtype, b, npairs, items);
+  if (rc != TTR_OK) return rc;
+  if (items == 0) return TTR_OK;
+  TTR_REQUIRE(G && V && pair_tab && W && ctrl, TTR_E_INVALID, "ttr_bj_apply: null pointer");
+  return bj_apply_dispatch(dtype, b, npairs, items, G, ldg, strideG, V, ldv, strideV, pair_tab, W, ctrl, offsq, (hipStream_t)stream);
+}
+
+int ttr_bj_control(int dtype, int64_t items, int32_t* ctrl, double* state, const void* gnorm, int relative, double tol,
+                   void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_bj_control: bad dtype %d", dtype);
+  TTR_REQUIRE(ctrl && state && (relative || gnorm), TTR_E_INVALID, "ttr_bj_control: null pointer");
+  return bj_control_dispatch(dtype, items, ctrl, state, gnorm, relative, tol, (hipStream_t)stream);
 }
 
 int ttr_norm(int dtype, int64_t count, int64_t batch, const void* x, int64_t stride_x, void* out, void* stream) {

@@ -48,6 +48,15 @@ struct EighArgs {
   int abs_floor;     // 1: also skip rotations with |G_pq| <= tol * max|G_ii| (plain Gram input: its entries are
                      //    only accurate to eps*||G||, below that level rotations chase rounding noise forever)
   int32_t* sweeps;   // optional [batch]: sweeps used (diagnostics / convergence tests)
+  // rank rule with the bound on the DEVICE (one double per launch; overrides delta2): eps-mode sweeps enqueue every bond
+  // without reading the norm back
+  const double* delta2_dev;
+  // block-Jacobi pair problems (ttr_bj_solve): grid = pairs_per_item * items; problem (item, pair) is the 2b x 2b matrix
+  // [[G_ii, G_ij], [G_ji, G_jj]] of blocks i = pair_tab[2 pair], j = pair_tab[2 pair + 1] of the item's n x n matrix
+  const int32_t* pair_tab;
+  int pair_b, pairs_per_item;
+  const int32_t* skip_flag;  // != 0 on the device: the driver has converged, the launch returns at once
+  int32_t* rot_count;        // incremented once per problem that rotated anything (the driver's "a whole sweep found nothing")
 };
 
 constexpr int kMaxPairs = 2048;  // n <= 4096 (fp32) / 2048 (fp64) in the global-memory variant: its rotation table and
@@ -85,6 +94,7 @@ constexpr int UNR = 8;          // rotation items batched per thread (n = 64: ex
 template <typename T, bool LDSRES>
 __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (p.skip_flag && *p.skip_flag != 0) return;  // (wave-uniform: one word for the whole launch)
   const int tid = threadIdx.x;
   const int64_t bt = blockIdx.x;
   const int n = p.n;
@@ -118,6 +128,20 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     Gs = Vs + (size_t)n * ld;
   }
 
+  if (p.pair_tab) {
+    // pair problem of the block-Jacobi driver: gather the four b x b blocks of the pair (the driver never moves blocks)
+    const int64_t item = bt / p.pairs_per_item;
+    const int pair = (int)(bt - item * p.pairs_per_item);
+    const int b = p.pair_b;
+    const int64_t ri = (int64_t)p.pair_tab[2 * pair] * b, rj = (int64_t)p.pair_tab[2 * pair + 1] * b;
+    const T* __restrict__ G = p.G + item * p.strideG;
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int i = idx / n, j = idx % n;
+      const int64_t gi = i < b ? ri + i : rj + (i - b), gj = j < b ? ri + j : rj + (j - b);
+      Gs[i * ld + j] = G[gi * p.ldg + gj];
+      Vs[i * ld + j] = (i == j) ? T(1) : T(0);
+    }
+  } else {
   const T* __restrict__ G = p.G + bt * p.strideG;
   for (int idx = tid; idx < n * n; idx += kThreads) {
     const int i = idx / n, j = idx % n;
@@ -125,6 +149,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
     Gs[i * ld + j] = gv;
     Vs[i * ld + j] = (i == j) ? T(1) : T(0);
+  }
   }
   if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
   __syncthreads();
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     } else if (!p.use_delta) {
       rank = (int)(cap < 1 ? 1 : cap);
     } else {
-      const T d2 = (T)p.delta2;
+      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
       double acc = 0.0;
       int tail = 0;
       for (int k = n - 1; k >= 0; --k) {
@@ -381,6 +406,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
     p.info[bt] = rank;
     if (p.sweeps) p.sweeps[bt] = sweeps_used;
+    if (p.rot_count && sweeps_used > 0) atomicAdd(p.rot_count, 1);
   }
 }
 
@@ -927,7 +953,7 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
     } else if (!p.use_delta) {
       rank = (int)(cap < 1 ? 1 : cap);
     } else {
-      const T d2 = (T)p.delta2;
+      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
       double acc = 0.0;
       int tail = 0;
       for (int k = n - 1; k >= 0; --k) {
@@ -978,11 +1004,12 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
                       int64_t stride_gpart, void* V,
                       int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                       int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                      int64_t ws_bytes, hipStream_t stream) {
+                      int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr) {
   const int64_t nmax = eigh_max_n(dtype);
   TTR_REQUIRE(n >= 1 && n <= nmax, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %lld]", (long long)n,
               (long long)nmax);
-  EighArgs<T> p;
+  EighArgs<T> p{};
+  p.delta2_dev = delta2_dev;
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
   p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
@@ -1029,12 +1056,52 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                   int64_t stride_gpart, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                  int64_t ws_bytes, hipStream_t stream) {
+                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev) {
   if (dtype == TTR_F32)
     return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
+                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
   return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                            use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream);
+                            use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
+}
+
+// Pair problems of one block-Jacobi round (ttr_bj_solve): `items * npairs` LDS-resident Jacobi problems of size w = 2 b <= 64
+// gathered from the items' n x n matrices through the device pair table; eigenvectors with the diagonal-matched column
+// order (W -> I as the pair block -> diagonal), W[(item * npairs + pair)] = w x w contiguous.  `scratch`: w + 1 elements per
+// problem (sigma, rank -- unused by the driver).  `skip_flag` / `rot_count`: device words of the driver's control block.
+template <typename T>
+static int eigh_pairs_typed(int64_t b, int64_t npairs, int64_t items, const T* G, int64_t ldg, int64_t strideG,
+                            const int32_t* pair_tab, T* W, T* scratch, const int32_t* skip_flag, int32_t* rot_count,
+                            hipStream_t stream) {
+  const int64_t w = 2 * b, nprob = items * npairs;
+  EighArgs<T> p{};
+  p.n = (int)w;
+  p.G = G; p.ldg = ldg; p.strideG = strideG; p.gparts = 1;
+  p.V = W; p.ldv = w; p.strideV = w * w;
+  p.sigma = scratch; p.stride_sigma = w;
+  p.info = reinterpret_cast<int32_t*>(scratch + nprob * w);
+  p.eig_mode = TTR_EIG_MATCH_DIAG; p.use_delta = 0; p.rmax = w;
+  p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
+  p.abs_floor = TTR_SOLVER_JACOBI_ABS;
+  p.pair_tab = pair_tab; p.pair_b = (int)b; p.pairs_per_item = (int)npairs;
+  p.skip_flag = skip_flag; p.rot_count = rot_count;
+  const size_t lds = eigh_lds_bytes(sizeof(T), w, true);
+  auto kern = eigh_jacobi_kernel<T, true>;
+  if (lds > 64 * 1024)
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ProfScope prof(TTR_PROF_EIGH, stream);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nprob), dim3(kThreads), lds, stream, p);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
+int eigh_pairs_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, const void* G, int64_t ldg, int64_t strideG,
+                        const int32_t* pair_tab, void* W, void* scratch, const int32_t* skip_flag, int32_t* rot_count,
+                        hipStream_t stream) {
+  if (dtype == TTR_F32)
+    return eigh_pairs_typed<float>(b, npairs, items, (const float*)G, ldg, strideG, pair_tab, (float*)W, (float*)scratch,
+                                   skip_flag, rot_count, stream);
+  return eigh_pairs_typed<double>(b, npairs, items, (const double*)G, ldg, strideG, pair_tab, (double*)W, (double*)scratch,
+                                  skip_flag, rot_count, stream);
 }
 
 }  // namespace ttr

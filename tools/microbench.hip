@@ -126,8 +126,39 @@ static void run_mfma() {
   hipFree(out);
 }
 
+// the same for v_mfma_f64_16x16x4_f64: the fp64 matrix peak the fp64 configs (BASELINE C2) are priced against
+__global__ void mfma64_kernel(double* out, int iters) {
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  f64x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double x = threadIdx.x * 1e-3, y = 1.0 + x;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+
+static void run_mfma64() {
+  double* out;
+  hipMalloc(&out, sizeof(double) * 256 * 4096);
+  const int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma64_kernel, dim3(1024), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma64_kernel, dim3(1024), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double flops = 1024.0 * 4 * iters * 4 * 2048.0;
+  printf("{\"microbench\": \"v_mfma_f64_16x16x4_f64 x4 back to back, 4 waves/SIMD\", \"ms\": %.3f, \"tflops\": %.1f}\n", ms, flops / ms / 1e9);
+  hipFree(out);
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && argv[1][0] == 'm') { run_mfma(); return 0; }
+  if (argc > 1 && argv[1][0] == 'd') { run_mfma64(); return 0; }
   run<0>("v_fma_f32 x8 independent", 8);
   run<1>("v_pk_fma_f32 x4 independent", 4);
   run<2>("v_mov_dpp row_newbcast x8", 8);
