@@ -380,6 +380,13 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *   TTR_KNOB_QR_PANEL  1 = the 8-wave QR blocks factor / apply their panel columns in pairs (two reflectors per step,
  *                      v_permlane-swap reductions; default), 0 = one reflector at a time (round-1 kernel). */
 #define TTR_KNOB_QR_PANEL 0
+/*   TTR_KNOB_BJ_INNER_SWEEPS  cyclic sweeps ttr_bj_solve spends on every pair problem (0 = until the pair problem has
+ *                      converged; default 2: the outer iteration converges with inexact inner solves -- W is a product of
+ *                      rotations either way -- and a round costs a fraction) */
+#define TTR_KNOB_BJ_INNER_SWEEPS 1
+/*   TTR_KNOB_GEMM_BIG  1 (default) = fp32 products with both output dimensions >= 128 run on the 128 x 128-tile kernel
+ *                      (symmetric products: upper-triangle tiles only); 0 = the 64 x 64-tile kernel everywhere (A/B runs) */
+#define TTR_KNOB_GEMM_BIG 2
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */

@@ -46,6 +46,56 @@ def test_gemm(dt, M, N, K, tA, tB, B):
     assert err < tol(dt, 3e-5 if K > 10000 else 5e-6, 1e-12), err
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB,B", [
+    (256, 384, 1000, True, False, 2),     # TN, both operands mn-contiguous (the Gram orientation of a tall unfolding)
+    (1024, 128, 512, False, False, 1),    # NN: M V1 (k-contiguous A, mn-contiguous B)
+    (128, 256, 260, False, True, 3),      # NT: both k-contiguous
+    (384, 128, 96, True, True, 1),        # TT
+    (132, 260, 68, False, False, 2),      # ragged tile edges (multiples of 4, not of 128)
+    (256, 256, 40000, True, False, 1),    # split-K with the XCD map (8 splits x 4 tiles)
+    (2048, 256, 256, False, False, 1),    # row panels on the XCD map (16 x 2 tiles)
+])
+def test_gemm_big_tiles(M, N, K, tA, tB, B):
+    """The 128 x 128-tile kernel (fp32, both output dimensions >= 128): every operand orientation, ragged edges, split-K,
+    both workgroup maps -- against float64 torch."""
+    h = _hip()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((B, K, M) if tA else (B, M, K), generator=g, dtype=torch.float64)
+    Bm = torch.randn((B, N, K) if tB else (B, K, N), generator=g, dtype=torch.float64)
+    ref = (A.transpose(1, 2) if tA else A) @ (Bm.transpose(1, 2) if tB else Bm)
+    out = h.gemm(A.float().cuda(), Bm.float().cuda(), transA=tA, transB=tB).cpu().double()
+    assert (out - ref).abs().max() / ref.abs().max() < (3e-5 if K > 10000 else 5e-6)
+    # epilogue scales and axpby on the big path
+    rs = torch.rand(B, M, generator=g, dtype=torch.float64) + 0.5
+    cs = torch.rand(B, N, generator=g, dtype=torch.float64) + 0.5
+    out = h.gemm(A.float().cuda(), Bm.float().cuda(), transA=tA, transB=tB, rowscale=rs.float().cuda(), rowscale_mode=h.SCALE_DIV,
+                 colscale=cs.float().cuda(), colscale_mode=h.SCALE_MUL).cpu().double()
+    want = ref / rs[:, :, None] * cs[:, None, :]
+    assert (out - want).abs().max() / want.abs().max() < (3e-5 if K > 10000 else 5e-6)
+    C = torch.randn(B, M, N, generator=g, dtype=torch.float64)
+    Cd = C.float().cuda()
+    h.gemm_axpby(A.float().cuda(), Bm.float().cuda(), Cd, -0.5, 2.0, transA=tA, transB=tB)
+    want = 2.0 * C - 0.5 * ref
+    assert (Cd.cpu().double() - want).abs().max() / want.abs().max() < (3e-5 if K > 10000 else 5e-6)
+
+
+@pytest.mark.parametrize("rows,n,B,side", [(5000, 256, 2, "right"), (70000, 1024, 1, "right"), (300, 384, 3, "left"), (4096, 128, 4, "right")])
+def test_gemm_symmetric_products(rows, n, B, side):
+    """A^T A / A A^T with the SAME tensor on both sides run only the tiles on and above the diagonal (mirrored on output,
+    also through the split-K partials): equal to the float64 Gram matrix, exactly symmetric."""
+    h = _hip()
+    g = torch.Generator().manual_seed(rows + n)
+    A = torch.randn((B, rows, n) if side == "right" else (B, n, rows), generator=g, dtype=torch.float64)
+    Ad = A.float().cuda()
+    if side == "right":
+        out, ref = h.gemm(Ad, Ad, transA=True), A.transpose(1, 2) @ A
+    else:
+        out, ref = h.gemm(Ad, Ad, transB=True), A @ A.transpose(1, 2)
+    out = out.cpu().double()
+    assert (out - ref).abs().max() / ref.abs().max() < (3e-5 if rows > 10000 else 5e-6)
+    assert (out - out.transpose(1, 2)).abs().max() == 0
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_scales_and_views(dt):
     h = _hip()
@@ -235,7 +285,8 @@ def test_block_jacobi_device_loop_matches_host_loop(dt, relative, n, B):
     grow = max(1.0, (n / 512) ** 0.5)
     for on_dev, (V, d) in out.items():
         ds = d.sort(dim=1).values
-        assert ((ds - wref).abs().max(dim=1).values / wref[:, -1]).max() < grow * tol(dt, 4e-6, 1e-13), on_dev
+        # (relative mode returns diag(G) after all in-place updates, without the Rayleigh refinement: 3e-13 at n = 1024)
+        assert ((ds - wref).abs().max(dim=1).values / wref[:, -1]).max() < grow * tol(dt, 4e-6, 3e-13 if relative else 1e-13), on_dev
         assert (V.transpose(1, 2) @ V - torch.eye(n, dtype=torch.float64)).abs().max() < grow * tol(dt, 3e-5, 1e-12), on_dev
         resid = (G.cpu().double() @ V - V * d[:, None, :]).abs().max() / wref.max()
         assert resid < grow * tol(dt, 3e-5, 1e-12), on_dev

@@ -825,6 +825,8 @@ def core_kron(a: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
 
 
 KNOB_QR_PANEL = 0
+KNOB_BJ_INNER_SWEEPS = 1
+KNOB_GEMM_BIG = 2
 
 
 def set_knob(knob: int, value: int):

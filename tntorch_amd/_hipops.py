@@ -118,6 +118,7 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 # matrices) and the pair rotations are applied with the MFMA GEMM:  G <- W^T G W,  V <- V W.  Pairs are kept
 # physically adjacent by permuting the block order between rounds (gather copies -- layout only).
 _BJ_MAX_SWEEPS = 12
+_BJ_MAX_SWEEPS_DEVICE = 20   # (launches after convergence return at once: a generous bound is free)
 
 
 def _bj_block(n: int) -> Optional[int]:
@@ -171,7 +172,7 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
     if nbk % 2 == 0 and BLOCK_JACOBI_ON_DEVICE:
         # the whole sweep loop on the device: two launches per round, one control launch per sweep, no readback -- the
         # maximum number of sweeps is enqueued and everything after convergence returns at its first instruction
-        _hip.bj_sweeps(G, V, b, relative, 0.5 * math.sqrt(n) * torch.finfo(dt).eps, _BJ_MAX_SWEEPS)
+        _hip.bj_sweeps(G, V, b, relative, 0.5 * math.sqrt(n) * torch.finfo(dt).eps, _BJ_MAX_SWEEPS_DEVICE)
         return _bj_finish(G0, G, V, relative)
     circle = list(range(nbk)) + ([-1] if nbk % 2 else [])  # -1: bye
     phys = list(range(nbk))

@@ -289,6 +289,8 @@ int colproject_dispatch(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t 
 
 extern long long* g_qr_dbg;
 extern int g_qr_variant;
+extern int g_bj_inner_sweeps;
+extern int g_gemm_big;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -702,6 +704,14 @@ int ttr_debug_set_qr_stamps(void* device_buffer) {
 
 int ttr_debug_set_knob(int knob, int value) {
   switch (knob) {
+    case TTR_KNOB_GEMM_BIG:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: big-tile GEMM switch %d outside [0, 1]", value);
+      g_gemm_big = value;
+      return TTR_OK;
+    case TTR_KNOB_BJ_INNER_SWEEPS:
+      TTR_REQUIRE(value >= 0 && value <= 64, TTR_E_INVALID, "ttr_debug_set_knob: %d inner sweeps outside [0, 64]", value);
+      g_bj_inner_sweeps = value;
+      return TTR_OK;
     case TTR_KNOB_QR_PANEL:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: QR panel variant %d outside [0, 1]", value);
       g_qr_variant = value;

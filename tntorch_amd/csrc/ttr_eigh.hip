@@ -1064,6 +1064,8 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
 }
 
+int g_bj_inner_sweeps = 2;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS)
+
 // Pair problems of one block-Jacobi round (ttr_bj_solve): `items * npairs` LDS-resident Jacobi problems of size w = 2 b <= 64
 // gathered from the items' n x n matrices through the device pair table; eigenvectors with the diagonal-matched column
 // order (W -> I as the pair block -> diagonal), W[(item * npairs + pair)] = w x w contiguous.  `scratch`: w + 1 elements per
@@ -1080,7 +1082,7 @@ static int eigh_pairs_typed(int64_t b, int64_t npairs, int64_t items, const T* G
   p.sigma = scratch; p.stride_sigma = w;
   p.info = reinterpret_cast<int32_t*>(scratch + nprob * w);
   p.eig_mode = TTR_EIG_MATCH_DIAG; p.use_delta = 0; p.rmax = w;
-  p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
+  p.max_sweeps = g_bj_inner_sweeps > 0 ? g_bj_inner_sweeps : (sizeof(T) == 8 ? 40 : 30);
   p.abs_floor = TTR_SOLVER_JACOBI_ABS;
   p.pair_tab = pair_tab; p.pair_b = (int)b; p.pairs_per_item = (int)npairs;
   p.skip_flag = skip_flag; p.rot_count = rot_count;

@@ -186,6 +186,174 @@ __global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(GemmArgs<T> p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- compute-shaped products
+// fp32 products with BOTH output dimensions >= 128 -- the n = I r = 1024 Gram matrix, rotation and rotated Gram matrix of
+// the second step of a dense 64^k TT-SVD (BASELINE config C1: 3.5e13 flop, fp32-MFMA-bound), the n = 256 bonds
+// of config C3 -- are not HBM-bound, and the 64 x 64 tile above spends as long on its two barriers, sixteen dword loads
+// and LDS traffic per K step as on its 16 MFMAs per wave (measured ~60 TFLOP/s).  This kernel owns a 128 x 128 tile per
+// workgroup: every wave a 64 x 64 quadrant = 4 x 4 accumulators, 64 MFMAs (2048 cycles of matrix pipe) per K step of 16
+// against 4 sixteen-byte global loads per thread, staged through one LDS image per operand:
+//   k-contiguous operand  -> [mn][20]: 16-byte writes, and ONE 16-byte read hands a lane the four K steps of its fragment
+//                            (MFMA step s of lane group g consumes k = 4 g + s -- any bijection of the 16 k's onto
+//                            (step, group) is a valid K order as long as both operands use the same one)
+//   mn-contiguous operand -> [k][144]: 16-byte writes (512 contiguous bytes per 32 lanes from HBM), b32 fragment reads
+// Symmetric products (A^T A, A A^T: `sym`) only run the tiles on and above the diagonal and mirror them on output.
+// Workgroup -> (tile, split) map: the dispatcher places consecutive workgroups on consecutive XCDs (observed, used for
+// speed only), so the workgroups that read the same operand rows at the same time -- all tiles of one K split, or the
+// column tiles of one row panel -- are given ids that are congruent modulo 8 and adjacent: their common operand is
+// fetched from HBM once per XCD and served from that XCD's L2 to the others.
+constexpr int GBT = 128;   // tile edge
+constexpr int GLDK = 20;   // [mn][k] image: 16 k + 4 pad
+constexpr int GLDM = 144;  // [k][mn] image: 128 mn + 16 pad
+
+struct BigMap {
+  int inner, outer;  // ids: j = L / 8, in = j % inner, o = (j / inner) * 8 + L % 8 (workgroups with o >= outer exit)
+  int split_mode;    // 1: in = tile, o = K split;  0: in = column tile, o = row tile
+  int sym, tiles1d;  // sym: tile list = upper triangle of a tiles1d x tiles1d grid
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(kThreads, 2) void gemm_big_kernel(GemmArgs<float> p, BigMap mp) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float As[AKC ? GBT * GLDK : BK * GLDM];
+  __shared__ __attribute__((aligned(16))) float Bs[BKC ? GBT * GLDK : BK * GLDM];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cl = lane & 15, g = lane >> 4;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int64_t b = blockIdx.z;
+  const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+  const int in = jj % mp.inner, o = (jj / mp.inner) * 8 + xcd;
+  if (o >= mp.outer) return;
+  int tile, split;
+  if (mp.split_mode) { tile = in; split = o; } else { tile = o * mp.inner + in; split = 0; }
+  int tmi, tni;
+  if (mp.sym) {
+    int t = mp.split_mode ? tile : in + o * mp.inner;
+    tmi = 0;
+    while (t >= mp.tiles1d - tmi) { t -= mp.tiles1d - tmi; ++tmi; }
+    tni = tmi + t;
+  } else if (mp.split_mode) {
+    tmi = tile / p.tilesN; tni = tile % p.tilesN;
+  } else {
+    tmi = o; tni = in;
+  }
+  const int64_t m0 = (int64_t)tmi * GBT, n0 = (int64_t)tni * GBT;
+  const int64_t k_begin = (int64_t)split * p.k_chunk;
+  const int64_t k_end = (k_begin + p.k_chunk < p.K) ? (k_begin + p.k_chunk) : p.K;
+  const float* __restrict__ A = p.A + b * p.strideA;
+  const float* __restrict__ B = p.B + b * p.strideB;
+
+  // staging: two 16-byte pieces per operand and thread (all extents / leading dimensions are multiples of 4: a piece is
+  // either entirely inside the matrix or entirely outside)
+  int64_t aoff[2], boff[2];
+  bool aok[2], bok[2];
+  int akq[2], bkq[2], alds[2], blds[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int f = tid + kThreads * e;
+    if (AKC) { const int i = f >> 2, kq = f & 3; aoff[e] = (m0 + i) * p.a_rs + 4 * kq; aok[e] = m0 + i < p.M; akq[e] = 4 * kq; alds[e] = i * GLDK + 4 * kq; }
+    else { const int iq = f & 31, kk = f >> 5; aoff[e] = (int64_t)kk * p.a_cs + m0 + 4 * iq; aok[e] = m0 + 4 * iq < p.M; akq[e] = kk; alds[e] = kk * GLDM + 4 * iq; }
+    if (BKC) { const int i = f >> 2, kq = f & 3; boff[e] = (n0 + i) * p.b_cs + 4 * kq; bok[e] = n0 + i < p.N; bkq[e] = 4 * kq; blds[e] = i * GLDK + 4 * kq; }
+    else { const int iq = f & 31, kk = f >> 5; boff[e] = (int64_t)kk * p.b_rs + n0 + 4 * iq; bok[e] = n0 + 4 * iq < p.N; bkq[e] = kk; blds[e] = kk * GLDM + 4 * iq; }
+  }
+  const int64_t astep = AKC ? 1 : p.a_cs, bstep = BKC ? 1 : p.b_rs;  // element stride of one k
+  f4 ra[2], rb[2];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ra[e] = (aok[e] && k0 + akq[e] < k_end) ? *reinterpret_cast<const f4*>(A + aoff[e] + k0 * astep) : f4{0.f, 0.f, 0.f, 0.f};
+      rb[e] = (bok[e] && k0 + bkq[e] < k_end) ? *reinterpret_cast<const f4*>(B + boff[e] + k0 * bstep) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (k_begin < k_end) fetch(k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      *reinterpret_cast<f4*>(&As[alds[e]]) = ra[e];
+      *reinterpret_cast<f4*>(&Bs[blds[e]]) = rb[e];
+    }
+    __syncthreads();
+    if (k0 + BK < k_end) fetch(k0 + BK);  // in flight under the 64 MFMAs below
+    f4 af[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = 64 * wm + 16 * t + cl;
+      if (AKC) af[t] = *reinterpret_cast<const f4*>(&As[row * GLDK + 4 * g]);
+      else af[t] = f4{As[(4 * g + 0) * GLDM + row], As[(4 * g + 1) * GLDM + row], As[(4 * g + 2) * GLDM + row], As[(4 * g + 3) * GLDM + row]};
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int col = 64 * wn + 16 * tn + cl;
+      f4 bf;
+      if (BKC) bf = *reinterpret_cast<const f4*>(&Bs[col * GLDK + 4 * g]);
+      else bf = f4{Bs[(4 * g + 0) * GLDM + col], Bs[(4 * g + 1) * GLDM + col], Bs[(4 * g + 2) * GLDM + col], Bs[(4 * g + 3) * GLDM + col]};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][s4], bf[s4], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool direct = (p.nsplit == 1);
+  float* __restrict__ C = direct ? (p.C + b * p.strideC) : (p.part + ((int64_t)split * p.batch + b) * p.M * p.N);
+  const int64_t ldc = direct ? p.ldc : p.N;
+  const bool mirror = mp.sym && tmi != tni;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + 64 * wm + 16 * i + 4 * g + r;
+        const int64_t col = n0 + 64 * wn + 16 * j + cl;
+        if (row < p.M && col < p.N) {
+          float v = acc[i][j][r], vt = v;
+          if (direct) {
+            v = apply_scale(v, p.rs ? p.rs + b * p.stride_rs : nullptr, row, p.rs ? p.rs_mode : TTR_SCALE_NONE);
+            v = apply_scale(v, p.cs ? p.cs + b * p.stride_cs : nullptr, col, p.cs ? p.cs_mode : TTR_SCALE_NONE);
+            if (p.axpby) v = p.alpha * v + (p.beta != 0.f ? p.beta * C[row * ldc + col] : 0.f);
+          }
+          C[row * ldc + col] = v;
+          if (mirror) {  // (symmetric products are only dispatched here without scales / axpby)
+            C[col * ldc + row] = vt;
+          }
+        }
+      }
+}
+
+// Plan of the big-tile path for a product shape; nsplit is what gemm_workspace_bytes and the dispatch must agree on.
+struct BigPlan {
+  bool use;
+  int64_t tilesM, tilesN;
+  int nsplit;
+};
+int g_gemm_big = 1;  // ttr_debug_set_knob(TTR_KNOB_GEMM_BIG)
+
+static BigPlan big_plan(int dtype, int64_t M, int64_t N, int64_t K, int64_t batch, bool sym) {
+  BigPlan pl{false, 0, 0, 1};
+  if (!g_gemm_big || dtype != TTR_F32 || M < GBT || N < GBT || K < 64) return pl;
+  if ((M | N | K) & 3) return pl;
+  pl.use = true;
+  pl.tilesM = ceil_div(M, GBT); pl.tilesN = ceil_div(N, GBT);
+  const int64_t tiles = sym ? pl.tilesM * (pl.tilesM + 1) / 2 : pl.tilesM * pl.tilesN;
+  const int64_t wgs = tiles * batch;
+  if (wgs < 768 && K >= 4096) {  // too few tiles for 256 CUs x 3-4 workgroups: split K (multiples of 8: one split per XCD id)
+    int64_t s = align_up(ceil_div(1024, wgs), 8);
+    const int64_t maxs = K / 1024;
+    if (s > maxs) s = maxs / 8 * 8;
+    if (s > 256) s = 256;
+    pl.nsplit = (int)(s < 8 ? 1 : s);
+  }
+  return pl;
+}
+
 // Split only when the plain launch would leave most of the 256 CUs idle and K is long.
 static int pick_nsplit(int64_t tiles, int64_t batch, int64_t K) {
   const int64_t wgs = tiles * batch;
@@ -226,6 +394,44 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   p.rs = (const T*)rs; p.stride_rs = stride_rs; p.rs_mode = rs_mode;
   p.cs = (const T*)cs; p.stride_cs = stride_cs; p.cs_mode = cs_mode;
   p.batch = batch;
+  if constexpr (sizeof(T) == 4) {
+    // symmetric product: the same matrix on both sides, transposed on exactly one (A^T A or A A^T), no epilogue
+    const bool sym = A == B && lda == ldb && strideA == strideB && transA != transB && M == N && !rs && !cs && !axpby;
+    const BigPlan pl = big_plan(TTR_F32, M, N, K, batch, sym);
+    const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
+                         strideA % 4 == 0 && strideB % 4 == 0;
+    if (pl.use && aligned && batch <= 65535) {
+      int nsplit = pl.nsplit;
+      if (nsplit > 1 && (!ws || ws_bytes < (int64_t)nsplit * batch * M * N * 4)) nsplit = 1;
+      p.nsplit = nsplit;
+      p.k_chunk = nsplit == 1 ? align_up(K, BK) : align_up(ceil_div(K, nsplit), BK);
+      p.part = (T*)ws;
+      p.tilesN = (int)pl.tilesN;
+      BigMap mp;
+      mp.sym = sym ? 1 : 0; mp.tiles1d = (int)pl.tilesM;
+      const int64_t tiles = sym ? pl.tilesM * (pl.tilesM + 1) / 2 : pl.tilesM * pl.tilesN;
+      mp.split_mode = (nsplit > 1 || sym) ? 1 : 0;
+      if (mp.split_mode) { mp.inner = (int)tiles; mp.outer = nsplit; }
+      else { mp.inner = (int)pl.tilesN; mp.outer = (int)pl.tilesM; }
+      const int64_t blocks = (int64_t)mp.inner * align_up(mp.outer, 8);
+      TTR_REQUIRE(blocks <= 2147483647LL, TTR_E_UNSUPPORTED, "ttr_gemm: too many tiles");
+      const dim3 grid((unsigned)blocks, 1, (unsigned)batch);
+      const bool akc = p.a_cs == 1, bkc = p.b_rs == 1;
+      ProfScope prof(TTR_PROF_GEMM, stream);
+      const GemmArgs<float>& pf = reinterpret_cast<const GemmArgs<float>&>(p);
+      if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<true, true>), grid, dim3(kThreads), 0, stream, pf, mp);
+      else if (akc) hipLaunchKernelGGL((gemm_big_kernel<true, false>), grid, dim3(kThreads), 0, stream, pf, mp);
+      else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<false, true>), grid, dim3(kThreads), 0, stream, pf, mp);
+      else hipLaunchKernelGGL((gemm_big_kernel<false, false>), grid, dim3(kThreads), 0, stream, pf, mp);
+      if (nsplit > 1) {
+        int64_t gx = ceil_div(M * N, kThreads);
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, stream, p);
+      }
+      TTR_HIP_CHECK(hipGetLastError());
+      return TTR_OK;
+    }
+  }
   const int shape = pick_shape(M, N);
   int64_t BM, BN;
   tile_dims(shape, BM, BN);
@@ -264,7 +470,11 @@ int64_t gemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int64_t
   int64_t BM, BN;
   tile_dims(pick_shape(M, N), BM, BN);
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  const int ns = pick_nsplit(tiles, batch, K);
+  int ns = pick_nsplit(tiles, batch, K);
+  // the big-tile path decides its own split count; symmetric products (fewer tiles) may split further than general ones
+  const int nb = big_plan(dtype, M, N, K, batch, false).nsplit, nbs = M == N ? big_plan(dtype, M, N, K, batch, true).nsplit : 1;
+  if (nb > ns) ns = nb;
+  if (nbs > ns) ns = nbs;
   if (ns == 1) return 0;
   return (int64_t)ns * batch * M * N * (dtype == TTR_F64 ? 8 : 4);
 }
