@@ -284,6 +284,12 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch,
                    const void* in, int64_t ldi, int64_t stride_in,
                    const void* s, int64_t stride_s, int mode,
                    void* out, int64_t ldo, int64_t stride_out, void* stream);
+/* x[b][:, j] <- 0 for j >= keep[b], in place (keep: device int32 [batch], e.g. ttr_eigh_trunc's info).  The device-side
+ * form of `left = vectors[..., :rank]` (round.py:160-161) for a sweep that computes every bond at its rank cap and reads the
+ * selected ranks back once, at the end (at most one host synchronisation per round_tt). */
+int ttr_mask_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, void* x, int64_t ldx, int64_t stride_x,
+                  const int32_t* keep, void* stream);
+
 
 /*
  * Fused kernels of the right-to-left truncation sweep: the (R <= 64) x n right unfolding M of a core is streamed once,
@@ -387,6 +393,11 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
 /*   TTR_KNOB_GEMM_BIG  1 (default) = fp32 products with both output dimensions >= 128 run on the 128 x 128-tile kernel
  *                      (symmetric products: upper-triangle tiles only); 0 = the 64 x 64-tile kernel everywhere (A/B runs) */
 #define TTR_KNOB_GEMM_BIG 2
+/*   TTR_KNOB_QR_STAMP_BX / _BY  which level-0 block of ttr_qr_factor* writes the cycle stamps of ttr_debug_set_qr_stamps
+ *                      (block index within the matrix / batch item; default (0, 0), which starts with the first wave of
+ *                      workgroups -- a block in the middle of the grid shows the steady state) */
+#define TTR_KNOB_QR_STAMP_BX 3
+#define TTR_KNOB_QR_STAMP_BY 4
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */

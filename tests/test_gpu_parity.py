@@ -1062,10 +1062,12 @@ def test_c4_proxy_cp_als_r32_vs_oracle(kind):
     """BASELINE config C4's path at a size the oracle finishes in seconds: CP-ALS R = 32 on a dense 48^4 fp32 tensor, a
     fixed 5 sweeps (tol < 0 never stops, tensor.py:380-381).  R = 32 takes the 128x32-tile / split-K GEMMs and
     `ttr_krp_contract` with the shapes of the 256^4 config (R <= 5 in the golden cases does not).  Against
-    `oracle.cp_als` (tensor.py:210-400 restated, same precision): the error after EVERY sweep agrees to 2e-4 absolute on the
-    low-rank + noise input, whose error still falls by ~0.1 per sweep (the fp32 oracle's own trajectory is 6e-5 away from
-    the fp64 oracle's after 5 sweeps, measured), 1e-5 on `randn` (ours: the algebraic estimate of the sweep; oracle: dense
-    reconstruction), and so does the true error of the final factors."""
+    `oracle.cp_als` (tensor.py:210-400 restated) run in FLOAT64 on the same fp32 data: the error after EVERY sweep agrees to
+    3e-4 absolute on the low-rank + noise input, 1e-5 on `randn` (ours: the algebraic estimate of the sweep; oracle: dense
+    reconstruction), and so does the true error of the final factors.  Why fp64 as the yardstick: the input's
+    Hadamard-of-Grams matrices reach condition 2e6 while the error still falls by ~0.1 per sweep, and the reference's own
+    fp32 trajectory (lstsq) then depends on the host -- 0.316288 in the build container, 0.316509 on the GPU box's CPU after
+    five sweeps, against 0.316341 in fp64 (measured); the device solves the R x R systems in fp64 for that reason."""
     torch.manual_seed(17)
     shape, R = [48] * 4, 32
     if kind == "lowrank":
@@ -1074,10 +1076,10 @@ def test_c4_proxy_cp_als_r32_vs_oracle(kind):
         X = (X / X.norm() * math.sqrt(X.numel()) + 1e-2 * torch.randn(shape, dtype=torch.float64)).float()
     else:
         X = torch.randn(shape, dtype=torch.float32)
-    ref_cores, ref_err = oracle.cp_als(X, R, max_iter=5, tol=-1.0)
+    ref_cores, ref_err = oracle.cp_als(X.double(), R, max_iter=5, tol=-1.0)
     t = tn.Tensor(X.cuda(), ranks_cp=R, max_iter=5, tol=-1.0)
     assert len(t.cp_errors) == len(ref_err) == 5
-    tol = 2e-4 if kind == "lowrank" else 1e-5
+    tol = 3e-4 if kind == "lowrank" else 1e-5
     for k, (a, b) in enumerate(zip(t.cp_errors, ref_err)):
         assert abs(float(a) - float(b)) <= tol, (kind, k, float(a), float(b))
     e_o = rel_diff(oracle.cp_to_dense([c.cpu().double() for c in t.cores]), X.double())
@@ -1129,3 +1131,42 @@ def test_zero_item_inside_batch(dt):
     tol = 2e-5 if dt == torch.float32 else 1e-10
     for i in (0, 1, 3):  # (dense comparison: the inner-product formula of tt_rel_err resolves 1e-8 at best)
         assert rel_diff(dense([c[i] for c in ours]), dense([c[i] for c in ref])) <= tol
+
+
+@pytest.mark.parametrize("dt,eps", [(torch.float32, 1e-3), (torch.float64, 1e-6), (torch.float64, 1e-14)])
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_eps_mode_without_rank_readbacks(dt, eps, alg, monkeypatch):
+    """at most ONE host synchronisation per round_tt in eps mode.  The deferred sweep (rank rule bound on the
+    device, every bond computed at its rank cap and masked there, one readback of all ranks at the end) against the
+    round-2 sweep that reads one rank back per bond: identical ranks and the same train, on a decaying-spectrum input
+    (data-dependent ranks that differ from bond to bond), with and without an rmax cap, and on an all-zero train."""
+    inp = _decaying_tt([12, 10, 9, 11, 8, 16], 14, 0.6, dt, seed=3)   # (every bond: rows <= columns, the fused kernels' side)
+    from tntorch_amd import _hipops
+    calls = []
+    orig = _hipops._eps_deferred_ok
+    monkeypatch.setattr(_hipops, "_eps_deferred_ok", lambda *a: calls.append(orig(*a)) or calls[-1])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TTR_EPS_DEFERRED", mode)
+        res = []
+        for rmax in (None, 6):
+            t = gpu_tensor(inp)
+            t.round_tt(eps=eps, rmax=rmax, algorithm=alg)
+            res.append(to_list(t.cores))
+        z = gpu_tensor([torch.zeros_like(c) for c in inp])
+        z.round_tt(eps=eps, algorithm=alg)
+        res.append(to_list(z.cores))
+        out[mode] = res
+    assert calls == [True] * 3 + [False] * 3                                             # both sweeps really ran
+    for a, b in zip(out["1"], out["0"]):
+        assert ranks(a) == ranks(b)
+        assert all(x.is_contiguous() for x in a)
+    assert len(set(ranks(out["1"][0])[1:-1])) > 1 and max(ranks(out["1"][1])) <= 6      # data-dependent ranks, capped ranks
+    assert ranks(out["1"][2]) == [1] * 7 and all((c == 0).all() for c in out["1"][2])   # zero guard: rank-1 zeros
+    tol = 2e-5 if dt == torch.float32 else 1e-10
+    for a, b in zip(out["1"][:2], out["0"][:2]):
+        assert rel_diff(dense(a), dense(b)) <= tol
+    ref = oracle.round_tt([c.clone() for c in inp], eps=eps, algorithm=alg)
+    if alg == "svd" or eps > 1e-10:   # ('eig' at eps = 1e-14 sits on the Gram noise floor: ranks not asserted, tests/test_round.py:52-59)
+        assert all(abs(x - y) <= 1 for x, y in zip(ranks(out["1"][0]), ranks(ref)))
+    assert rel_diff(dense(out["1"][0]), dense(ref)) <= max(3 * eps, tol)

@@ -140,6 +140,7 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
          c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "ttr_mask_cols": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ttr_krp_contract": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_hadamard": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_core_kron": (c_int, [c_int] + [c_int64] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -604,6 +605,16 @@ def scale_cols(X: torch.Tensor, s: torch.Tensor, mode: int) -> torch.Tensor:
     return out
 
 
+@_on_device
+def mask_cols(X: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    """In place: X[b, :, j] = 0 for j >= keep[b] (keep: int32 [batch] on the device)."""
+    X3, ldx, sX = _mat(X)
+    assert X3.data_ptr() == X.data_ptr() and keep.dtype == torch.int32 and keep.shape[0] == X.shape[0]
+    _check(lib().ttr_mask_cols(dtype_code(X.dtype), X.shape[1], X.shape[2], X.shape[0], X.data_ptr(), ldx, sX, keep.data_ptr(),
+                               _stream()), "ttr_mask_cols")
+    return X
+
+
 def sweep_fused_ok(M: torch.Tensor) -> bool:
     """The fused row-Gram / rotate-Gram / projection kernels hold up to 64 rows."""
     return M.shape[1] <= 64
@@ -827,6 +838,7 @@ def core_kron(a: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
 KNOB_QR_PANEL = 0
 KNOB_BJ_INNER_SWEEPS = 1
 KNOB_GEMM_BIG = 2
+KNOB_QR_STAMP_BX, KNOB_QR_STAMP_BY = 3, 4
 
 
 def set_knob(knob: int, value: int):

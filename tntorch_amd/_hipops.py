@@ -329,6 +329,7 @@ def truncate(
     right_alloc=None,
     scratch_ok: bool = False,
     gram: Optional[torch.Tensor] = None,
+    delta2_dev: Optional[torch.Tensor] = None,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
@@ -336,6 +337,10 @@ def truncate(
     more than 64 columns is then rotated IN PLACE (row chunks) instead of into a second tensor of its size.
     ``gram``: split partials of M M^T already accumulated by the kernel that produced M (``qr_apply(want_gram=True)``);
     saves the first of the three passes over M.
+    ``delta2_dev`` (device double [1], fused <= 64-row path only): eps mode WITHOUT a readback -- the rank rule takes its bound
+    from device memory, the factors are computed at the rank cap ``min(rmax, k)``, the selected rank stays on the device
+    (``Truncation.info``) and the columns of ``left`` beyond it are zeroed there (``ttr_mask_cols``): the caller slices the
+    cores once, at the end of its sweep, after ONE readback of all ranks.
 
     ``left_ortho=False`` (the branch round_tt uses): ``right`` has orthonormal rows,
     ``left * colscale`` carries the singular values.  ``left_ortho=True``: ``left`` is
@@ -359,10 +364,17 @@ def truncate(
         if algorithm == "svd":
             V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
-                                           abs_floor=_hip.SOLVER_JACOBI_LIVE)
+                                           abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev)
         else:
             V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF, use_delta, delta2, cap,
-                                           abs_floor=_hip.SOLVER_TRIDIAG)
+                                           abs_floor=_hip.SOLVER_TRIDIAG, delta2_dev=delta2_dev)
+        if delta2_dev is not None:  # rank on the device: factors at the cap, the columns beyond info[b] zeroed in place
+            r = _rank_cap(rmax, k)
+            right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho)
+            if algorithm == "svd" and not left_ortho:
+                _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)
+            _hip.mask_cols(left, info)
+            return Truncation(left, None, right, r, info=info)
         r = _select_rank(info, batch, rmax, k)
         if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
@@ -859,8 +871,14 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
     if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
         c[N - 1], _ = _hip.pow2_normalize(c[N - 1], expo_acc=expo)
+    d2dev, infos = None, []
     if batch:  # tensor.py:2036-2037
         delta = None
+    elif _eps_deferred_ok(c, facs, rmax):
+        # tensor.py:2039-2051 without the `.item()`: delta^2 = (eps / max(1, sqrt(N - 1)))^2 ||last core||^2 stays on the
+        # device (three scalar ops), every bond is enqueued at its rank cap, ONE readback of the N - 1 ranks at the end
+        delta = 0.0
+        d2dev = _hip.norm(c[-1].reshape(1, -1)).double().square_().mul_((eps / max(1.0, math.sqrt(N - 1))) ** 2)
     else:  # tensor.py:2039-2051
         nrm = float(_hip.norm(c[-1].reshape(1, -1))[0].item())
         delta = eps / max(1.0, math.sqrt(N - 1)) * nrm
@@ -881,7 +899,9 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
         if arena is not None:
             def alloc(r, mu=mu, n=I * rn):
                 return arena.slice(mu, chunk, (r, n))
-        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram)
+        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram, delta2_dev=d2dev)
+        if d2dev is not None:
+            infos.append(t.info)
         if zflags is not None and mu == N - 1 and t.info is not None:
             zflags.append(_deferred_readback(t.info.amax()))  # ([B] int32 -> one scalar: control flow only)
         right = t.right
@@ -899,7 +919,44 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
     if arena is not None:
         dst = arena.slice(0, chunk, (r0 * I, left.shape[2]))
     c[0] = _apply_q(f, left, dst).reshape(f.batch, r0, I, left.shape[2])
+    if d2dev is not None:
+        # the ONE host synchronisation of the sweep: the selected ranks (bond N-1 first), then the cores -- computed at their
+        # caps, zero beyond the selected ranks -- are cut to size (layout copies)
+        ranks = torch.cat(infos).tolist()[::-1]          # ranks[mu - 1] = rank of bond mu
+        if min(ranks) == 0:  # zero guard (round.py:137-145): the carry was zero from the first bond on
+            return [torch.zeros((1, c[0].shape[1] if mu == 0 else 1, c[mu].shape[2], c[N - 1].shape[3] if mu == N - 1 else 1),
+                                dtype=c[0].dtype, device=c[0].device) for mu in range(N)]
+        bond = [c[0].shape[1]] + ranks + [c[N - 1].shape[3]]
+        c = [x[:, :bond[mu], :, :bond[mu + 1]].contiguous() for mu, x in enumerate(c)]
     return c
+
+
+_EPS_DEFERRED_MAX_ELEMS = 1 << 24   # eps-mode sweeps of trains up to this many core elements keep the ranks on the device
+
+
+def _eps_deferred_ok(c, facs, rmax) -> bool:
+    """Non-batch (eps-mode) sweep: can every bond be enqueued without reading its rank back?  Only worth it where the
+    host synchronisations dominate (a small train: every kernel is latency-bound and the factors are computed at the rank
+    cap, i.e. possibly wider than needed), and only on the fused <= 64-row truncation kernels."""
+    mode = os.environ.get("TTR_EPS_DEFERRED", "auto")
+    if mode == "0":
+        return False
+    N = len(c)
+    last = c[N - 1]
+    if last.shape[0] != 1 or any(isinstance(f[0], _ExplicitQ) for f in facs):
+        return False
+    elems = last.numel() + sum(f[0].m * f[0].n for f in facs)
+    if mode != "1" and elems > _EPS_DEFERRED_MAX_ELEMS:
+        return False
+    rn = last.shape[3]
+    for mu in range(N - 1, 0, -1):
+        m = last.shape[1] if mu == N - 1 else facs[mu][1]
+        I = last.shape[2] if mu == N - 1 else facs[mu][2]
+        n = I * rn
+        if m > 64 or m > n:
+            return False
+        rn = _rank_cap(rmax[mu - 1], min(m, n))
+    return True
 
 
 def round_tucker(cores4: Sequence[torch.Tensor], Us, eps, rmax, ndims, algorithm, batch):

@@ -120,6 +120,21 @@ __global__ __launch_bounds__(kThreads) void scale_cols_kernel(int64_t rows, int6
   }
 }
 
+// x[b][:, j] <- 0 for j >= keep[b] (in place): the device-side truncation of an eps-mode sweep that computes every bond at
+// its rank CAP and never reads the selected rank back (keep = the eigensolver's info[b]; 0 = zero guard: everything goes)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mask_cols_kernel(int64_t rows, int64_t cols, T* __restrict__ x, int64_t ldx,
+                                                             int64_t stride_x, const int32_t* __restrict__ keep) {
+  const int64_t b = blockIdx.y;
+  const int64_t k = keep[b];
+  if (k >= cols) return;
+  const int64_t w = cols - k, total = rows * w;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = idx / w, j = k + idx % w;
+    x[b * stride_x + i * ldx + j] = T(0);
+  }
+}
+
 // Block-wide sum of doubles (256 threads), result in every thread.
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -291,6 +306,7 @@ extern long long* g_qr_dbg;
 extern int g_qr_variant;
 extern int g_bj_inner_sweeps;
 extern int g_gemm_big;
+extern int g_qr_dbg_bx, g_qr_dbg_by;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -539,6 +555,26 @@ int ttr_scale_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, const v
   return TTR_OK;
 }
 
+int ttr_mask_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, void* x, int64_t ldx, int64_t stride_x,
+                  const int32_t* keep, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_mask_cols: bad dtype %d", dtype);
+  if (rows <= 0 || cols <= 0 || batch <= 0) return TTR_OK;
+  TTR_REQUIRE(x && keep, TTR_E_INVALID, "ttr_mask_cols: null pointer");
+  TTR_REQUIRE(batch <= 65535, TTR_E_UNSUPPORTED, "ttr_mask_cols: batch %lld > 65535", (long long)batch);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t gx = ceil_div(rows * cols, kThreads);
+  if (gx > 1024) gx = 1024;
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(mask_cols_kernel<float>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, s, rows, cols, (float*)x,
+                       ldx, stride_x, keep);
+  else
+    hipLaunchKernelGGL(mask_cols_kernel<double>, dim3((unsigned)gx, (unsigned)batch), dim3(kThreads), 0, s, rows, cols,
+                       (double*)x, ldx, stride_x, keep);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
 int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch) {
   if (n <= 0 || batch <= 0) return 1;
   return sweep_gram_parts(n, batch);
@@ -704,6 +740,12 @@ int ttr_debug_set_qr_stamps(void* device_buffer) {
 
 int ttr_debug_set_knob(int knob, int value) {
   switch (knob) {
+    case TTR_KNOB_QR_STAMP_BX:
+      g_qr_dbg_bx = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_STAMP_BY:
+      g_qr_dbg_by = value;
+      return TTR_OK;
     case TTR_KNOB_GEMM_BIG:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: big-tile GEMM switch %d outside [0, 1]", value);
       g_gemm_big = value;

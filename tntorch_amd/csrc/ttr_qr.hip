@@ -68,7 +68,8 @@ struct QrLevel {
   const T* Cn2;
   int64_t strideCn2;
   int sumRa, sumCa;
-  long long* dbg;      // optional: cycle stamps of block (0,0) at phase boundaries (diagnostics)
+  long long* dbg;      // optional: cycle stamps of block (dbg_bx, dbg_by) at phase boundaries (diagnostics)
+  int dbg_bx, dbg_by;
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
   int dbgi = 0;
-  auto stamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  auto stamp = [&]() { if (p.dbg && blockIdx.x == p.dbg_bx && blockIdx.y == p.dbg_by && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
   stamp();
   Acc acc[4][NT];
   if constexpr (PUSHED) {
@@ -1136,6 +1137,8 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 }
 
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
+int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_set_knob: a block in the middle of the grid shows the
+                                        // steady state -- block (0, 0) starts together with every other first-wave block)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
 struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
@@ -1156,6 +1159,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
   for (int l = 0; l < L; ++l) {
     QrLevel<T> p;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
+    p.dbg_bx = g_qr_dbg_bx; p.dbg_by = g_qr_dbg_by;
     p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
     p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
     p.Cn2 = (const T*)pu.Cn2; p.strideCn2 = pu.strideCn2; p.sumRa = pu.sumRa; p.sumCa = pu.sumCa;
