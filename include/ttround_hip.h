@@ -367,7 +367,10 @@ int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int6
  * O(dead_rel * sigma_0) only.  Items without such vectors exit immediately (the normal case).
  */
 int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
-                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, void* stream);
+                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
+                   void* stream);
+/* `rank_dev` (optional, device int32 [batch]): only the first min(r, rank_dev[b]) vectors of item b are looked at -- a sweep
+ * that computes its factors at the rank cap and cuts them to the selected rank later does not complete vectors it drops. */
 
 /* Per-kernel device timing (HIP events on `stream`), used by bench.py for the roofline line. */
 #define TTR_PROF_GEMM 0
@@ -387,7 +390,7 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      v_permlane-swap reductions; default), 0 = one reflector at a time (round-1 kernel). */
 #define TTR_KNOB_QR_PANEL 0
 /*   TTR_KNOB_BJ_INNER_SWEEPS  cyclic sweeps ttr_bj_solve spends on every pair problem (0 = until the pair problem has
- *                      converged; default 2: the outer iteration converges with inexact inner solves -- W is a product of
+ *                      converged; default 1: the outer iteration converges with inexact inner solves -- W is a product of
  *                      rotations either way -- and a round costs a fraction) */
 #define TTR_KNOB_BJ_INNER_SWEEPS 1
 /*   TTR_KNOB_GEMM_BIG  1 (default) = fp32 products with both output dimensions >= 128 run on the 128 x 128-tile kernel

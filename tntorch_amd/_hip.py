@@ -132,7 +132,7 @@ _SIGNATURES = {
     ),
     "ttr_orth_fixup": (
         c_int,
-        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p],
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p, c_void_p],
     ),
     "ttr_norm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_scale_cols": (
@@ -775,7 +775,8 @@ def scale_batch(x: torch.Tensor, scale=None, expo: Optional[torch.Tensor] = None
 
 
 @_on_device
-def orth_fixup(X: torch.Tensor, sigma: torch.Tensor, r: int, dead_rel: float, columns: bool = False) -> None:
+def orth_fixup(X: torch.Tensor, sigma: torch.Tensor, r: int, dead_rel: float, columns: bool = False,
+               rank_dev: Optional[torch.Tensor] = None) -> None:
     """In place: orthonormal completion of the kept vectors whose sigma <= dead_rel * sigma_max (ttr_orth_fixup).
     ``X``: contiguous [batch, r, n] (rows are the vectors) or, with ``columns=True``, [batch, n, r]."""
     L = lib()
@@ -791,7 +792,8 @@ def orth_fixup(X: torch.Tensor, sigma: torch.Tensor, r: int, dead_rel: float, co
     if batch == 0 or r == 0 or n == 0:
         return
     _check(L.ttr_orth_fixup(dt, r, n, batch, X.data_ptr(), vs, es, X.shape[1] * X.shape[2], sigma.data_ptr(),
-                            sigma.shape[-1], float(dead_rel), _stream()), "ttr_orth_fixup")
+                            sigma.shape[-1], float(dead_rel), rank_dev.data_ptr() if rank_dev is not None else None, _stream()),
+           "ttr_orth_fixup")
 
 
 @_on_device

@@ -372,7 +372,7 @@ def truncate(
             r = _rank_cap(rmax, k)
             right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho)
             if algorithm == "svd" and not left_ortho:
-                _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)
+                _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps, rank_dev=info)  # (not the rows that are cut away)
             _hip.mask_cols(left, info)
             return Truncation(left, None, right, r, info=info)
         r = _select_rank(info, batch, rmax, k)

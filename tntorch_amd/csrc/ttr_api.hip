@@ -190,9 +190,11 @@ __global__ __launch_bounds__(kThreads) void scale_batch_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(kThreads) void orth_fixup_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t es,
                                                               int64_t strideX, const T* __restrict__ sigma,
-                                                              int64_t stride_sigma, double dead_rel) {
+                                                              int64_t stride_sigma, double dead_rel,
+                                                              const int32_t* __restrict__ rank_dev) {
   __shared__ double red[kThreads / kWave];
   const int64_t b = blockIdx.x;
+  if (rank_dev) r = rank_dev[b] < r ? rank_dev[b] : r;  // vectors beyond the selected rank are cut away by the caller later
   const T* __restrict__ sg = sigma + b * stride_sigma;
   const double s0 = (double)sg[0];
   int first = r;
@@ -690,7 +692,8 @@ int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int6
 }
 
 int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
-                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, void* stream) {
+                   int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
+                   void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_orth_fixup: bad dtype %d", dtype);
   TTR_REQUIRE(r >= 0 && n >= 0 && batch >= 0 && r <= 2147483647LL, TTR_E_INVALID, "ttr_orth_fixup: bad sizes");
   if (batch == 0 || r == 0 || n == 0) return TTR_OK;
@@ -699,10 +702,10 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
   ProfScope prof(TTR_PROF_MISC, s);
   if (dtype == TTR_F32)
     hipLaunchKernelGGL(orth_fixup_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (float*)X,
-                       vec_stride, elem_stride, strideX, (const float*)sigma, stride_sigma, dead_rel);
+                       vec_stride, elem_stride, strideX, (const float*)sigma, stride_sigma, dead_rel, rank_dev);
   else
     hipLaunchKernelGGL(orth_fixup_kernel<double>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (double*)X,
-                       vec_stride, elem_stride, strideX, (const double*)sigma, stride_sigma, dead_rel);
+                       vec_stride, elem_stride, strideX, (const double*)sigma, stride_sigma, dead_rel, rank_dev);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }

@@ -1064,7 +1064,7 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
 }
 
-int g_bj_inner_sweeps = 2;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS)
+int g_bj_inner_sweeps = 1;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS); measured on C3's share: 1 -> 72 ms, 2 -> 82, 3 -> 90, until converged -> 97
 
 // Pair problems of one block-Jacobi round (ttr_bj_solve): `items * npairs` LDS-resident Jacobi problems of size w = 2 b <= 64
 // gathered from the items' n x n matrices through the device pair table; eigenvectors with the diagonal-matched column

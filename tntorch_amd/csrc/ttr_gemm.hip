@@ -344,12 +344,19 @@ static BigPlan big_plan(int dtype, int64_t M, int64_t N, int64_t K, int64_t batc
   pl.tilesM = ceil_div(M, GBT); pl.tilesN = ceil_div(N, GBT);
   const int64_t tiles = sym ? pl.tilesM * (pl.tilesM + 1) / 2 : pl.tilesM * pl.tilesN;
   const int64_t wgs = tiles * batch;
-  if (wgs < 768 && K >= 4096) {  // too few tiles for 256 CUs x 3-4 workgroups: split K (multiples of 8: one split per XCD id)
-    int64_t s = align_up(ceil_div(1024, wgs), 8);
-    const int64_t maxs = K / 1024;
-    if (s > maxs) s = maxs / 8 * 8;
-    if (s > 256) s = 256;
-    pl.nsplit = (int)(s < 8 ? 1 : s);
+  if (wgs < 768 && K >= 4096) {
+    // too few tiles for 256 CUs x 3 workgroups: split K, in multiples of 8 (one split per XCD id).  Among the candidates
+    // that leave >= 2048 rows per split, take the one that fills whole rounds of the chip's 768 workgroup slots best
+    // (36 symmetric tiles x 32 splits = 1.5 rounds ran at 75 % of the rate of x 64 = 3.0 rounds, measured)
+    const int64_t maxs = K / 2048 < 256 ? K / 2048 : 256;
+    int64_t best = 1;
+    double best_eff = 0.0;
+    for (int64_t s = 8; s <= maxs; s += 8) {
+      const int64_t w = wgs * s, rounds = ceil_div(w, 768);
+      const double eff = (double)w / (double)(rounds * 768);
+      if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    pl.nsplit = (int)best;
   }
   return pl;
 }

@@ -49,6 +49,19 @@ def _timeit(fn, reps, warmup=1):
     return ts[len(ts) // 2], ts, r
 
 
+def _kinds(fn):
+    """Per-kind kernel time of ONE extra (untimed) repetition: HIP events around every launch inside the library."""
+    from tntorch_amd import _hip
+
+    torch.cuda.synchronize()
+    _hip.prof_enable(True)
+    fn()
+    torch.cuda.synchronize()
+    prof = _hip.prof_collect()
+    _hip.prof_enable(False)
+    return {k: {"ms": round(v["ms"], 3), "launches": int(v["launches"])} for k, v in prof.items() if v["launches"]}
+
+
 def _cpu_time(fn, threads=(8,), reps=2, budget_s=12.0):
     """Median seconds of `fn` on the host cores, best over a few MKL thread counts, bounded by `budget_s`."""
     saved = torch.get_num_threads()
@@ -134,7 +147,8 @@ def c2(tn, dev, algorithm="svd", cpu=True):
     secB, allB, outB = _timeit(lambda: tn.round_tt(tb, rmax=r, algorithm=algorithm), reps=3, warmup=1)
     res["batch_256"] = {"ms": secB * 1e3, "ms_all": [round(x * 1e3, 2) for x in allB], "tensors": B,
                         "ranks": outB.ranks_tt.tolist(), "cores_per_s": B * N / secB,
-                        "roofline": _roof("mfma_f64", flop * B, byts * B, secB)}
+                        "roofline": _roof("mfma_f64", flop * B, byts * B, secB),
+                        "kernel_ms": _kinds(lambda: tn.round_tt(tb, rmax=r, algorithm=algorithm))}
     del tb, outB, cores
     res["ms"] = sec1 * 1e3
     res["roofline"] = res["batch_256"]["roofline"]
@@ -161,19 +175,35 @@ def c3(tn, dev, algorithm="svd", cpu=True):
     sec, allt, out = _timeit(lambda: tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm), reps=3, warmup=1)
     assert out.ranks_tt.tolist() == [1, 8, 8, 8, 8, 1]
 
-    def whole():
-        o = None
-        for _ in range(total // share):  # the same resident share stands in for every one of the 8 (synthetic data)
-            o = tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm)
-        return o
+    # the whole config on ONE GPU: all 512 tensors resident (68.7 GB) and decomposed as one batch -- the latency-bound
+    # block-Jacobi launches of the two n = 256 bonds then carry 8x the pair problems each
+    del out
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free > 2.2 * total * 32 ** 5 * 4:
+        XW = torch.randn([total] + shape, generator=gen, device=dev, dtype=torch.float32)
+        secW, allW, outW = _timeit(lambda: tn.Tensor(XW, ranks_tt=8, batch=True, algorithm=algorithm), reps=1, warmup=1)
+        assert outW.ranks_tt.tolist() == [1, 8, 8, 8, 8, 1]
+        how = "one resident batch of 512"
+        del XW, outW
+    else:
+        def whole():
+            o = None
+            for _ in range(total // share):  # the same resident share stands in for every one of the 8 (synthetic data)
+                o = tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm)
+            return o
 
-    secW, allW, _ = _timeit(whole, reps=1, warmup=0)
+        secW, allW, _ = _timeit(whole, reps=1, warmup=0)
+        how = "8 shares of 64 back to back"
+    out = tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm)  # (for the oracle check below)
+    kinds = _kinds(lambda: tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm))
     res = {
+        "kernel_ms": kinds,
         "workload": "TT-SVD of dense 32^5 fp32 tensors, rmax 8: the 64-tensor per-GPU share of the 8-GPU config (8.6 GB resident)",
         "dtype": "f32", "algorithm": algorithm,
         "ms": sec * 1e3, "ms_all": [round(x * 1e3, 2) for x in allt], "tensors": share, "tensors_per_s": share / sec,
         "roofline": _roof("hbm", flop * share, byts * share, sec),
-        "whole_config_on_one_gpu": {"tensors": total, "ms": secW * 1e3, "tensors_per_s": total / secW,
+        "whole_config_on_one_gpu": {"tensors": total, "how": how, "ms": secW * 1e3, "tensors_per_s": total / secW,
                                     "roofline": _roof("hbm", flop * total, byts * total, secW)},
     }
     x0 = X[0].cpu()
@@ -219,17 +249,20 @@ def c1(tn, dev, algorithm="svd", cpu=True):
     gen = torch.Generator(device=dev).manual_seed(7)
     X = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
     sec, allt, out = _timeit(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm), reps=2, warmup=1)
+    ranks_out = out.ranks_tt.tolist()
     flop, byts, gram = _c1_model(shape)
     name = "x".join(map(str, shape))
+    del out
     res = {
+        "kernel_ms": _kinds(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm)),
         "workload": f"TT-SVD of a dense {name} fp32 tensor ({math.prod(shape) * 4 / 2 ** 30:.0f} GiB resident) to ranks_tt=16: the largest "
                     "member of the C1 family that fits (64^6 = 256 GiB does not fit 288 GB together with its carry)",
-        "dtype": "f32", "algorithm": algorithm, "shape": shape, "ranks": out.ranks_tt.tolist(),
+        "dtype": "f32", "algorithm": algorithm, "shape": shape, "ranks": ranks_out,
         "ms": sec * 1e3, "ms_all": [round(x * 1e3, 1) for x in allt],
         # AI = flop / bytes ~ 60 > ridge 19.7: the n = 1024 Gram matrix of the second step binds (MFMA >= 301 ms, HBM >= 121 ms at 64^6)
         "roofline": _roof("mfma", flop, byts, sec),
     }
-    del X, out
+    del X
     torch.cuda.empty_cache()
     if cpu:
         torch.manual_seed(3)
