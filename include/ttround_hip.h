@@ -114,6 +114,18 @@ int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch,
            void* R, int64_t ldr, int64_t strideR,
            void* workspace, int64_t workspace_bytes, void* stream);
 /*
+ * The same factorisation with TRANSPOSED addressing -- tensor.py:1853-1863 factors the transpose of the right unfolding
+ * (`torch.linalg.qr(unfolding.T)`, torch has no RQ) and transposes Q back (1866-1878).  `At` is the n x m row-major
+ * matrix whose TRANSPOSE A (m x n) is factored; `Qt` receives Q^T (k x m row-major, ldqt >= m); R as for ttr_qr.  The
+ * kernels read / write through (row, column) strides, nothing is copied.
+ */
+int ttr_qr_t(int dtype, int64_t m, int64_t n, int64_t batch,
+             const void* At, int64_t ldat, int64_t strideAt,
+             void* Qt, int64_t ldqt, int64_t strideQt,
+             void* R, int64_t ldr, int64_t strideR,
+             void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * The two halves of ttr_qr, for callers that fuse work into the formation of Q:
  *   ttr_qr_factor  factors A (TSQR tree of blocked compact-WY Householder blocks on MFMA), writes R (k x n) and
  *                  leaves the reflectors / T factors in `workspace` (which must stay alive and untouched);

@@ -55,6 +55,12 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_void_p],
     ),
+    "ttr_qr_t": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p],
+    ),
     "ttr_qr_factor": (
         c_int,
         [c_int, c_int64, c_int64, c_int64,
@@ -350,6 +356,26 @@ def qr(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
                     ws.data_ptr(), wsb, _stream())
     _check(code, "ttr_qr")
     return Q, R
+
+
+@_on_device
+def qr_t(At: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """QR of the TRANSPOSE of ``At`` [batch, n, m] without transposing it: returns (Qt [batch, k, m] = Q^T, R [batch, k, n])
+    (ttr_qr_t: the kernels address the operand and the result through strides)."""
+    L = lib()
+    dt = dtype_code(At.dtype)
+    At, ldat, sAt = _mat(At)
+    batch, n, m = At.shape
+    k = min(m, n)
+    Qt = torch.empty((batch, k, m), dtype=At.dtype, device=At.device)
+    R = torch.empty((batch, k, n), dtype=At.dtype, device=At.device)
+    if batch == 0:
+        return Qt, R
+    wsb = L.ttr_qr_workspace_bytes(dt, m, n, batch)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=At.device)
+    _check(L.ttr_qr_t(dt, m, n, batch, At.data_ptr(), ldat, sAt, Qt.data_ptr(), m, k * m, R.data_ptr(), n, k * n,
+                      ws.data_ptr(), wsb, _stream()), "ttr_qr_t")
+    return Qt, R
 
 
 class QrFactors:

@@ -559,12 +559,16 @@ def truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch):
 
 # ----------------------------------------------------------------------------------------------
 def mode_mul(core4: torch.Tensor, M3: torch.Tensor) -> torch.Tensor:
-    """[B, r0, S, r1] x_2 [B, a, S] -> [B, r0, a, r1] (the einsum of tensor.py:1790-1798, 1999-2002) as one
-    batched GEMM on the mode unfolding (the two permutes are layout copies)."""
+    """[B, r0, S, r1] x_2 [B, a, S] -> [B, r0, a, r1] (the einsum of tensor.py:1790-1798, 1999-2002) as ONE batched GEMM
+    over the B * r0 slices ``core[b, r0]`` (S x r1, contiguous where they lie) with the small matrix as the left
+    operand: out[b, r0] = M[b] @ core[b, r0].  Neither the core nor the result is permuted (round 2 moved both through
+    layout copies); the a x S matrix is the only thing replicated (r0 times, KB)."""
     Bt, r0, S, r1 = core4.shape
-    A = core4.permute(0, 2, 1, 3).reshape(Bt, S, r0 * r1)
-    out = _hip.gemm(M3, A)  # [B, a, r0*r1]
-    return out.reshape(Bt, M3.shape[1], r0, r1).permute(0, 2, 1, 3).contiguous()
+    a = M3.shape[1]
+    core4 = core4 if core4.is_contiguous() else core4.contiguous()
+    Mrep = M3.reshape(Bt, 1, a, S).expand(Bt, r0, a, S).reshape(Bt * r0, a, S)
+    out = _hip.gemm(Mrep, core4.reshape(Bt * r0, S, r1))  # [B * r0, a, r1]
+    return out.reshape(Bt, r0, a, r1)
 
 
 def merge_swap(c1: torch.Tensor, c2: torch.Tensor) -> torch.Tensor:
@@ -611,11 +615,18 @@ def right_orthogonalize(c: List[torch.Tensor], mu: int, Us=None) -> torch.Tensor
     """tensor.py:1835-1879: QR of the transposed right unfolding; returns L [B, r0, k]."""
     factor_orthogonalize(c, Us, mu)
     Bt, r0, I, r1 = c[mu].shape
-    Mt = c[mu].reshape(Bt, r0, I * r1).transpose(1, 2).contiguous()  # layout only
-    Q, Lt = qr(Mt)  # Mt (I r1 x r0) = Q (I r1 x k) Lt (k x r0)
-    k = Q.shape[2]
-    c[mu] = Q.transpose(1, 2).contiguous().reshape(Bt, k, I, r1)
-    L = Lt.transpose(1, 2).contiguous()  # r0 x k
+    if r0 <= _hip.max_qr_cols(c[mu].dtype):
+        # the right unfolding is the TRANSPOSE of the matrix to factor: the QR kernels address it (and Q^T, which is the new
+        # core as it lies) through strides -- no transposed copies of the core (round 2: three layout copies)
+        Qt, Lt = _hip.qr_t(c[mu].reshape(Bt, r0, I * r1))  # unfolding^T (I r1 x r0) = Q Lt;  Qt = Q^T (k x I r1)
+        k = Qt.shape[1]
+        c[mu] = Qt.reshape(Bt, k, I, r1)
+    else:
+        Mt = c[mu].reshape(Bt, r0, I * r1).transpose(1, 2).contiguous()  # more than one TSQR panel of columns: blocked QR on a copy
+        Q, Lt = qr(Mt)  # Mt (I r1 x r0) = Q (I r1 x k) Lt (k x r0)
+        k = Q.shape[2]
+        c[mu] = Q.transpose(1, 2).contiguous().reshape(Bt, k, I, r1)
+    L = Lt.transpose(1, 2).contiguous()  # r0 x k (a rank-sized matrix)
     prev = c[mu - 1]
     pushed = _hip.gemm(prev.reshape(Bt, prev.shape[1] * prev.shape[2], r0), L)
     c[mu - 1] = pushed.reshape(Bt, prev.shape[1], prev.shape[2], k)
@@ -936,8 +947,9 @@ _EPS_DEFERRED_MAX_ELEMS = 1 << 24   # eps-mode sweeps of trains up to this many 
 
 def _eps_deferred_ok(c, facs, rmax) -> bool:
     """Non-batch (eps-mode) sweep: can every bond be enqueued without reading its rank back?  Only worth it where the
-    host synchronisations dominate (a small train: every kernel is latency-bound and the factors are computed at the rank
-    cap, i.e. possibly wider than needed), and only on the fused <= 64-row truncation kernels."""
+    host synchronisations dominate (a small train: every kernel is latency-bound) AND the caller gave a rank cap (the
+    factors are computed at the cap: `round_tt(rmax=r)` on one tensor -- eps defaults to 1e-14, tensor.py:2008-2014 --
+    is the case this is for); only on the fused <= 64-row truncation kernels.  TTR_EPS_DEFERRED=1 / 0 forces / forbids it."""
     mode = os.environ.get("TTR_EPS_DEFERRED", "auto")
     if mode == "0":
         return False
@@ -946,7 +958,9 @@ def _eps_deferred_ok(c, facs, rmax) -> bool:
     if last.shape[0] != 1 or any(isinstance(f[0], _ExplicitQ) for f in facs):
         return False
     elems = last.numel() + sum(f[0].m * f[0].n for f in facs)
-    if mode != "1" and elems > _EPS_DEFERRED_MAX_ELEMS:
+    if mode != "1" and (elems > _EPS_DEFERRED_MAX_ELEMS or any(r is None for r in rmax)):
+        # (without a rank cap every bond would be computed at its FULL rank: measured on config C2 -- rank 64 in, 32 out, no
+        # rmax -- 9.3 ms deferred against 8.3 ms with one readback per bond; with a cap the widths are those of the result)
         return False
     rn = last.shape[3]
     for mu in range(N - 1, 0, -1):

@@ -254,10 +254,10 @@ int hadamard_dispatch(int dtype, int64_t count, const void* a, const void* b, vo
 int core_kron_dispatch(int dtype, int64_t B, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
                        const void* c, void* out, hipStream_t stream);
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
-                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs = 1);
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
                       int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
-                      hipStream_t stream);
+                      hipStream_t stream, int64_t o_cs = 1);
 int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
 int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch);
 int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
@@ -392,6 +392,21 @@ int ttr_qr(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_
   if (rc != TTR_OK || batch == 0) return rc;
   return ttr_qr_apply(dtype, m, n, batch, workspace, workspace_bytes, nullptr, 0, 0, m < n ? m : n, Q, ldq, strideQ,
                       stream);
+}
+
+int ttr_qr_t(int dtype, int64_t m, int64_t n, int64_t batch, const void* At, int64_t ldat, int64_t strideAt, void* Qt,
+             int64_t ldqt, int64_t strideQt, void* R, int64_t ldr, int64_t strideR, void* workspace,
+             int64_t workspace_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_t: bad dtype %d", dtype);
+  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_qr_t: bad shape %lld x %lld", (long long)m, (long long)n);
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(At && Qt && R && workspace, TTR_E_INVALID, "ttr_qr_t: null pointer");
+  TTR_REQUIRE(ldat >= m && ldqt >= m, TTR_E_INVALID, "ttr_qr_t: leading dimensions below m");
+  // the factored matrix is A = At^T: element (row, col) at At[col * ldat + row]; Q^T goes out the same way
+  int rc = qr_factor_dispatch(dtype, m, n, batch, At, 1, strideAt, R, ldr, strideR, workspace, workspace_bytes, (hipStream_t)stream, ldat);
+  if (rc != TTR_OK) return rc;
+  return qr_apply_dispatch(dtype, m, n, batch, workspace, workspace_bytes, nullptr, 0, 0, m < n ? m : n, Qt, 1, strideQt,
+                           (hipStream_t)stream, ldqt);
 }
 
 int64_t ttr_qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {

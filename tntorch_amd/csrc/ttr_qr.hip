@@ -45,8 +45,8 @@ using IC = std::integral_constant<int, I>;
 
 template <typename T>
 struct QrLevel {
-  const T* X;          // input matrix of this level
-  int64_t ldx, strideX;
+  const T* X;          // input matrix of this level: element (row, col) at X[row * ldx + col * xcs]
+  int64_t ldx, strideX, xcs;  // xcs = 1 except for a TRANSPOSED level-0 input (ttr_qr_t: ldx = 1, xcs = leading dimension)
   int64_t m;           // rows
   int n;               // cols (<= 16*NT)
   int nb;              // row blocks (evenly split)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rowl(tm, r), col = tn * PW + cl;
-          acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + col] : T(0);
+          acc[tm][tn][r] = (row < rows && col < n) ? X[(int64_t)row * p.ldx + (int64_t)col * p.xcs] : T(0);
         }
   }
   // fp32 range guard: the Householder steps square the entries (column norms, alpha^2 + ss); for blocks whose
@@ -845,7 +845,7 @@ struct QrApply {
   const T* Top;  // level above: row block b*n, n x kcols ; nullptr => identity
   int64_t ldtop, strideTop;
   T* Out;
-  int64_t ldout, strideOut;
+  int64_t ldout, strideOut, ocs;  // element (row, col) at Out[row * ldout + col * ocs] (ocs != 1: transposed level-0 output)
   int pk, pI;    // > 0: level 0 of a PUSHED factorisation, local row (wave, kk) <-> global row kk * pI + NW*b + wave
   T* Gp;           // optional (level 0 of a pushed factorisation, fp32, pk = 64, kcols = 32, whole blocks): the block's share of the
                    // ROW GRAM matrix of Out as a pk x pk unfolding, Gp[(bt * nb + b)][pk][pk] = sum_i Out_i Out_i^T over the block's mode indices
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rowl(tm, r), col = tc * PW + cl;
-          if (row < rows && col < kc) Out[(int64_t)row * p.ldout + col] = C[tm][tc][r];
+          if (row < rows && col < kc) Out[(int64_t)row * p.ldout + (int64_t)col * p.ocs] = C[tm][tc][r];
         }
   }
   astamp();
@@ -1154,7 +1154,7 @@ struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factoris
 
 template <typename T, int NT>
 static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* R, int64_t ldr,
-                      int64_t strideR, T* ws, const QrPlan& pl, const Pushed& pu, hipStream_t stream) {
+                      int64_t strideR, T* ws, const QrPlan& pl, const Pushed& pu, hipStream_t stream, int64_t a_cs = 1) {
   const int L = pl.levels;
   for (int l = 0; l < L; ++l) {
     QrLevel<T> p;
@@ -1165,6 +1165,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.Cn2 = (const T*)pu.Cn2; p.strideCn2 = pu.strideCn2; p.sumRa = pu.sumRa; p.sumCa = pu.sumCa;
     p.X = l == 0 ? A : ws + pl.off_x[l];
     p.ldx = l == 0 ? lda : n;
+    p.xcs = l == 0 ? a_cs : 1;
     p.strideX = l == 0 ? strideA : pl.m[l] * n;
     p.m = pl.m[l]; p.n = n; p.nb = pl.nb[l];
     p.Vt = ws + pl.off_vt[l];
@@ -1193,10 +1194,12 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
 
 template <typename T, int NT, int NTC>
 static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const QrPlan& pl, const T* C, int64_t ldc,
-                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream) {
+                     int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream,
+                     int64_t o_cs = 1) {
   const int L = pl.levels;
   for (int l = L - 1; l >= 0; --l) {
     QrApply<T> p;
+    p.ocs = l == 0 ? o_cs : 1;
     p.Vt = ws + pl.off_vt[l];
     p.tau = ws + pl.off_tau[l];
     p.Tg = ws + pl.off_tg[l];
@@ -1219,7 +1222,8 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
 
 template <typename T>
 static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
-                        int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, const Pushed& pu, hipStream_t stream) {
+                        int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, const Pushed& pu, hipStream_t stream,
+                        int64_t a_cs = 1) {
   if (batch > kMaxBatchSlice) {  // slices of the batch, one after the other (see qr_workspace_bytes)
     TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
                 "ttr_qr: workspace too small for batch %lld", (long long)batch);
@@ -1232,7 +1236,7 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
       if (ps.Cn) ps.Cn = (const T*)ps.Cn + b0 * ps.strideCn;
       if (ps.Cn2) ps.Cn2 = (const T*)ps.Cn2 + b0 * ps.strideCn2;
       const int rc = factor_typed<T>(m, n, nb, A ? (const void*)((const T*)A + b0 * strideA) : nullptr, lda, strideA,
-                                     (T*)R + b0 * strideR, ldr, strideR, wsp, wsb, ps, stream);
+                                     (T*)R + b0 * strideR, ldr, strideR, wsp, wsb, ps, stream, a_cs);
       if (rc != TTR_OK) return rc;
       wsp += wsb;
     }
@@ -1242,24 +1246,24 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
   switch (nt_for(n)) {
-    case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
-    case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
-    default: return factor_run<T, 4>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream);
+    case 1: return factor_run<T, 1>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream, a_cs);
+    case 2: return factor_run<T, 2>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream, a_cs);
+    default: return factor_run<T, 4>(m, (int)n, batch, (const T*)A, lda, strideA, (T*)R, ldr, strideR, (T*)ws, pl, pu, stream, a_cs);
   }
 }
 
 template <typename T, int NT>
 static int apply_nt(int64_t m, int n, int64_t batch, T* ws, const QrPlan& pl, const T* C, int64_t ldc, int64_t strideC,
-                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream) {
-  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
-  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
-  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream);
+                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream, int64_t o_cs) {
+  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
+  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
+  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
 }
 
 template <typename T>
 static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
                        int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI, void* Gp,
-                       hipStream_t stream) {
+                       hipStream_t stream, int64_t o_cs = 1) {
   if (batch > kMaxBatchSlice) {
     TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
                 "ttr_qr_apply: workspace too small for batch %lld", (long long)batch);
@@ -1269,7 +1273,7 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
       const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
       const int rc = apply_typed<T>(m, n, nb, wsp, wsb, C ? (const void*)((const T*)C + b0 * strideC) : nullptr, ldc, strideC, kc,
                                     (T*)Out + b0 * strideO, ldo, strideO, pk, pI,
-                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb).nb[0] * (int64_t)(64 * 64)) : nullptr, stream);
+                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb).nb[0] * (int64_t)(64 * 64)) : nullptr, stream, o_cs);
       if (rc != TTR_OK) return rc;
       wsp += wsb;
     }
@@ -1281,30 +1285,30 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
               (long long)kc);
   switch (nt_for(n)) {
-    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
-    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
-    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream);
+    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
+    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
+    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
   }
 }
 
 int qr_max_cols(int) { return 64; }
 
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
-                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
   const Pushed none;
-  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream);
-  return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream);
+  if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream, a_cs);
+  return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream, a_cs);
 }
 
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
                       int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
-                      hipStream_t stream) {
+                      hipStream_t stream, int64_t o_cs) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr_apply: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream);
-  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream);
+  if (dtype == TTR_F32) return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream, o_cs);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, 0, 0, nullptr, stream, o_cs);
 }
 
 // Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/NW)

@@ -30,7 +30,7 @@ def kind_of(name):
         return "project"
     if "eigh_" in name:
         return "eigh"
-    if "gemm_kernel" in name or "splitk_reduce" in name:
+    if "gemm_kernel" in name or "gemm_big_kernel" in name or "splitk_reduce" in name or "bj_apply_kernel" in name:
         return "gemm"
     if "ttr::" in name:
         return "misc"
@@ -83,7 +83,7 @@ def main():
     if os.path.isdir(cd):
         vals, _ = read_pass(cd)
         for name, cs in vals.items():
-            if "mfma_kernel" in name and cs.get("GRBM_GUI_ACTIVE"):
+            if ("mfma_kernel" in name or "mfma64_kernel" in name) and cs.get("GRBM_GUI_ACTIVE"):
                 calib = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(cs["GRBM_GUI_ACTIVE"]) * 1024.0)
     out = {"_source": f"tools/profile_round.sh ({steps} single-stream steps at B = {B}; separate --pmc passes)", "_batch": B,
            "source_sha": source_sha(), "mfma_busy_ratio_of_pure_mfma_kernel": calib}
@@ -103,7 +103,7 @@ def main():
             util = ratio / calib if calib else ratio
             entry["mfma_busy_ratio"] = ratio
             entry["mfma_util"] = util
-        mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+        mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"))
         if mops is not None:
             entry["mfma_flops_per_step"] = mops * 512 / steps
         out[k] = entry

@@ -20,3 +20,17 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 python $R/tools/pmc_to_json.py $OUT 2 $B > $OUT/pmc_summary.txt 2> $OUT/pmc_summary.err
 tail -n 30 $OUT/pmc_summary.txt
 head -n 25 $OUT/kernel_stats.txt
+# ---- fp64: a resident batch of BASELINE config C2 (256 rank-64 trains, 10 cores x mode 128), same views
+F=$OUT/fp64
+mkdir -p $F
+rocprofv3 --kernel-trace --stats --output-format csv -d $F/kt -o kt -- python $R/tools/c2_step.py 256 3 > $F/kt.log 2> $F/kt.err
+python $R/tools/rocprof_summary.py $(find $F/kt -name "*kernel_trace.csv" | head -1) > $F/kernel_stats.txt 2>> $F/kt.err
+for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+  name=${spec%%:*}; ctrs=${spec#*:}
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $F/pmc_$name -o p -- python $R/tools/c2_step.py 256 2 > $F/pmc_$name.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $F/pmc_mfma_calib -o p -- /tmp/ttr_microbench d > $F/pmc_mfma_calib.log 2>&1
+python $R/tools/pmc_to_json.py $F 2 256 > $F/pmc_summary.txt 2> $F/pmc_summary.err
+tail -n 24 $F/pmc_summary.txt
+head -n 22 $F/kernel_stats.txt
+
