@@ -118,7 +118,7 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 # matrices) and the pair rotations are applied with the MFMA GEMM:  G <- W^T G W,  V <- V W.  Pairs are kept
 # physically adjacent by permuting the block order between rounds (gather copies -- layout only).
 _BJ_MAX_SWEEPS = 12
-_BJ_MAX_SWEEPS_DEVICE = 20   # (launches after convergence return at once: a generous bound is free)
+_BJ_MAX_SWEEPS_DEVICE = 24   # (launches after convergence return at once: a generous bound is free)
 
 
 def _bj_block(n: int) -> Optional[int]:
@@ -151,14 +151,17 @@ def _pair_rows(X: torch.Tensor, W: torch.Tensor, npairs: int, w: int) -> torch.T
     return torch.cat([out, X[:, used:, :]], dim=1)
 
 
-def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def eigh_block_jacobi(G: torch.Tensor, relative: bool = False, prerotation: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [B, n, n] (n a multiple of a block size in 8..32).
 
     Returns (V [B, n, n] orthogonal, d [B, n] eigenvalues, unsorted).
     Pair problems run on the Jacobi kernel (relative rotation test + absolute floor).  ``relative=False``: stop
     when ||offdiag|| <= sqrt(n)/2 eps ||G|| (absolute accuracy O(eps ||G||): pass 1 / 'eig').  ``relative=True``:
     stop when a whole sweep found nothing to rotate (pass 2 of 'svd': G is an accurately formed, nearly diagonal,
-    graded Gram matrix and small eigenvalues keep relative accuracy).
+    graded Gram matrix and small eigenvalues keep relative accuracy).  ``prerotation`` (pass 1 of 'svd'): V only has to
+    bring the matrix close to diagonal -- pass 2 re-forms the Gram matrix of the rotated data and continues from there --
+    so the sweeps stop at an off-diagonal ratio of 1e-3 instead of the rounding floor (same total number of sweeps over
+    the two passes, none wasted on digits pass 2 recomputes).
     """
     Bt, n, _ = G.shape
     b = _bj_block(n)
@@ -172,7 +175,8 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
     if nbk % 2 == 0 and BLOCK_JACOBI_ON_DEVICE:
         # the whole sweep loop on the device: two launches per round, one control launch per sweep, no readback -- the
         # maximum number of sweeps is enqueued and everything after convergence returns at its first instruction
-        _hip.bj_sweeps(G, V, b, relative, 0.5 * math.sqrt(n) * torch.finfo(dt).eps, _BJ_MAX_SWEEPS_DEVICE)
+        tol_dev = 1e-3 if prerotation else 0.5 * math.sqrt(n) * torch.finfo(dt).eps
+        _hip.bj_sweeps(G, V, b, relative, tol_dev, _BJ_MAX_SWEEPS_DEVICE)
         return _bj_finish(G0, G, V, relative)
     circle = list(range(nbk)) + ([-1] if nbk % 2 else [])  # -1: bye
     phys = list(range(nbk))
@@ -218,7 +222,7 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False) -> Tuple[torch.Te
         Goff = G.clone()
         torch.diagonal(Goff, dim1=1, dim2=2).zero_()
         ratio = float((_hip.norm(Goff.reshape(Bt, -1)) / gnorm.clamp_min(torch.finfo(dt).tiny)).max().item())
-        if ratio <= tol or (prev is not None and sweep >= 3 and ratio > 0.5 * prev):
+        if ratio <= tol or (prev is not None and sweep >= 3 and ratio > 0.7 * prev and ratio <= 64 * tol):  # (as bj_control_kernel)
             break
         prev = ratio
     return _bj_finish(G0, G, V, relative)
@@ -240,7 +244,7 @@ def _bj_finish(G0, G, V, relative):
     return V, d
 
 
-def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, cap: int, solver: int):
+def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, cap: int, solver: int, prerotation: bool = False):
     """Dispatch on the problem size: n <= LDS limit -> one workgroup per matrix (tridiagonal QL for n <= 64 when
     requested, Jacobi otherwise); larger -> block Jacobi over the GPU, then one (rotation-free) pass of the
     Jacobi kernel for its epilogue (clamp, sqrt, sort, rank rule).  Sizes no block width in 8..32 divides are
@@ -251,7 +255,7 @@ def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, ca
         return _hip.eigh_trunc(G, eig_mode, use_delta, delta2, cap, abs_floor=solver)
     relative = solver != _hip.SOLVER_TRIDIAG
     if _bj_block(n) is not None:
-        Vb, d = eigh_block_jacobi(G, relative=relative)
+        Vb, d = eigh_block_jacobi(G, relative=relative, prerotation=prerotation)
         P, sig, info = _hip.eigh_trunc(torch.diag_embed(d), eig_mode, use_delta, delta2, cap, abs_floor=_hip.SOLVER_JACOBI_ABS)
         return _hip.gemm(Vb, P), sig, info
     nblk = -(-n // 32)
@@ -410,12 +414,12 @@ def truncate(
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         if left_side:
             G = _hip.gemm(M, M, transB=True)
-            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG)
+            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG, prerotation=True)
             Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
             G = _hip.gemm(Mw, Mw, transB=True)
         else:
             G = _hip.gemm(M, M, transA=True)
-            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG)
+            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG, prerotation=True)
             if scratch_ok and M.is_contiguous() and M.numel() * M.element_size() > _INPLACE_ROTATE_BYTES:
                 # config-scale carries (C1 class: tens of GiB): every row of M V1 depends on the same row of M only, so
                 # the rotation runs chunk by chunk into a bounded buffer that is copied back over its source rows
