@@ -1091,9 +1091,12 @@ struct QrPlan {
 };
 
 static int nt_for(int64_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : 4); }
-static int nw_for(int64_t rows) { return rows > BR4 ? 8 : 4; }
+int g_qr_f64_nw4 = 1;  // ttr_debug_set_knob(TTR_KNOB_QR_F64_NW4): fp64 trees out of 256-row (4-wave) blocks only
+// fp64: the 8-wave block needs 132 KB of LDS and 237 VGPRs (ONE block, i.e. one Householder chain, per CU); two 4-wave
+// blocks fit (75 KB, 2 waves per SIMD) -- more chains in flight beat the shallower tree (measured on config C2)
+static int nw_for(int64_t rows, bool f64) { return (rows > BR4 && !(f64 && g_qr_f64_nw4)) ? 8 : 4; }
 
-static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
+static QrPlan make_plan(int64_t m, int64_t n, int64_t batch, bool f64) {
   QrPlan pl{};
   const int NT = nt_for(n);
   pl.npad = NT * PW;
@@ -1101,7 +1104,7 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch) {
   int L = 0;
   for (;;) {
     pl.m[L] = cur;
-    pl.nw[L] = nw_for(cur);
+    pl.nw[L] = nw_for(cur, f64);
     pl.nb[L] = (int)ceil_div(cur, 64 * pl.nw[L]);
     ++L;
     if (pl.nb[L - 1] <= 1) break;
@@ -1132,7 +1135,7 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
   const int64_t elem = dtype == TTR_F64 ? 8 : 4;
   int64_t total = 0;
   for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice)
-    total += make_plan(m, n, batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice).total * elem;
+    total += make_plan(m, n, batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice, dtype == TTR_F64).total * elem;
   return total;
 }
 
@@ -1230,7 +1233,7 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
     char* wsp = (char*)ws;
     for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice) {
       const int64_t nb = batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice;
-      const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
+      const int64_t wsb = make_plan(m, n, nb, sizeof(T) == 8).total * (int64_t)sizeof(T);
       Pushed ps = pu;
       if (ps.Rm) ps.Rm = (const T*)ps.Rm + b0 * ps.strideRm;
       if (ps.Cn) ps.Cn = (const T*)ps.Cn + b0 * ps.strideCn;
@@ -1242,7 +1245,7 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
     }
     return TTR_OK;
   }
-  const QrPlan pl = make_plan(m, n, batch);
+  const QrPlan pl = make_plan(m, n, batch, sizeof(T) == 8);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
   switch (nt_for(n)) {
@@ -1270,16 +1273,16 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
     char* wsp = (char*)ws;
     for (int64_t b0 = 0; b0 < batch; b0 += kMaxBatchSlice) {
       const int64_t nb = batch - b0 < kMaxBatchSlice ? batch - b0 : kMaxBatchSlice;
-      const int64_t wsb = make_plan(m, n, nb).total * (int64_t)sizeof(T);
+      const int64_t wsb = make_plan(m, n, nb, sizeof(T) == 8).total * (int64_t)sizeof(T);
       const int rc = apply_typed<T>(m, n, nb, wsp, wsb, C ? (const void*)((const T*)C + b0 * strideC) : nullptr, ldc, strideC, kc,
                                     (T*)Out + b0 * strideO, ldo, strideO, pk, pI,
-                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb).nb[0] * (int64_t)(64 * 64)) : nullptr, stream, o_cs);
+                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb, sizeof(T) == 8).nb[0] * (int64_t)(64 * 64)) : nullptr, stream, o_cs);
       if (rc != TTR_OK) return rc;
       wsp += wsb;
     }
     return TTR_OK;
   }
-  const QrPlan pl = make_plan(m, n, batch);
+  const QrPlan pl = make_plan(m, n, batch, sizeof(T) == 8);
   TTR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), TTR_E_WORKSPACE, "ttr_qr_apply: workspace %lld < %lld bytes",
               (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
@@ -1313,11 +1316,14 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
 
 // Pushed variants: the factored matrix is the (k*I) x n left unfolding of Rm * C; level 0 has ceil(I/NW)
 // zero-padded blocks of 64*NW rows (one mode index per wave), so the plan is that of a (64*NW*ceil(I/NW)) x n
-// matrix -- NW = 8 as soon as there are more than four mode indices (consistent with nw_for).
-static int64_t pushed_rows(int64_t I) { return I > 4 ? 512 * ceil_div(I, 8) : 256; }
+// matrix -- NW = 8 as soon as there are more than four mode indices (consistent with nw_for; fp64: 4-wave blocks, see there).
+static int64_t pushed_rows(int64_t I, int dtype) {
+  if (dtype == TTR_F64 && g_qr_f64_nw4) return 256 * ceil_div(I, 4);
+  return I > 4 ? 512 * ceil_div(I, 8) : 256;
+}
 
 int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {
-  return qr_workspace_bytes(dtype, pushed_rows(I), n, batch);
+  return qr_workspace_bytes(dtype, pushed_rows(I, dtype), n, batch);
 }
 
 static int pushed_ok(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n) {
@@ -1337,7 +1343,7 @@ int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int6
   Pushed pu;
   pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Cn; pu.strideCn = strideCn;
   pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
-  const int64_t m = pushed_rows(I);
+  const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
   return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
 }
@@ -1355,7 +1361,7 @@ int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch
   pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Ca; pu.strideCn = strideCa;
   pu.Cn2 = Cb; pu.strideCn2 = strideCb; pu.sumRa = (int)ra; pu.sumCa = (int)ca;
   pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
-  const int64_t m = pushed_rows(I);
+  const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
   return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
 }
@@ -1373,7 +1379,7 @@ int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t
   if (rc != TTR_OK) return rc;
   TTR_REQUIRE(!G || (qr_apply_pushed_gram_parts(dtype, k, I, n, kc) > 0 && ldo == kc), TTR_E_UNSUPPORTED,
               "ttr_qr_apply_pushed_gram: shape not covered by the fused Gram epilogue (see ttr_qr_apply_pushed_gram_parts)");
-  const int64_t m = pushed_rows(I);
+  const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32)
     return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, G, stream);
   return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, nullptr, stream);
