@@ -1091,9 +1091,11 @@ struct QrPlan {
 };
 
 static int nt_for(int64_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : 4); }
-int g_qr_f64_nw4 = 1;  // ttr_debug_set_knob(TTR_KNOB_QR_F64_NW4): fp64 trees out of 256-row (4-wave) blocks only
+int g_qr_f64_nw4 = 0;  // ttr_debug_set_knob(TTR_KNOB_QR_F64_NW4): fp64 trees out of 256-row (4-wave) blocks only
 // fp64: the 8-wave block needs 132 KB of LDS and 237 VGPRs (ONE block, i.e. one Householder chain, per CU); two 4-wave
-// blocks fit (75 KB, 2 waves per SIMD) -- more chains in flight beat the shallower tree (measured on config C2)
+// blocks would fit (75 KB, 2 waves per SIMD).  Measured on config C2's resident batch (tools/c2_ab.py): 256 trains in
+// 40.9 ms with the 4-wave blocks against 34.0 ms with the 8-wave blocks (qr_factor 37.1 vs 25.5 ms) -- the pair phases of
+// the 8-wave block and the shallower tree outweigh the second chain per CU.  Kept as a switch, off.
 static int nw_for(int64_t rows, bool f64) { return (rows > BR4 && !(f64 && g_qr_f64_nw4)) ? 8 : 4; }
 
 static QrPlan make_plan(int64_t m, int64_t n, int64_t batch, bool f64) {
