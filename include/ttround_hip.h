@@ -225,8 +225,11 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
                    int32_t* info,
                    int eig_mode, int use_delta, double delta2, const double* delta2_dev, int64_t rmax,
                    int abs_floor, int32_t* sweeps,
+                   const int32_t* skip_items, const void* sigma_in, int64_t stride_sigma_in,
                    void* workspace, int64_t workspace_bytes, void* stream);
-/* `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
+/* `skip_items` / `sigma_in` (optional; Jacobi solvers, use_delta = 0): pass-through items of the two-pass truncation, see
+ * ttr_spectrum_flat below.
+ * `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
  * of `delta2` -- tensor.py:2039-2051 computes delta from the norm of the last core and reads it back (`.item()`); an
  * eps-mode sweep that keeps it on the device enqueues every bond without a host synchronisation. */
 
@@ -319,7 +322,20 @@ int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch);
 int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 void* G, int64_t nparts, void* stream);
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
-                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, void* stream);
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip, void* stream);
+/*
+ * When is the second pass needed?  The first Gram matrix G = M M^T carries sigma_i^2 with an ABSOLUTE error of c eps sigma_1^2
+ * (c: a small constant of the fp32 accumulation), i.e. sigma_i and the unit norm of row i of `right` to c eps (sigma_1 /
+ * sigma_i)^2 / 2: the second pass exists for kept singular values far below sigma_1.  When the `keep` kept ones lie within
+ * a factor 1 / thr of each other (thr = 0.25: 8 c eps -- measured: right-orthonormality 2.4e-7 after one pass against
+ * 3.4e-7 after two at sigma_keep = 0.25 sigma_1, CPU emulation in DESIGN.md), one pass already is in the accuracy class
+ * of the two.  ttr_spectrum_flat writes flat[b] = (sigma[b][keep - 1] >= thr * sigma[b][0] > 0) from pass 1's sigma (sorted
+ * decreasing); ttr_rotgram skips items with skip[b] != 0 (their G is not written) and ttr_eigh_trunc passes them through
+ * (`skip_items`: V = I, sigma = sigma_in, rank rule without delta).  Only meaningful without delta (batch mode:
+ * round.py:149-150), where the rank does not depend on the small singular values.
+ */
+int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
+                      int32_t* flat, void* stream);
 int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
                 const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1,

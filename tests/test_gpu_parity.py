@@ -1170,3 +1170,43 @@ def test_eps_mode_without_rank_readbacks(dt, eps, alg, monkeypatch):
     if alg == "svd" or eps > 1e-10:   # ('eig' at eps = 1e-14 sits on the Gram noise floor: ranks not asserted, tests/test_round.py:52-59)
         assert all(abs(x - y) <= 1 for x, y in zip(ranks(out["1"][0]), ranks(ref)))
     assert rel_diff(dense(out["1"][0]), dense(ref)) <= max(3 * eps, tol)
+
+
+def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
+    """Batch-mode 'svd' truncation: an item whose KEPT singular values lie within a factor 4 of each other is decided by the
+    first Gram pass alone (ttr_spectrum_flat; the second pass exists for kept singular values far below sigma_1).  On the
+    metric's shape (flat bonds: sigma_32 / sigma_1 ~ 0.7 on five of seven) the shortcut must (a) really trigger, (b) agree
+    with the full two-pass result to 2e-6, (c) stay inside the parity bounds against the oracle's LAPACK 'svd', and (d) not
+    touch items with a decaying spectrum (bit-identical results there)."""
+    from tntorch_amd import _hip, _hipops
+    sg = torch.tensor([[4.0, 3.0, 2.0, 1.0, 0.1], [4.0, 3.0, 2.0, 0.9, 0.1], [0.0, 0.0, 0.0, 0.0, 0.0]], dtype=torch.float32).cuda()
+    assert _hip.spectrum_flat(sg, 4, 0.25).tolist() == [1, 0, 0] and _hip.spectrum_flat(sg, 5, 0.02).tolist() == [1, 1, 0]
+    inp = _metric_input(4, seed=11)
+    calls = []
+    orig = _hip.spectrum_flat
+    monkeypatch.setattr(_hip, "spectrum_flat", lambda *a: calls.append(orig(*a)) or calls[-1])
+    res = {}
+    for thr in (0.25, 0.0):
+        monkeypatch.setattr(_hipops, "FLAT_SPECTRUM_THR", thr)
+        t = gpu_tensor(inp, batch=True)
+        t.round_tt(rmax=32)
+        res[thr] = to_list(t.cores)
+    skipped = sum(int(c.sum().item()) for c in calls)
+    assert len(calls) == 7 and skipped >= 4 * 4          # at least four of the seven bonds of every item
+    for i in range(4):
+        a, b = [c[i] for c in res[0.25]], [c[i] for c in res[0.0]]
+        assert tt_rel_err(a, b) <= 2e-6
+        ref = oracle.round_tt([c[i] for c in inp], rmax=32, algorithm="svd")
+        assert ranks(a) == ranks(ref) and tt_rel_err(a, ref) <= 2e-5
+        so, sr = oracle.bond_singular_values(a), oracle.bond_singular_values(ref)
+        assert all(((x - y).abs().max() / y.max()).item() <= 2e-5 for x, y in zip(so, sr))
+    assert _right_orth_err([c[0] for c in res[0.25]]) <= 5e-6
+    # decaying spectrum: nothing is flat, the shortcut changes nothing
+    dec = _decaying_tt([20, 18, 16, 18, 20], 24, 1.0, torch.float32, seed=5, batch=3)
+    out = {}
+    for thr in (0.25, 0.0):
+        monkeypatch.setattr(_hipops, "FLAT_SPECTRUM_THR", thr)
+        t = gpu_tensor(dec, batch=True)
+        t.round_tt(rmax=12)
+        out[thr] = to_list(t.cores)
+    assert all(torch.equal(x, y) for x, y in zip(out[0.25], out[0.0]))

@@ -100,8 +100,9 @@ _SIGNATURES = {
         c_int,
         [c_int, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
-         c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+         c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
+    "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p]),
     "ttr_bj_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_bj_solve": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_apply": (
@@ -114,7 +115,7 @@ _SIGNATURES = {
     "ttr_rowgram": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "ttr_rotgram": (
         c_int,
-        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "ttr_project": (
         c_int,
@@ -507,6 +508,7 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
 def eigh_trunc(
     G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, rmax: int, abs_floor: int = 1,
     sweeps: Optional[torch.Tensor] = None, delta2_dev: Optional[torch.Tensor] = None,
+    skip_items: Optional[torch.Tensor] = None, sigma_in: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Eigen-decomposition of symmetric [batch, n, n] + rank rule.  Returns V (columns sorted by
     decreasing sigma), sigma [batch, n], info [batch] int32 (rank, or 0 for the zero guard).
@@ -534,6 +536,8 @@ def eigh_trunc(
         eig_mode, int(bool(use_delta)), float(delta2),
         delta2_dev.data_ptr() if delta2_dev is not None else None, rmax, int(abs_floor),
         sweeps.data_ptr() if sweeps is not None else None,
+        skip_items.data_ptr() if skip_items is not None else None,
+        sigma_in.data_ptr() if sigma_in is not None else None, sigma_in.shape[-1] if sigma_in is not None else 0,
         ws.data_ptr() if ws is not None else None, wsb, _stream(),
     )
     _check(code, "ttr_eigh_trunc")
@@ -647,7 +651,19 @@ def sweep_fused_ok(M: torch.Tensor) -> bool:
 
 
 @_on_device
-def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
+def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float) -> torch.Tensor:
+    """int32 [batch]: 1 where sigma[b, keep - 1] >= thr * sigma[b, 0] > 0 (sigma [batch, n] sorted decreasing; ttr_spectrum_flat)."""
+    sigma = sigma.contiguous()
+    batch, n = sigma.shape
+    flat = torch.empty((batch,), dtype=torch.int32, device=sigma.device)
+    if batch:
+        _check(lib().ttr_spectrum_flat(dtype_code(sigma.dtype), n, batch, sigma.data_ptr(), n, int(keep), float(thr),
+                                       flat.data_ptr(), _stream()), "ttr_spectrum_flat")
+    return flat
+
+
+@_on_device
+def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Split-K partials [batch, parts, R, R] of M M^T (V1 None) or of (V1^T M)(V1^T M)^T for M [batch, R, n], R <= 64
     (ttr_rowgram / ttr_rotgram); ``eigh_trunc`` sums the parts on load."""
     L = lib()
@@ -663,7 +679,8 @@ def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
     else:
         V1, ldv, sV = _mat(V1)
         assert V1.shape == (batch, R, R)
-        _check(L.ttr_rotgram(dt, R, n, batch, M.data_ptr(), ldm, sM, V1.data_ptr(), ldv, sV, G.data_ptr(), parts, _stream()),
+        _check(L.ttr_rotgram(dt, R, n, batch, M.data_ptr(), ldm, sM, V1.data_ptr(), ldv, sV, G.data_ptr(), parts,
+                             skip.data_ptr() if skip is not None else None, _stream()),
                "ttr_rotgram")
     return G
 

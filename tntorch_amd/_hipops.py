@@ -313,6 +313,11 @@ def _deferred_readback(x: torch.Tensor):
     return wait
 
 
+# sigma_keep >= FLAT_SPECTRUM_THR * sigma_1: the second Gram pass of the 'svd' truncation is skipped for that item (batch
+# mode); 0 disables the shortcut (TTR_FLAT_SPECTRUM_THR)
+FLAT_SPECTRUM_THR = float(os.environ.get("TTR_FLAT_SPECTRUM_THR", "0.25"))
+
+
 def _select_rank(info: torch.Tensor, batch: bool, rmax: Optional[int], k: int) -> int:
     if batch:  # round.py:149-150: no eps truncation, no device->host sync
         return _rank_cap(rmax, k)
@@ -366,9 +371,17 @@ def truncate(
         V1 = None
         G = gram if gram is not None else _hip.rowgram(M)
         if algorithm == "svd":
-            V1, _, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
-            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
-                                           abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev)
+            V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            flat = None
+            if batch and FLAT_SPECTRUM_THR > 0:
+                # items whose KEPT singular values lie within a factor 4 of each other do not need the second pass (the first
+                # Gram matrix already carries them to a few eps; include/ttround_hip.h: ttr_spectrum_flat): their rotated
+                # Gram matrix is not formed and the pass-2 solver hands pass 1's result through.  Decided per item, on the
+                # device; batch mode only (the rank does not depend on the small singular values there).
+                flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR)
+            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev,
+                                           skip_items=flat, sigma_in=sig1 if flat is not None else None)
         else:
             V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG, delta2_dev=delta2_dev)

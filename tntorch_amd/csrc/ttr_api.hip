@@ -135,6 +135,17 @@ __global__ __launch_bounds__(kThreads) void mask_cols_kernel(int64_t rows, int64
   }
 }
 
+// flat[b] = 1 when the `keep` largest singular values of item b (sigma sorted decreasing) lie within a factor 1 / thr of
+// each other: sigma[keep - 1] >= thr * sigma[0] > 0
+template <typename T>
+__global__ void spectrum_flat_kernel(int64_t batch, int keep, T thr, const T* __restrict__ sigma, int64_t stride_sigma,
+                                     int32_t* __restrict__ flat) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const T s0 = sigma[b * stride_sigma], sk = sigma[b * stride_sigma + keep - 1];
+  flat[b] = (s0 > T(0) && sk >= thr * s0) ? 1 : 0;
+}
+
 // Block-wide sum of doubles (256 threads), result in every thread.
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -275,7 +286,8 @@ int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                   int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr);
+                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr, const int32_t* skip_items = nullptr,
+                  const void* sigma_in = nullptr, int64_t stride_sigma_in = 0);
 int eigh_pairs_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, const void* G, int64_t ldg, int64_t strideG,
                         const int32_t* pair_tab, void* W, void* scratch, const int32_t* skip_flag, int32_t* rot_count,
                         hipStream_t stream);
@@ -290,7 +302,8 @@ int eigh_max_n_lds(int dtype);
 
 int sweep_gram_parts(int64_t n, int64_t batch);
 int sweep_gram_dispatch(int dtype, int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
-                        const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream);
+                        const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream,
+                        const int32_t* skip = nullptr);
 int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
                            int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
                            int64_t strideV2, const void* sigma, int64_t stride_sigma, int scale_right, void* right,
@@ -469,7 +482,8 @@ int64_t ttr_eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) { return e
 int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                    int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma,
                    int32_t* info, int eig_mode, int use_delta, double delta2, const double* delta2_dev, int64_t rmax,
-                   int abs_floor, int32_t* sweeps, void* workspace, int64_t workspace_bytes, void* stream) {
+                   int abs_floor, int32_t* sweeps, const int32_t* skip_items, const void* sigma_in, int64_t stride_sigma_in,
+                   void* workspace, int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_trunc: bad dtype %d", dtype);
   TTR_REQUIRE(n >= 1 && batch >= 0 && rmax >= 1 && gparts >= 1, TTR_E_INVALID, "ttr_eigh_trunc: bad arguments");
   TTR_REQUIRE(abs_floor >= TTR_SOLVER_JACOBI_REL && abs_floor <= TTR_SOLVER_JACOBI_LIVE, TTR_E_INVALID,
@@ -480,7 +494,7 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch, const void* G, int64_t l
               eig_mode);
   return eigh_dispatch(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info,
                        eig_mode, use_delta, delta2, rmax, abs_floor, sweeps, workspace, workspace_bytes,
-                       (hipStream_t)stream, delta2_dev);
+                       (hipStream_t)stream, delta2_dev, skip_items, sigma_in, stride_sigma_in);
 }
 
 int64_t ttr_bj_scratch_bytes(int dtype, int64_t b, int64_t npairs, int64_t items) {
@@ -608,12 +622,32 @@ int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
 }
 
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
-                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, void* stream) {
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_rotgram: bad dtype %d", dtype);
   TTR_REQUIRE(R >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_rotgram: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && G && V1, TTR_E_INVALID, "ttr_rotgram: null pointer");
-  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream);
+  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream, skip);
+}
+
+int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
+                      int32_t* flat, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_spectrum_flat: bad dtype %d", dtype);
+  TTR_REQUIRE(n >= 1 && keep >= 1 && keep <= n && batch >= 0 && thr > 0.0 && thr <= 1.0, TTR_E_INVALID,
+              "ttr_spectrum_flat: bad arguments");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(sigma && flat, TTR_E_INVALID, "ttr_spectrum_flat: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned gx = (unsigned)ceil_div(batch, kThreads);
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(spectrum_flat_kernel<float>, dim3(gx), dim3(kThreads), 0, s, batch, (int)keep, (float)thr, (const float*)sigma,
+                       stride_sigma, flat);
+  else
+    hipLaunchKernelGGL(spectrum_flat_kernel<double>, dim3(gx), dim3(kThreads), 0, s, batch, (int)keep, thr, (const double*)sigma,
+                       stride_sigma, flat);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
 }
 
 int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* M, int64_t ldm, int64_t strideM,

@@ -55,6 +55,12 @@ struct EighArgs {
   // [[G_ii, G_ij], [G_ji, G_jj]] of blocks i = pair_tab[2 pair], j = pair_tab[2 pair + 1] of the item's n x n matrix
   const int32_t* pair_tab;
   int pair_b, pairs_per_item;
+  // pass 2 of the two-pass truncation, items whose kept spectrum is flat (ttr_spectrum_flat): the first Gram matrix already
+  // carries every kept singular value to a few eps, so the item passes through -- V = I, sigma = sigma_in (pass 1's, sorted),
+  // rank rule as usual -- and its rotated Gram matrix (which ttr_rotgram did not write) is never read
+  const int32_t* skip_items;
+  const T* sigma_in;
+  int64_t stride_sigma_in;
   const int32_t* skip_flag;  // != 0 on the device: the driver has converged, the launch returns at once
   int32_t* rot_count;        // incremented once per problem that rotated anything (the driver's "a whole sweep found nothing")
 };
@@ -98,6 +104,21 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const int tid = threadIdx.x;
   const int64_t bt = blockIdx.x;
   const int n = p.n;
+  if (p.skip_items && p.skip_items[bt] != 0) {  // (block-uniform) pass-through item, see EighArgs
+    T* __restrict__ Vo = p.V + bt * p.strideV;
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int i = idx / n, j = idx - i * n;
+      Vo[(int64_t)i * p.ldv + j] = (i == j) ? T(1) : T(0);
+    }
+    const T* __restrict__ si = p.sigma_in + bt * p.stride_sigma_in;
+    for (int i = tid; i < n; i += kThreads) p.sigma[bt * p.stride_sigma + i] = si[i];
+    if (tid == 0) {
+      const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
+      p.info[bt] = si[0] < T(1e-13) ? 0 : (int)(cap < 1 ? 1 : cap);  // (only used without delta: batch mode)
+      if (p.sweeps) p.sweeps[bt] = 0;
+    }
+    return;
+  }
   const int ld = n + 1;
   const int ne = n + (n & 1);  // even number of players (phantom index n if n is odd)
   const int np = ne / 2;
@@ -1004,12 +1025,16 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
                       int64_t stride_gpart, void* V,
                       int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                       int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                      int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr) {
+                      int64_t ws_bytes, hipStream_t stream, const double* delta2_dev = nullptr,
+                      const int32_t* skip_items = nullptr, const void* sigma_in = nullptr, int64_t stride_sigma_in = 0) {
   const int64_t nmax = eigh_max_n(dtype);
   TTR_REQUIRE(n >= 1 && n <= nmax, TTR_E_UNSUPPORTED, "ttr_eigh_trunc: n = %lld outside [1, %lld]", (long long)n,
               (long long)nmax);
   EighArgs<T> p{};
   p.delta2_dev = delta2_dev;
+  p.skip_items = skip_items; p.sigma_in = (const T*)sigma_in; p.stride_sigma_in = stride_sigma_in;
+  TTR_REQUIRE(!skip_items || (sigma_in && !use_delta && !(abs_floor == TTR_SOLVER_TRIDIAG && n <= 64)), TTR_E_INVALID,
+              "ttr_eigh_trunc: skip_items needs sigma_in, use_delta = 0 and a Jacobi solver");
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
   p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
@@ -1056,12 +1081,15 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                   int64_t stride_gpart, void* V,
                   int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int eig_mode,
                   int use_delta, double delta2, int64_t rmax, int abs_floor, int32_t* sweeps, void* ws,
-                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev) {
+                  int64_t ws_bytes, hipStream_t stream, const double* delta2_dev, const int32_t* skip_items,
+                  const void* sigma_in, int64_t stride_sigma_in) {
   if (dtype == TTR_F32)
     return eigh_typed<float>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
+                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev, skip_items, sigma_in,
+                             stride_sigma_in);
   return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
-                            use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev);
+                            use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev, skip_items, sigma_in,
+                            stride_sigma_in);
 }
 
 int g_bj_inner_sweeps = 1;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS); measured on C3's share: 1 -> 72 ms, 2 -> 82, 3 -> 90, until converged -> 97

@@ -32,6 +32,7 @@ struct SweepArgs {
   // rowgram / rotgram
   T* G;             // [batch][nsplit][R][R]
   int nsplit;
+  const int32_t* skip;  // optional [batch]: != 0 -> this item's workgroups return at once (its G is not written)
   // project
   const T* V2;      // R x R (columns = directions), first ro used
   int64_t ldv2, strideV2;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
   T* Vl = smem;  // V1 as [k][row], zero padded to 64 x 64
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
   const int64_t b = blockIdx.y;
+  if (p.skip && p.skip[b] != 0) return;  // (block-uniform) pass 2 is not needed for this item: see ttr_spectrum_flat
   const int split = blockIdx.x;
   const T* __restrict__ Mp = p.M + b * p.strideM;
   const int R = p.R;
@@ -670,8 +672,9 @@ int sweep_gram_parts(int64_t n, int64_t batch) { return pick_split(n, batch); }
 
 template <typename T>
 static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM, const void* V1,
-                      int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream) {
+                      int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream, const int32_t* skip) {
   SweepArgs<T> p{};
+  p.skip = skip;
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.G = (T*)G; p.nsplit = (int)nsplit;
@@ -682,6 +685,7 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
     q.M = p.M + b0 * strideM;
     if (V1) q.V1 = p.V1 + b0 * strideV1;
     q.G = p.G + b0 * nsplit * R * R;
+    if (skip) q.skip = skip + b0;
     const dim3 grid((unsigned)nsplit, (unsigned)nb);
     if (V1) hipLaunchKernelGGL((rotgram_kernel<T, false>), grid, dim3(kThreads), 0, stream, q);
     else hipLaunchKernelGGL((rotgram_kernel<T, true>), grid, dim3(kThreads), 0, stream, q);
@@ -691,12 +695,13 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
 }
 
 int sweep_gram_dispatch(int dtype, int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
-                        const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream) {
+                        const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream,
+                        const int32_t* skip) {
   TTR_REQUIRE(R >= 1 && R <= 64, TTR_E_UNSUPPORTED, "ttr_rowgram / ttr_rotgram: %lld rows (the fused kernels hold <= 64)",
               (long long)R);
   TTR_REQUIRE(nsplit >= 1 && nsplit <= 65535, TTR_E_INVALID, "ttr_rowgram / ttr_rotgram: bad split %lld", (long long)nsplit);
-  if (dtype == TTR_F32) return gram_typed<float>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream);
-  return gram_typed<double>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream);
+  if (dtype == TTR_F32) return gram_typed<float>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip);
+  return gram_typed<double>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip);
 }
 
 template <typename T>
