@@ -357,7 +357,7 @@ int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
 int64_t ttr_colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch);
 int ttr_colgram(int dtype, int64_t rows, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* workspace, int64_t workspace_bytes,
-                void* stream);
+                const int32_t* skip /* optional [batch], as ttr_rotgram's */, void* stream);
 int ttr_colproject(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch,
                    const void* M, int64_t ldm, int64_t strideM,
                    const void* V1, int64_t ldv1, int64_t strideV1,

@@ -125,7 +125,7 @@ _SIGNATURES = {
     "ttr_colgram_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_colgram": (
         c_int,
-        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p],
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "ttr_colproject": (
         c_int,
@@ -723,7 +723,7 @@ def colsweep_fused_ok(M: torch.Tensor) -> bool:
 
 
 @_on_device
-def colgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
+def colgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[batch, n, n] = M^T M (V1 None) or (M V1)^T (M V1) for a tall M [batch, rows, n], n <= 64 (ttr_colgram)."""
     L = lib()
     dt = dtype_code(M.dtype)
@@ -740,7 +740,8 @@ def colgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert V1.shape == (batch, n, n)
         v1p = V1.data_ptr()
     _check(L.ttr_colgram(dt, rows, n, batch, M.data_ptr(), ldm, sM, v1p, ldv, sV, G.data_ptr(),
-                         ws.data_ptr() if ws is not None else None, wsb, _stream()), "ttr_colgram")
+                         ws.data_ptr() if ws is not None else None, wsb, skip.data_ptr() if skip is not None else None,
+                         _stream()), "ttr_colgram")
     return G
 
 

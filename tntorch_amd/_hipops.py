@@ -408,9 +408,11 @@ def truncate(
         # carry (r / n of its size) is written -- no rotated copy of the input.
         V1 = None
         if algorithm == "svd":
-            V1, _, _ = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
-            V, sig, info = _hip.eigh_trunc(_hip.colgram(M, V1), _hip.EIG_RAW, use_delta, delta2, cap,
-                                           abs_floor=_hip.SOLVER_JACOBI_LIVE)
+            V1, sig1, _ = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR) if (batch and FLAT_SPECTRUM_THR > 0) else None
+            V, sig, info = _hip.eigh_trunc(_hip.colgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
+                                           abs_floor=_hip.SOLVER_JACOBI_LIVE,
+                                           skip_items=flat, sigma_in=sig1 if flat is not None else None)  # (as the row sweep above)
         else:
             V, sig, info = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG)

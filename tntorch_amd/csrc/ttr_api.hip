@@ -311,7 +311,8 @@ int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t 
 
 int64_t colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch);
 int colgram_dispatch(int dtype, int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
-                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream);
+                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream,
+                     const int32_t* skip = nullptr);
 int colproject_dispatch(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
                         int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
                         int64_t strideV2, const void* sigma, int64_t stride_sigma, int left_ortho, void* left, int64_t ldl,
@@ -670,13 +671,13 @@ int64_t ttr_colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t 
 
 int ttr_colgram(int dtype, int64_t rows, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* workspace, int64_t workspace_bytes,
-                void* stream) {
+                const int32_t* skip, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_colgram: bad dtype %d", dtype);
   TTR_REQUIRE(rows >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_colgram: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && G, TTR_E_INVALID, "ttr_colgram: null pointer");
   return colgram_dispatch(dtype, rows, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, workspace, workspace_bytes,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, skip);
 }
 
 int ttr_colproject(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t batch, const void* M, int64_t ldm,

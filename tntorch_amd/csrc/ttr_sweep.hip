@@ -344,6 +344,7 @@ struct ColArgs {
   int64_t ldv1, strideV1;
   T* G;        // [batch][nsplit][n][n]
   int nsplit;
+  const int32_t* skip;  // optional [batch]: != 0 -> the item's workgroups return at once (colgram; see ttr_spectrum_flat)
   const T* V2;
   int64_t ldv2, strideV2;
   const T* sigma;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
   T* Vl = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
   const int64_t b = blockIdx.y;
+  if (p.skip && p.skip[b] != 0) return;
   const int split = blockIdx.x;
   const T* __restrict__ Mp = p.M + b * p.strideM;
   const int n = p.n;
@@ -581,7 +583,7 @@ int64_t colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batc
 template <typename T>
 static int colgram_typed(int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
                          const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const int32_t* skip) {
   const int sp = col_split(rows, batch);
   TTR_REQUIRE(sp == 1 || (ws && ws_bytes >= (int64_t)sp * batch * n * n * (int64_t)sizeof(T)), TTR_E_WORKSPACE,
               "ttr_colgram: workspace too small");
@@ -596,6 +598,7 @@ static int colgram_typed(int64_t rows, int64_t n, int64_t batch, const void* Mx,
     q.M = p.M + b0 * strideM;
     if (V1) q.V1 = p.V1 + b0 * strideV1;
     q.G = p.G + b0 * sp * n * n;
+    q.skip = skip ? skip + b0 : nullptr;
     const dim3 grid((unsigned)sp, (unsigned)nb);
     if (V1) hipLaunchKernelGGL((colgram_kernel<T, true>), grid, dim3(kThreads), 0, stream, q);
     else hipLaunchKernelGGL((colgram_kernel<T, false>), grid, dim3(kThreads), 0, stream, q);
@@ -610,10 +613,11 @@ static int colgram_typed(int64_t rows, int64_t n, int64_t batch, const void* Mx,
 }
 
 int colgram_dispatch(int dtype, int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
-                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                     const void* V1, int64_t ldv1, int64_t strideV1, void* G, void* ws, int64_t ws_bytes, hipStream_t stream,
+                     const int32_t* skip) {
   TTR_REQUIRE(n >= 1 && n <= 64, TTR_E_UNSUPPORTED, "ttr_colgram: %lld columns (the fused kernels hold <= 64)", (long long)n);
-  if (dtype == TTR_F32) return colgram_typed<float>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream);
-  return colgram_typed<double>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream);
+  if (dtype == TTR_F32) return colgram_typed<float>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream, skip);
+  return colgram_typed<double>(rows, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, ws, ws_bytes, stream, skip);
 }
 
 template <typename T>
