@@ -327,9 +327,9 @@ int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
  * When is the second pass needed?  The first Gram matrix G = M M^T carries sigma_i^2 with an ABSOLUTE error of c eps sigma_1^2
  * (c: a small constant of the fp32 accumulation), i.e. sigma_i and the unit norm of row i of `right` to c eps (sigma_1 /
  * sigma_i)^2 / 2: the second pass exists for kept singular values far below sigma_1.  When the `keep` kept ones lie within
- * a factor 1 / thr of each other (thr = 0.25: 8 c eps -- measured: right-orthonormality 2.4e-7 after one pass against
- * 3.4e-7 after two at sigma_keep = 0.25 sigma_1, CPU emulation in DESIGN.md), one pass already is in the accuracy class
- * of the two.  ttr_spectrum_flat writes flat[b] = (sigma[b][keep - 1] >= thr * sigma[b][0] > 0) from pass 1's sigma (sorted
+ * a factor 1 / thr of each other (the host shim uses thr = 1/8; measured with the kernels' accumulation order emulated
+ * on the CPU: right-orthonormality 8e-7 / relative sigma error 4e-7 after one pass against 4e-7 / 2e-7 after two at
+ * sigma_keep = sigma_1 / 8), one pass already is in the accuracy class of the two.  ttr_spectrum_flat writes flat[b] = (sigma[b][keep - 1] >= thr * sigma[b][0] > 0) from pass 1's sigma (sorted
  * decreasing); ttr_rotgram skips items with skip[b] != 0 (their G is not written) and ttr_eigh_trunc passes them through
  * (`skip_items`: V = I, sigma = sigma_in, rank rule without delta).  Only meaningful without delta (batch mode:
  * round.py:149-150), where the rank does not depend on the small singular values.

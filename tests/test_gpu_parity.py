@@ -1173,7 +1173,7 @@ def test_eps_mode_without_rank_readbacks(dt, eps, alg, monkeypatch):
 
 
 def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
-    """Batch-mode 'svd' truncation: an item whose KEPT singular values lie within a factor 4 of each other is decided by the
+    """Batch-mode 'svd' truncation: an item whose KEPT singular values lie within a factor 8 (here: 4) of each other is decided by the
     first Gram pass alone (ttr_spectrum_flat; the second pass exists for kept singular values far below sigma_1).  On the
     metric's shape (flat bonds: sigma_32 / sigma_1 ~ 0.7 on five of seven) the shortcut must (a) really trigger, (b) agree
     with the full two-pass result to 5e-6 (measured 2.8e-6; either is 8.5e-6 from the oracle), (c) stay inside the parity
