@@ -428,16 +428,25 @@ def truncate(
             _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
         return Truncation(left, None, right, r, info=info)
 
+    one_pass = None
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
-        if left_side:
-            G = _hip.gemm(M, M, transB=True)
-            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG, prerotation=True)
+        G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+        # Batch mode: pass 1 is run to full accuracy and, when EVERY item's kept singular values lie within 1 / FLAT_SPECTRUM_THR
+        # of each other, it is the answer (see the fused path above) -- the rotation GEMM, the second Gram matrix and the
+        # second eigenproblem, i.e. two of the three passes over M, are not enqueued at all.  The decision concerns launches
+        # on the host, hence one flag readback per such bond (dense batches: BASELINE config C3; the bonds of a TT-to-TT
+        # rounding have <= 64 rows and decide per item on the device).  Otherwise pass 1 is a pre-rotation.
+        try_flat = batch and FLAT_SPECTRUM_THR > 0
+        V1, sig1, info1 = _eigh_any(G, _hip.EIG_RAW, False, 0.0, cap if try_flat else k, _hip.SOLVER_TRIDIAG,
+                                    prerotation=not try_flat)
+        if try_flat and int(_hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR).amin().item()) == 1:
+            one_pass = (V1, sig1, info1)
+            V1, Mw = None, M
+        elif left_side:
             Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
             G = _hip.gemm(Mw, Mw, transB=True)
         else:
-            G = _hip.gemm(M, M, transA=True)
-            V1, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, k, _hip.SOLVER_TRIDIAG, prerotation=True)
             if scratch_ok and M.is_contiguous() and M.numel() * M.element_size() > _INPLACE_ROTATE_BYTES:
                 # config-scale carries (C1 class: tens of GiB): every row of M V1 depends on the same row of M only, so
                 # the rotation runs chunk by chunk into a bounded buffer that is copied back over its source rows
@@ -457,8 +466,11 @@ def truncate(
     # 'eig' (and pass 1 above): absolute accuracy is all a plain Gram matrix carries -> tridiagonal QL solver;
     # pass 2 of 'svd': graded, accurately formed Gram matrix -> Jacobi (relative accuracy of the small sigmas)
     # (problems above the LDS limit go through the block-Jacobi driver in either pass: absolute accuracy)
-    V, sig, info = _eigh_any(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
-                             _hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_LIVE)
+    if one_pass is not None:
+        V, sig, info = one_pass
+    else:
+        V, sig, info = _eigh_any(G, _hip.EIG_REF if ref_clamp else _hip.EIG_RAW, use_delta, delta2, cap,
+                                 _hip.SOLVER_TRIDIAG if algorithm == "eig" else _hip.SOLVER_JACOBI_LIVE)
     # 'svd': kept directions whose sigma lies below the resolution of the input (k eps sigma_max) carry rounding
     # noise only; LAPACK's V is orthonormal there too (round.py:96), so they get an orthonormal completion
     # (ttr_orth_fixup; a per-item early exit when there are none -- the normal case)
