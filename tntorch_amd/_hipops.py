@@ -745,6 +745,9 @@ _SIDE_STREAMS: dict = {}
 def _stream_chunks(Bt: int, batch: bool) -> int:
     if not (batch and STREAM_CHUNKS_ENABLED):
         return 1
+    forced = os.environ.get("TTR_STREAM_CHUNKS")  # (experiments)
+    if forced:
+        return max(1, min(int(forced), Bt))
     return 2 if Bt >= 128 else 1  # (4 streams measured between -7 % and +7 % from box to box, 2 streams -5 % always)
 
 
