@@ -501,6 +501,22 @@ def main():
                     return t
                 el, _, _ = timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)
                 extras[label] = {"tensors_per_step": Bx, "ms_per_step": el / st * 1e3, "cores_per_s": Bx * N_CORES * st / el}
+            if B == 2048:
+                # a larger resident batch (26 GB of cores): what the headline's B leaves on the table (tail effects of the
+                # launches; the gather of an N > 1 job grows with it)
+                try:
+                    big = make_input(2 * B, dev, seed=4321)
+
+                    def bstep(big=big):
+                        t = tn.Tensor(big, batch=True)
+                        t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+                        return t
+                    el, _, _ = timed_steps(bstep, lambda: None, torch.cuda.synchronize, 2, 5)
+                    extras["batch_4096"] = {"tensors_per_step": 2 * B, "ms_per_step": el / 5 * 1e3, "cores_per_s": 2 * B * N_CORES * 5 / el}
+                    del big
+                except Exception as e:  # noqa: BLE001
+                    extras["batch_4096"] = {"error": repr(e)[:200]}
+                torch.cuda.empty_cache()
             res["extras"] = extras
         if world == 1 and not args.no_extras and not args.no_configs:
             # BASELINE's other configs (C1 .. C4), one entry each: time, SURVEY 8d flops / bytes, roofline fraction, CPU

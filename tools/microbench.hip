@@ -156,7 +156,134 @@ static void run_mfma64() {
   hipFree(out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-local Householder QR of a 64 x 16 panel held in the MFMA accumulator layout (lane = 16 g + cl holds rows
+// 16 tm + 4 g + r of column cl in c[tm][r]) -- the level-1 chain of the in-block TSQR the round-2 review proposed for
+// qr_factor_kernel.  Per step: the reflector is broadcast inside each 16-lane row with
+// row_newbcast, the dot products run as 16 FMAs per lane, the four row groups are combined with v_permlane32/16_swap, larfg
+// on wave-uniform scalars, 16 FMAs for the update; finished R rows leave the working set (Rsave).  `q` prints cycles per
+// 16-step panel for 1 / 2 / 4 waves per SIMD and checks R^T R = A^T A.
+template <int J>
+__device__ __forceinline__ void panel_step(float (&c)[4][4], float (&Rsave)[4], float& colsc, float& coltau, int cl, int g) {
+  constexpr int g0 = J >> 2, r0 = J & 3;
+  const bool ing0 = g == g0;
+  const float xm = ing0 ? 0.f : c[0][r0];
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+  float xb[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x = (tm == 0 && r == r0) ? xm : c[tm][r];
+      xb[tm][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + J, 0xF, 0xF, false));
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d0 = fmaf(xb[0][r], c[0][r], d0); d1 = fmaf(xb[1][r], c[1][r], d1);
+    d2 = fmaf(xb[2][r], c[2][r], d2); d3 = fmaf(xb[3][r], c[3][r], d3);
+  }
+  float d = (d0 + d1) + (d2 + d3);
+  float e = ing0 ? c[0][r0] : 0.f;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto allred = [](float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u32x2 s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+    u = __builtin_bit_cast(unsigned, v);
+    s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  };
+  d = allred(d);
+  e = allred(e);
+  const float ss = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), J));
+  const float alpha = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), J));
+  float beta = alpha, tau = 0.f, sc = 0.f;
+  if (ss != 0.f) {
+    beta = -copysignf(__builtin_amdgcn_sqrtf(alpha * alpha + ss), alpha);
+    tau = (beta - alpha) * __builtin_amdgcn_rcpf(beta);
+    sc = __builtin_amdgcn_rcpf(alpha - beta);
+  }
+  const float f = tau * fmaf(sc, d, e);
+  const float nfs = cl > J ? -f * sc : 0.f, nf = cl > J ? -f : 0.f;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[tm][r] = fmaf(xb[tm][r], nfs, c[tm][r]);
+  if (ing0) {
+    if (cl > J) { Rsave[r0] = c[0][r0] + nf; c[0][r0] = 0.f; }
+    else if (cl == J) { Rsave[r0] = beta; c[0][r0] = 0.f; }
+  }
+  if (cl == J) { colsc = sc; coltau = tau; }
+}
+
+__global__ void panel_qr_kernel(const float* __restrict__ A, float* __restrict__ Rout, long long* cyc, int panels) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 15, g = lane >> 4;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
+  float c[4][4], Rs[4] = {0.f, 0.f, 0.f, 0.f}, colsc = 0.f, coltau = 0.f, chk = 0.f;
+  const long long t0 = clock64();
+  for (int pnl = 0; pnl < panels; ++pnl) {
+    const float* __restrict__ Ap = A + ((size_t)wid * panels + pnl) * 1024;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[tm][r] = Ap[(16 * tm + 4 * g + r) * 16 + cl];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rs[r] = 0.f;
+    panel_step<0>(c, Rs, colsc, coltau, cl, g); panel_step<1>(c, Rs, colsc, coltau, cl, g);
+    panel_step<2>(c, Rs, colsc, coltau, cl, g); panel_step<3>(c, Rs, colsc, coltau, cl, g);
+    panel_step<4>(c, Rs, colsc, coltau, cl, g); panel_step<5>(c, Rs, colsc, coltau, cl, g);
+    panel_step<6>(c, Rs, colsc, coltau, cl, g); panel_step<7>(c, Rs, colsc, coltau, cl, g);
+    panel_step<8>(c, Rs, colsc, coltau, cl, g); panel_step<9>(c, Rs, colsc, coltau, cl, g);
+    panel_step<10>(c, Rs, colsc, coltau, cl, g); panel_step<11>(c, Rs, colsc, coltau, cl, g);
+    panel_step<12>(c, Rs, colsc, coltau, cl, g); panel_step<13>(c, Rs, colsc, coltau, cl, g);
+    panel_step<14>(c, Rs, colsc, coltau, cl, g); panel_step<15>(c, Rs, colsc, coltau, cl, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rout[((size_t)wid * panels + pnl) * 256 + (4 * g + r) * 16 + cl] = Rs[r];
+    chk += colsc + coltau + c[1][0];
+  }
+  const long long t1 = clock64();
+  if (lane == 0) cyc[wid] = t1 - t0;
+  if (chk == 12345.678f) Rout[0] = chk;
+}
+
+static void run_panel_qr() {
+  const int panels = 64;
+  for (int wps = 1; wps <= 4; wps *= 2) {  // waves per SIMD: one block of 256 * wps threads per CU
+    const int blocks = 256, wpb = 4 * wps, waves = blocks * wpb;
+    const size_t na = (size_t)waves * panels * 1024;
+    float* hA = (float*)malloc(na * sizeof(float));
+    unsigned st = 12345u;
+    for (size_t i = 0; i < na; ++i) { st = st * 1664525u + 1013904223u; hA[i] = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+    float *A, *R; long long* cyc;
+    hipMalloc(&A, na * sizeof(float)); hipMalloc(&R, (size_t)waves * panels * 256 * sizeof(float)); hipMalloc(&cyc, waves * sizeof(long long));
+    hipMemcpy(A, hA, na * sizeof(float), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(panel_qr_kernel, dim3(blocks), dim3(64 * wpb), 0, 0, A, R, cyc, panels);
+    hipLaunchKernelGGL(panel_qr_kernel, dim3(blocks), dim3(64 * wpb), 0, 0, A, R, cyc, panels);
+    hipDeviceSynchronize();
+    long long* hc = (long long*)malloc(waves * sizeof(long long));
+    float* hR = (float*)malloc((size_t)panels * 256 * sizeof(float));
+    hipMemcpy(hc, cyc, waves * sizeof(long long), hipMemcpyDeviceToHost);
+    hipMemcpy(hR, R, (size_t)panels * 256 * sizeof(float), hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < waves; ++i) avg += (double)hc[i]; avg /= waves;
+    // check wave 0, panel 0: R^T R = A^T A, R upper triangular
+    double err = 0, nrm = 0, low = 0;
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) {
+        double ata = 0, rtr = 0;
+        for (int k = 0; k < 64; ++k) ata += (double)hA[k * 16 + i] * hA[k * 16 + j];
+        for (int k = 0; k < 16; ++k) rtr += (double)hR[k * 16 + i] * hR[k * 16 + j];
+        err = fmax(err, fabs(ata - rtr)); nrm = fmax(nrm, fabs(ata));
+        if (i > j) low = fmax(low, fabs((double)hR[i * 16 + j]));
+      }
+    printf("{\"microbench\": \"wave-local 64x16 Householder panel (16 steps, DPP row_newbcast + permlane swaps)\", \"waves_per_simd\": %d, "
+           "\"cycles_per_panel\": %.0f, \"cycles_per_step\": %.0f, \"RtR_minus_AtA_rel\": %.2e, \"below_diagonal_max\": %.1e}\n",
+           wps, avg / panels, avg / panels / 16, err / nrm, low);
+    hipFree(A); hipFree(R); hipFree(cyc); free(hA); free(hc); free(hR);
+  }
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'q') { run_panel_qr(); return 0; }
   if (argc > 1 && argv[1][0] == 'm') { run_mfma(); return 0; }
   if (argc > 1 && argv[1][0] == 'd') { run_mfma64(); return 0; }
   run<0>("v_fma_f32 x8 independent", 8);
