@@ -56,16 +56,27 @@ __global__ void rate_kernel(float* out, long long* cyc, int iters) {
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// Sum of lane l and its partner through a half exchange.  Written as inline asm because hipcc (ROCm 7.2) miscompiles
+// __builtin_amdgcn_permlane{16,32}_swap(a, a): it copies a into a second register, swaps, and then adds the FIRST result to
+// itself (v_mov v2, v1 ; v_permlane32_swap v1, v2 ; v_add_f32 v1, v1, v1) -- the copy is still treated as equal to its
+// source after the swap, also when the copy is hidden behind an empty asm.  Distinct operands compile correctly.
+__device__ __forceinline__ float swap32_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float swap16_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 // lane-exchange semantics: out[0][l] = row_newbcast<5>, out[1][l] = permlane16-swap sum, out[2][l] = permlane32-swap sum
 __global__ void xlane_kernel(float* out) {
   const float v = (float)threadIdx.x;
   out[threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x155, 0xF, 0xF, false));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  unsigned a = __builtin_bit_cast(unsigned, v);
-  u32x2 s = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-  out[64 + threadIdx.x] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-  s = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-  out[128 + threadIdx.x] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  out[64 + threadIdx.x] = swap16_sum(v);
+  out[128 + threadIdx.x] = swap32_sum(v);
 }
 
 template <int KIND>
@@ -184,15 +195,7 @@ __device__ __forceinline__ void panel_step(float (&c)[4][4], float (&Rsave)[4], 
   }
   float d = (d0 + d1) + (d2 + d3);
   float e = ing0 ? c[0][r0] : 0.f;
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  auto allred = [](float v) {
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    u32x2 s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    v = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-    u = __builtin_bit_cast(unsigned, v);
-    s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-  };
+  auto allred = [](float v) { return swap16_sum(swap32_sum(v)); };
   d = allred(d);
   e = allred(e);
   const float ss = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), J));
