@@ -183,6 +183,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} was built for ABI version {L.ttr_version()}, this binding expects {ABI_VERSION} "
                 "(include/ttround_hip.h: TTR_ABI_VERSION): rebuild with `python __graft_entry__.py --force`.")
+        # A/B measurements without code changes: TTR_KNOBS="6=0,0=1" calls ttr_debug_set_knob(6, 0), (0, 1) once after loading
+        for item in filter(None, os.environ.get("TTR_KNOBS", "").split(",")):
+            k, v = item.split("=")
+            if L.ttr_debug_set_knob(int(k), int(v)) != 0:
+                raise ValueError(f"TTR_KNOBS: ttr_debug_set_knob({k}, {v}) rejected: " + L.ttr_last_error().decode(errors="replace"))
         _lib = L
     return _lib
 

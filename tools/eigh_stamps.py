@@ -17,7 +17,7 @@ for B in (1, 2048):
         ws = torch.zeros(64, dtype=torch.int64, device="cuda")
         for _ in range(2):
             code = L.ttr_eigh_trunc(_hip.dtype_code(G.dtype), n, B, G.data_ptr(), n, n * n, 1, 0, V.data_ptr(), n, n * n, sig.data_ptr(), n,
-                                    info.data_ptr(), _hip.EIG_RAW, 0, 0.0, 64, _hip.SOLVER_TRIDIAG, None, ws.data_ptr(), 64 * 8, _hip._stream())
+                                    info.data_ptr(), _hip.EIG_RAW, 0, 0.0, None, 64, _hip.SOLVER_TRIDIAG, None, None, None, 0, ws.data_ptr(), 64 * 8, _hip._stream())
             assert code == 0
         torch.cuda.synchronize()
         st = ws.cpu().tolist()
