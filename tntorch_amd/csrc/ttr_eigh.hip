@@ -991,6 +991,539 @@ __global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
   }
 }
 
+// Wilkinson-type shift of a QL sweep: g = d[m] - d[l] + e[l] / (t + sign(t) sqrt(t^2 + 1)),  t = (d[l+1] - d[l]) / (2 e[l]).  Only the
+// convergence rate depends on its accuracy, so fp32 takes the 1-ulp hardware reciprocal / sqrt: the two IEEE divisions and the
+// sqrt are ~30 instructions per sweep on the wave's serial chain.  e[l] is not deflated here (> eps * max(|d|, |e|) of a matrix
+// scaled to max |entry| = 1), so neither reciprocal sees a denormal.
+__device__ __forceinline__ float ql_shift(float dl, float dl1, float dm, float el) {
+  const float t = (dl1 - dl) * __builtin_amdgcn_rcpf(2.0f * el);
+  const float r = __builtin_amdgcn_sqrtf(fmaf(t, t, 1.0f));
+  return dm - dl + el * __builtin_amdgcn_rcpf(t + copysignf(r, t));
+}
+__device__ __forceinline__ double ql_shift(double dl, double dl1, double dm, double el) {
+  const double t = (dl1 - dl) / (2.0 * el);
+  const double r = sqrt(t * t + 1.0);
+  return dm - dl + el / (t + copysign(r, t));
+}
+
+// Two waves per matrix.  A single wave issues one VALU instruction per ~8 clocks whatever its dependencies (tools/microbench:
+// independent and dependent FMA chains both 8.0-8.5; four waves per SIMD: 2.4 per instruction), and at B <= 2048 there are at
+// most two matrices per SIMD -- the one-wave kernel above is bound by the INSTRUCTION COUNT of its single wave (cycle
+// stamps, B = 1 and B = 2048 alike: 163 k tridiagonalisation + 75 k Q formation + 309 k QL recurrence + 96 k rotation replay),
+// not by the chip.  Here the work that does not sit on the recurrence's chain runs on a second wave of the same workgroup:
+//   wave 0   tridiagonalisation, then the QL recurrence on (d, e); each sweep's rotations are published to LDS (two buffers)
+//   wave 1   Q^T = H_{n-2} ... H_0, accumulated FORWARD (X <- (I - V_b T_b^T V_b^T) X for b = 0, 1, ...: block b only needs the
+//            reflectors of the 16 steps wave 0 has just finished, so the Q formation hides under the tridiagonalisation
+//            except for its last block), stored transposed; then it replays the published sweeps on Q's rows.
+// Workgroup barriers are the only synchronisation: one per reflector block, then one per QL sweep (wave 0 arrives after
+// computing sweep s, wave 1 before replaying it, so wave 0 runs at most two sweeps ahead and never overwrites a buffer
+// that is still being replayed); the number of sweeps is data dependent, so every barrier's sweep carries a `done` word.
+template <typename T>
+__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_tridiag2_kernel(EighArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
+  const int64_t bt = blockIdx.x;
+  const int n = p.n;
+  const int ld = n + 1;
+  T* A = reinterpret_cast<T*>(smem_raw);     // [n][ld]  G -> reflectors -> Q -> eigenvectors
+  T* vs = A + n * ld + 3;                    // scratch region of 408 elements:
+  T* wsv = vs + 64;                          //   wave 0: the broadcast arrays v / w of the tridiagonalisation (first 131 elements), then
+  T* cv = wsv + 64;                          //           rotation buffer 0 of the QL phase
+  T* sv = cv + 64;                           //   wave 1: S_b of the Q formation (elements 132 .. 403)
+  int* posv = reinterpret_cast<int*>(sv + 64);  //   epilogue (after the last barrier): sigma, sorted sigma, diag(G), column order, sort positions
+  T* const Sq = vs + 132;                    // [16][17]
+  T* dv = vs + 408;                          // [66] diagonal / eigenvalues   } the QL phase keeps d / e in registers: dv .. ev is
+  T* ev = dv + 66;                           // [66] sub-diagonal             } rotation buffer 1 meanwhile
+  T* tauv = ev + 66;                         // [64]
+  T* Tb = tauv + 64;                         // [16][17] compact-WY factor of a reflector block (Q formation)
+  volatile int* meta = reinterpret_cast<volatile int*>(Tb + 16 * 17);  // [2][4]: m, ilast, done of the sweep in buffer 0 / 1
+
+  const T* __restrict__ G = p.G + bt * p.strideG;
+  // ---- load + scale (both waves)
+  if (n == 64 && p.ldg == 64 && (p.stride_gpart & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
+    typedef T VT __attribute__((ext_vector_type(4)));  // (see the one-wave kernel)
+    for (int it = 0; it < 8; ++it) {
+      const int e = (it * 2 * kWave + tid) * 4;
+      const T* __restrict__ src = G + e;
+      VT acc = *reinterpret_cast<const VT*>(src);
+      int pt = 1;
+      for (; pt + 3 < p.gparts; pt += 4) {
+        const VT x0 = *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
+        const VT x1 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 1) * p.stride_gpart);
+        const VT x2 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 2) * p.stride_gpart);
+        const VT x3 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 3) * p.stride_gpart);
+        acc += x0; acc += x1; acc += x2; acc += x3;  // same summation order as the element-wise loop
+      }
+      for (; pt < p.gparts; ++pt) acc += *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
+      T* dst = &A[(e >> 6) * ld + (e & 63)];
+      dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+    }
+  } else {
+    for (int idx = tid; idx < n * n; idx += 2 * kWave) {
+      const int i = idx / n, j = idx - i * n;
+      T gv = G[(int64_t)i * p.ldg + j];
+      for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
+      A[i * ld + j] = gv;
+    }
+  }
+  __syncthreads();
+  const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);
+  T gmax = T(0);  // (each wave over the whole matrix: the same value in both, no exchange)
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int i = idx / n, j = idx - i * n;
+    gmax = fmax(gmax, fabs(A[i * ld + j]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
+  const T ginv = gmax > T(0) ? T(1) / gmax : T(0);
+  __syncthreads();  // both waves have read the unscaled matrix
+  for (int idx = tid; idx < n * n; idx += 2 * kWave) {
+    const int i = idx / n, j = idx - i * n;
+    A[i * ld + j] *= ginv;
+  }
+  __syncthreads();
+
+#ifdef TTR_EIGH_STAMPS
+  long long* const dbg = reinterpret_cast<long long*>(p.ws);  // diagnostics build: cycle stamps of matrix 0 (wave 0)
+  int dbgi = 0;
+#define TTR_ESTAMP2() do { if (dbg && bt == 0 && tid == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
+#else
+#define TTR_ESTAMP2() do {} while (0)
+#endif
+  TTR_ESTAMP2();
+  T* const rowp = A + lane * ld;
+  constexpr int CH = 8;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  constexpr int kPer16 = 16 / (int)sizeof(T);
+  T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;  // 16-byte aligned (offset arithmetic on the LDS pointer, see above)
+  T* const wsh = vsh + 64;
+  T2* const cs0 = reinterpret_cast<T2*>(vsh);                                // rotation buffers: (c, s) of rotation i at [i + 1]
+  T2* const cs1 = reinterpret_cast<T2*>(dv + ((n * ld + 3 + 408) & 1));
+  const int nblk = (n - 1 + 15) / 16;  // blocks of 16 reflectors (0 for n = 1)
+  T dreg = T(0), ereg = T(0);
+  int total_iter = 0;
+#ifdef TTR_EIGH_STAMPS
+  long long nrot_dbg = 0, qlrec_dbg = 0;
+#endif
+  if (n == 1 && tid == 0) { dv[0] = A[0]; ev[0] = T(0); tauv[0] = T(0); }
+
+  if (wv == 0) {
+    // ---- 1. Householder tridiagonalisation (see the one-wave kernel); a barrier after every block of 16 reflectors
+    for (int k = 0; k + 1 < n; ++k) {
+      const bool below = lane >= k + 2 && lane < n;
+      const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
+      const T x = below ? xr : T(0);
+      const T alpha = lane_get(xr, k + 1);
+      const T xn2 = wave_sum_dpp(x * x);
+      T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
+      if (xn2 != T(0)) {
+        T scale;
+        householder_scalars(alpha, xn2, beta, t, scale);
+        if (below) v = x * scale;
+      }
+      if (lane == 0) { ev[k] = beta; tauv[k] = t; }
+      if (t != T(0)) {
+        const bool act = lane >= k + 1 && lane < n;
+        // v (and below w) are broadcast through two 16-byte aligned LDS arrays: one ds_write per lane, then every lane reads
+        // the values of a chunk of eight columns with two 16-byte broadcast reads -- v_readlane costs one instruction (plus a
+        // hazard slot) per VALUE, 24 per chunk of the rank-2 update.  Chunks start at a multiple of eight at or below k + 1:
+        // v and w are exactly zero in the columns <= k, which are therefore re-written unchanged.
+        vsh[lane] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int j0 = (k + 1) & ~(CH - 1), nfull = n & ~(CH - 1);
+        T pr = 0;
+        {
+          T2 p0 = {T(0), T(0)}, p1 = {T(0), T(0)};  // four chains
+          int j = j0;
+          for (; j < nfull; j += CH) {
+            T a8[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
+            const T4 va = *reinterpret_cast<const T4*>(&vsh[j]), vb = *reinterpret_cast<const T4*>(&vsh[j + 4]);
+            p0 += T2{a8[0], a8[1]} * T2{va[0], va[1]};
+            p1 += T2{a8[2], a8[3]} * T2{va[2], va[3]};
+            p0 += T2{a8[4], a8[5]} * T2{vb[0], vb[1]};
+            p1 += T2{a8[6], a8[7]} * T2{vb[2], vb[3]};
+          }
+          for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) pr += rowp[j] * vsh[j];
+          pr += (p0[0] + p0[1]) + (p1[0] + p1[1]);
+        }
+        pr = act ? pr * t : T(0);
+        const T dot = wave_sum_dpp(pr * v);
+        const T w = pr - T(0.5) * t * dot * v;
+        wsh[lane] = w;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+          // a[j] -= v w_j + w v_j
+          struct Chunk { T a[CH]; T4 v0, v1, w0, w1; };
+          auto load = [&](int jj, Chunk& c) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) c.a[u] = rowp[jj + u];
+            c.v0 = *reinterpret_cast<const T4*>(&vsh[jj]); c.v1 = *reinterpret_cast<const T4*>(&vsh[jj + 4]);
+            c.w0 = *reinterpret_cast<const T4*>(&wsh[jj]); c.w1 = *reinterpret_cast<const T4*>(&wsh[jj + 4]);
+          };
+          const T2 mv = {-v, -v}, mw = {-w, -w};
+          auto proc = [&](int jj, Chunk& c) {
+            T2 r0 = T2{c.a[0], c.a[1]} + mv * T2{c.w0[0], c.w0[1]};
+            T2 r1 = T2{c.a[2], c.a[3]} + mv * T2{c.w0[2], c.w0[3]};
+            T2 r2 = T2{c.a[4], c.a[5]} + mv * T2{c.w1[0], c.w1[1]};
+            T2 r3 = T2{c.a[6], c.a[7]} + mv * T2{c.w1[2], c.w1[3]};
+            r0 += mw * T2{c.v0[0], c.v0[1]};
+            r1 += mw * T2{c.v0[2], c.v0[3]};
+            r2 += mw * T2{c.v1[0], c.v1[1]};
+            r3 += mw * T2{c.v1[2], c.v1[3]};
+            if (act) {
+              rowp[jj + 0] = r0[0]; rowp[jj + 1] = r0[1]; rowp[jj + 2] = r1[0]; rowp[jj + 3] = r1[1];
+              rowp[jj + 4] = r2[0]; rowp[jj + 5] = r2[1]; rowp[jj + 6] = r3[0]; rowp[jj + 7] = r3[1];
+            }
+          };
+          int j = j0;
+          for (; j + 2 * CH <= nfull; j += 2 * CH) {  // sixteen columns per trip: all loads before the first store
+            Chunk ca, cb;
+            load(j, ca);
+            load(j + CH, cb);
+            proc(j, ca);
+            proc(j + CH, cb);
+          }
+          if (j < nfull) {
+            Chunk ca;
+            load(j, ca);
+            proc(j, ca);
+            j += CH;
+          }
+          for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) {
+            const T a1 = rowp[j] - (v * wsh[j] + w * vsh[j]);
+            if (act) rowp[j] = a1;
+          }
+        }
+      }
+      if (below) rowp[k] = v;  // keep the reflector below the sub-diagonal
+      if (lane == k) dv[k] = rowp[k];
+      if (k == n - 2 && lane == n - 1) { dv[n - 1] = rowp[n - 1]; ev[n - 1] = T(0); }  // (before the barrier: wave 1 overwrites A with Q)
+      if ((k & 15) == 15 || k == n - 2) __syncthreads();
+    }
+    TTR_ESTAMP2();
+    TTR_ESTAMP2();
+    // ---- 3. implicit-shift QL on (d, e) in registers (see the one-wave kernel); every sweep is published and replayed by wave 1
+    ereg = (lane < n) ? ev[lane] : T(0);
+    dreg = (lane < n) ? dv[lane] : T(0);
+    T creg = T(1), sreg = T(0);  // rotation i is kept in lane i + 1
+    const T eps = Num<T>::eps();
+    T an = fmax(fabs(dreg), fabs(ereg));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) an = fmax(an, __shfl_xor(an, off, 64));
+    const T floor_abs = eps * an;
+    int sweep = 0;
+    for (int l = 0; l < n; ++l) {
+      for (int iter = 0; iter < 64; ++iter) {
+        // m = first index >= l with a negligible sub-diagonal (n-1 if none)
+        const T dnext = __shfl_down(dreg, 1, 64);
+        bool small = true;
+        if (lane >= l && lane < n - 1) {
+          const T el = fabs(ereg);
+          small = (el <= eps * (fabs(dreg) + fabs(dnext))) || (el <= floor_abs);
+        }
+        unsigned long long mask = __ballot(small && lane >= l);
+        const int m = __ffsll((long long)mask) - 1;  // lanes >= n-1 always report "small"
+        if (m <= l) break;
+        ++total_iter;
+        const T dl = lane_get(dreg, l), el0 = lane_get(ereg, l);
+        T g = ql_shift(dl, lane_get(dreg, l + 1), lane_get(dreg, m), el0);
+        T r;
+        T sn = T(1), cs = T(1), pp = T(0);
+        bool underflow = false;
+        int ilast = l;
+#ifdef TTR_EIGH_STAMPS
+        const long long tq0 = clock64();
+        nrot_dbg += m - l;
+#endif
+        T d_ip1 = lane_get(dreg, m);  // d[i + 1] (not yet touched by this sweep)
+        // Branch-free body, exit tests at the end.  Underflow (givens_norm returns false, rn = 0) needs no repair code: the body
+        // itself stores e[i+1] = rn = 0 and d[i+1] = g = d[i+1] - p_old -- exactly tql2's "d[i+1] -= p, e[m] = 0, abandon the
+        // sweep"; the garbage rotation it records is never replayed (ilast = i + 1) and the carried values die with the sweep.
+        // With the repair on an early exit every carried value went through a copy at the back edge and the rotation took
+        // three branches: 48 instructions; now ~36.
+        int i = m - 1;
+        bool zero;
+        for (;;) {
+          const T e_i = lane_get(ereg, i), d_i = lane_get(dreg, i);  // lanes <= i are untouched by this sweep so far
+          const T f = sn * e_i, b = cs * e_i;
+          T rn, rinv;
+          const bool ok = givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2) (0 in the underflow case), rinv ~ 1 / rn
+          const bool here = lane == i + 1;
+          sn = f * rinv; cs = g * rinv;
+          g = d_ip1 - pp;
+          r = fma(cs, b + b, (d_i - g) * sn);   // (d_i - g) s + 2 c b with 2 b off the chain
+          pp = sn * r;
+          ereg = here ? rn : ereg;                         // e[i + 1]
+          dreg = here ? (ok ? g + pp : g) : dreg;          // d[i + 1]   (underflow: d[i + 1] - p_old, nothing derived from rinv)
+          creg = here ? cs : creg;
+          sreg = here ? sn : sreg;
+          g = fma(cs, r, -b);
+          d_ip1 = d_i;
+          zero = !ok;
+          if (zero) break;
+          if (i == l) break;
+          --i;
+        }
+        if (zero) {
+          if (lane == m) ereg = T(0);
+          underflow = true;
+          ilast = i + 1;
+        } else {  // d_ip1 = d[l] here
+          if (lane == l) { dreg = d_ip1 - pp; ereg = g; }
+          if (lane == m) ereg = T(0);
+        }
+#ifdef TTR_EIGH_STAMPS
+        qlrec_dbg += clock64() - tq0;
+#endif
+        {
+          const int par = sweep & 1;
+          T2* const buf = par ? cs1 : cs0;
+          if (lane < n) buf[lane] = T2{creg, sreg};
+          if (lane == 0) { meta[par * 4 + 0] = m; meta[par * 4 + 1] = ilast; meta[par * 4 + 2] = 0; }
+          __syncthreads();
+          ++sweep;
+        }
+      }
+    }
+    if (lane == 0) meta[(sweep & 1) * 4 + 2] = 1;
+    __syncthreads();
+    if (lane < n) dv[lane] = dreg;  // eigenvalues for the epilogue (wave 1 is past its last replay: buffer 1 is free)
+  } else {
+    // ---- 2. X = Q^T = H_{n-2} ... H_0 on the matrix cores, forward over the reflector blocks:  X <- (I - V_b T_b^T V_b^T) X
+    {
+      using MF = Mfma<T>;
+      using Acc = typename MF::Acc;
+      const int cl = lane & 15;
+      T* const Ss = Sq;  // [16][17] V_b^T V_b; its unused lower-left blocks are the scratch of the T construction
+      constexpr int SLD = 17;
+      auto vb = [&](int row, int c) -> T {  // V[row][c], c = reflector index
+        if (row >= n || c >= n - 1 || row <= c) return T(0);
+        return row == c + 1 ? T(1) : A[row * ld + c];
+      };
+      Acc Z[4][4];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Z[tm][tn][r] = (16 * tm + MF::row(lane, r) == 16 * tn + cl) ? T(1) : T(0);
+      for (int b = 0; b < nblk; ++b) {
+        __syncthreads();  // wave 0 has finished the block's reflectors (columns 16 b .. of A, tauv)
+        const int c0 = 16 * b;
+        {  // S = V_b^T V_b (rows <= c0 of V_b are zero: K starts at the block's first row tile)
+          Acc s4[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+          for (int tm = b; tm < 4; ++tm)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+              const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
+              s4[sI] = MF::mma(a, a, s4[sI]);
+            }
+          const Acc sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ss[MF::row(lane, r) * SLD + cl] = sacc[r];
+        }
+        for (int e = lane; e < 256; e += kWave) {
+          const int i = e >> 4, k = e & 15;
+          Tb[i * SLD + k] = (i == k && c0 + i < n - 1) ? tauv[c0 + i] : T(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 1; h < 16; h <<= 1) {  // T12 = -T11 S12 T22 (see the QR kernel); X = S12 T22 goes to S's lower-left block
+          const int hh = h * h;
+          const int bq = lane / hh, rr2 = lane % hh, i = rr2 / h, jx = rr2 % h;
+          const int o = bq * 2 * h;
+          const bool act = lane < 8 * h;
+          if (act) {
+            T x = T(0);
+#pragma unroll
+            for (int k = 0; k < h; ++k) x += Ss[(o + i) * SLD + o + h + k] * Tb[(o + h + k) * SLD + o + h + jx];
+            Ss[(o + h + i) * SLD + o + jx] = x;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (act) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k < h; ++k) t += Tb[(o + i) * SLD + o + k] * Ss[(o + h + k) * SLD + o + jx];
+            Tb[(o + i) * SLD + o + h + jx] = -t;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // W = V_b^T Z (16 x 64): A[i][k] = V_b[row k][i], B = Z tiles from the accumulators
+        Acc W[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+        for (int tm = b; tm < 4; ++tm)
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) {
+            const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+              // (static register index for Z: tm is a runtime loop variable, so select the tile explicitly)
+              const T zb = tm == 0 ? Z[0][tn][sI] : (tm == 1 ? Z[1][tn][sI] : (tm == 2 ? Z[2][tn][sI] : Z[3][tn][sI]));
+              W[tn] = MF::mma(a, zb, W[tn]);
+            }
+          }
+        // W2 = T_b^T W
+        Acc W2[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+          const T a = Tb[MF::row(lane, sI) * SLD + cl];
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) W2[tn] = MF::mma(a, W[tn][sI], W2[tn]);
+        }
+        // Z -= V_b W2 (row tiles above the block's first row are untouched: V_b is zero there)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          if (tm < b) continue;  // wave-uniform
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) {
+            const T a = -vb(16 * tm + cl, c0 + MF::row(lane, sI));
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // Q[j][i] = X[i][j]: the transposed store (wave 0 no longer reads A: its last access is before the last block's barrier)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * tm + MF::row(lane, r), j = 16 * tn + cl;
+            if (i < n && j < n) A[j * ld + i] = Z[tm][tn][r];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- 3'. replay wave 0's sweeps on the rows of Q (lane = row)
+    for (int s = 0;; ++s) {
+      __syncthreads();
+      const int par = s & 1;
+      if (__builtin_amdgcn_readfirstlane(meta[par * 4 + 2])) break;
+      const int m = __builtin_amdgcn_readfirstlane(meta[par * 4 + 0]);
+      const int ilast = __builtin_amdgcn_readfirstlane(meta[par * 4 + 1]);
+      const T2* const buf = par ? cs1 : cs0;
+      if (lane < n) {
+        T hi = rowp[m];
+        int i = m - 1;
+        for (; i - (CH - 1) >= ilast; i -= CH) {
+          T lo8[CH], o8[CH];
+          T2 cs8[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) { lo8[u] = rowp[i - u]; cs8[u] = buf[i - u + 1]; }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const T c2 = cs8[u][0], s2 = cs8[u][1];
+            const T cl = c2 * lo8[u], sl = s2 * lo8[u];  // off the chain
+            o8[u] = fma(c2, hi, sl);
+            hi = fma(-s2, hi, cl);                        // the chain: one FMA per rotation
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) rowp[i - u + 1] = o8[u];
+        }
+        for (; i >= ilast; --i) {
+          const T lo = rowp[i];
+          const T2 cs2 = buf[i + 1];
+          rowp[i + 1] = cs2[1] * lo + cs2[0] * hi;
+          hi = cs2[0] * lo - cs2[1] * hi;
+        }
+        rowp[ilast] = hi;
+      }
+    }
+  }
+  __syncthreads();
+  TTR_ESTAMP2();
+#ifdef TTR_EIGH_STAMPS
+  if (dbg && bt == 0 && tid == 0) { dbg[dbgi++] = total_iter; dbg[dbgi++] = nrot_dbg; dbg[dbgi++] = qlrec_dbg; dbg[dbgi++] = 0; }
+#endif
+
+  // ---- 4. epilogue: un-scale, clamp / sqrt / sort, permuted write, rank rule (round.py:118-158)
+  T* sig = vs;          // reuse
+  T* sig_sorted = wsv;
+  if (tid < n) {
+    T w = dv[tid] * gmax;
+    if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
+    else { if (!(w > T(0))) w = T(0); }
+    sig[tid] = sqrt(w);
+  }
+  __syncthreads();
+  if (tid < n) {
+    const T si = sig[tid];
+    int pos = 0;
+    for (int j = 0; j < n; ++j) {
+      const T sj = sig[j];
+      pos += (sj > si) || (sj == si && j < tid);
+    }
+    sig_sorted[pos] = si;
+    posv[tid] = pos;
+  }
+  __syncthreads();
+  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
+  if (p.eig_mode == TTR_EIG_MATCH_DIAG) {
+    // Column order for block-Jacobi drivers: the eigenvector of the r-th largest eigenvalue goes to the
+    // column holding the r-th largest diagonal entry of G, so that V -> I as G -> diagonal (no sorting
+    // swaps; this is what makes the outer block iteration converge).
+    int* colof = reinterpret_cast<int*>(sv);
+    if (tid < kWave) cv[tid] = gdiag;
+    __syncthreads();
+    if (tid < n) {
+      int dpos = 0;
+      for (int j = 0; j < n; ++j) {
+        const T dj = cv[j];
+        dpos += (dj > gdiag) || (dj == gdiag && j < tid);
+      }
+      colof[dpos] = tid;
+    }
+    __syncthreads();
+    if (tid < n) {
+      const int c = colof[posv[tid]];
+      posv[tid] = c;
+      sout[c] = sig[tid];
+    }
+    __syncthreads();
+  } else if (tid < n) {
+    sout[tid] = sig_sorted[tid];
+  }
+  T* __restrict__ V = p.V + bt * p.strideV;
+  for (int idx = tid; idx < n * n; idx += 2 * kWave) {
+    const int row = idx / n, j = idx - row * n;
+    V[(int64_t)row * p.ldv + posv[j]] = A[row * ld + j];
+  }
+  if (tid == 0) {
+    int rank;
+    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
+    if (sig_sorted[0] < T(1e-13)) {
+      rank = 0;  // zero guard, round.py:137-145
+    } else if (!p.use_delta) {
+      rank = (int)(cap < 1 ? 1 : cap);
+    } else {
+      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
+      double acc = 0.0;
+      int tail = 0;
+      for (int k = n - 1; k >= 0; --k) {
+        acc += (double)(sig_sorted[k] * sig_sorted[k]);
+        if ((T)acc <= d2) tail = n - k; else break;
+      }
+      int64_t rk = n - tail;
+      if (rk > cap) rk = cap;
+      if (rk < 1) rk = 1;
+      rank = (int)rk;
+    }
+    p.info[bt] = rank;
+    if (p.sweeps) p.sweeps[bt] = total_iter;
+  }
+}
+
+static size_t eigh_tridiag2_lds_bytes(size_t elem, int64_t n) {  // A, 3 pad, 408 scratch, d / e (66 each), tau, T_b, 8 control words
+  return (((size_t)n * (n + 1) + 3 + 408 + 66 * 2 + 64 + 16 * 17 + 8) * elem + 15) & ~size_t(15);
+}
+
+int g_eigh_two_wave = 1;  // ttr_debug_set_knob(TTR_KNOB_EIGH_TWO_WAVE): 1 = two waves per matrix (default), 0 = the one-wave kernel
+
 static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {
   return (((size_t)n * (n + 1) + 3 + 64 * 5 + 66 * 2 + 16 * 17) * elem + 64 * sizeof(int) + 15) & ~size_t(15);
 }
@@ -1047,9 +1580,11 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.abs_floor = abs_floor;
   p.sweeps = sweeps;
   if (abs_floor == TTR_SOLVER_TRIDIAG && n <= 64) {  // tridiagonal QL, one wave per matrix
-    const size_t lds = eigh_tridiag_lds_bytes(sizeof(T), n);
     ProfScope prof(TTR_PROF_EIGH, stream);
-    hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(kWave), lds, stream, p);
+    if (g_eigh_two_wave)
+      hipLaunchKernelGGL(eigh_tridiag2_kernel<T>, dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag2_lds_bytes(sizeof(T), n), stream, p);
+    else
+      hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     return TTR_OK;
   }

@@ -20,7 +20,8 @@ for B in (1, 4, 16, 64):
         t = tn.Tensor(inp, batch=True); t.round_tt(rmax=32); return t
     _hip.prof_enable(True); f(); torch.cuda.synchronize(); prof = _hip.prof_collect(); _hip.prof_enable(False)
     nl = sum(v["launches"] for v in prof.values()); kms = sum(v["ms"] for v in prof.values())
-    print(f"batch=True B={B}: {timeit(f):.3f} ms per call ({nl} library launches, {kms:.3f} ms of kernel time)")
+    print(f"batch=True B={B}: {timeit(f):.3f} ms per call ({nl} library launches, {kms:.3f} ms of kernel time; per kind ms/launches: "
+          + ", ".join(f"{k} {v['ms']:.3f}/{v['launches']}" for k, v in prof.items() if v["launches"]) + ")")
 one = [c[0] for c in bench.make_input(1, torch.device('cuda', 0), 7)]
 def g():
     t = tn.Tensor(one); t.round_tt(rmax=32); return t
