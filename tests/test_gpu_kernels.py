@@ -396,6 +396,30 @@ def test_qr_blocked_rank_deficient(dt):
     assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 2e-5, 1e-12)
 
 
+def test_qr_blocked_perturbs_only_collapsing_panels(monkeypatch):
+    """Full-rank panels are factored as they are (rounds 1-2 added seeded 8-eps noise to every panel); the noise is only
+    drawn for a panel whose projected remainder collapses, and only the collapsing items of the batch receive it."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(21)
+    full = torch.randn(2, 500, 150, generator=g, dtype=torch.float64)
+    deficient = full.clone()
+    deficient[:, :, 100:] = 0.0
+    mixed = torch.stack([full[0], deficient[1]])  # item 0 keeps its rank in every panel, item 1 collapses in panels 2 and 3
+    drawn = []
+    orig = torch.randn
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: (drawn.append(a), orig(*a, **k))[1])
+    Qf, Rf = _hipops.qr(full.cuda())
+    assert not drawn
+    Qm, Rm = _hipops.qr(mixed.cuda())
+    assert drawn
+    monkeypatch.undo()
+    assert torch.equal(Qm[0], Qf[0]) and torch.equal(Rm[0], Rf[0])  # the full-rank item of the mixed batch: bit-identical
+    for Q, R, X in ((Qf, Rf, full), (Qm, Rm, mixed)):
+        Q, R = Q.cpu(), R.cpu()
+        assert (Q.transpose(1, 2) @ Q - torch.eye(150, dtype=torch.float64)).abs().max() < 1e-11
+        assert (Q @ R - X).abs().max() / X.abs().max() < 1e-12
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_krp_contract_and_hadamard(dt):
     """ttr_krp_contract: out[p,q,r] = sum_j T[p,j,q,r] B[j,r] (trailing mode Q = 1, leading mode P = 1, general)."""

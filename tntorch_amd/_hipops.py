@@ -71,39 +71,57 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     Q = torch.empty((Bt, m, n), dtype=A.dtype, device=A.device)
     # Exactly dependent / exactly zero columns (block-structured sums such as t + t have them) leave an exactly
     # zero remainder after the projection; the Householder kernel then completes the panel with unit vectors
-    # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  Every panel therefore gets
-    # a perturbation at the rounding level of its OWN batch item (8 eps * rms(A[b]), seeded, deterministic): zero
-    # remainders become generic directions, which the two projection passes make orthogonal to the finished Q;
-    # A = Q R still holds to O(eps ||A[b]||).  Per item: every item is first brought to ||A[b]|| in [0.5, 1) by an
-    # exact power of two (ttr_pow2_normalize; given back to R at the end), so one delta serves the whole batch and
-    # an item 1e-6 times smaller than its neighbours is not swamped by their noise level.
+    # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  A panel whose remainder
+    # COLLAPSES (some |R_ii| of the projected panel <= 32 eps x that column's norm before the projection) is therefore
+    # redone with a perturbation at the rounding level of its OWN batch item (8 eps * rms(A[b]), seeded, deterministic;
+    # only the collapsing items of the batch receive it): zero remainders become generic directions, which the two
+    # projection passes make orthogonal to the finished Q; A = Q R still holds to O(eps ||A[b]||).  Panels that keep
+    # their rank -- every panel of a full-rank input -- are factored exactly as they are (rounds 1-2 perturbed all of
+    # them).  Per item: every item is first brought to ||A[b]|| in [0.5, 1) by an exact power of two
+    # (ttr_pow2_normalize; given back to R at the end), so one delta serves the whole batch and an item 1e-6 times
+    # smaller than its neighbours is not swamped by their noise level.  The collapse test costs one readback per panel
+    # (control flow; this path only exists for TT ranks above the kernel's 64 columns).
     A, a_exp = _hip.pow2_normalize(A)
-    delta = 8.0 * torch.finfo(A.dtype).eps / math.sqrt(max(1, m * n))
+    eps = torch.finfo(A.dtype).eps
+    delta = 8.0 * eps / math.sqrt(max(1, m * n))
     # (an all-zero item keeps exponent 0: its perturbation is scaled down by 1e-20 -- still generic directions for the
     # panels, the QR kernel factors every block at its own exponent, but R comes back at 1e-28 instead of 1e-8.  A
-    # [Bt]-element mask: the only torch arithmetic here.)
+    # [Bt]-element mask and the [Bt, w] collapse test: the only torch arithmetic here.)
     live = torch.sign(_hip.norm(A.reshape(Bt, -1))).clamp_min(1e-20)
     gen = torch.Generator(device=A.device)
+
+    def factor_panel(W, j0):
+        """BCGS2 step for the (contiguous, overwritten) panel W against Q[:, :, :j0] -> (Q_j, R_jj, R_0j, diag of the projected panel's R)."""
+        if j0 == 0:
+            Qj, Rjj = _hip.qr(W)
+            return Qj, Rjj, None, torch.diagonal(Rjj, dim1=1, dim2=2)
+        Qp = Q[:, :, :j0]
+        C1 = _hip.gemm(Qp, W, transA=True)                 # j0 x w
+        _hip.gemm_axpby(Qp, C1, W, -1.0, 1.0)              # W -= Qp C1
+        Q1, R1 = _hip.qr(W)
+        C2 = _hip.gemm(Qp, Q1, transA=True)
+        _hip.gemm_axpby(Qp, C2, Q1, -1.0, 1.0)             # Q1 -= Qp C2
+        Qj, R2 = _hip.qr(Q1)
+        Rjj = _hip.gemm(R2, R1)
+        _hip.gemm_axpby(C2, R1, C1, 1.0, 1.0)              # C1 += C2 R1
+        return Qj, Rjj, C1, torch.diagonal(R1, dim1=1, dim2=2)
+
     for j0 in range(0, n, pw):
         j1 = min(j0 + pw, n)
         w = j1 - j0
-        W = A[:, :, j0:j1].contiguous()
-        gen.manual_seed(0x5EED + j0)
-        noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
-        eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(), scale=live)
-        _hip.gemm_axpby(noise, eye, W, delta, 1.0)             # W += delta * noise (zero items: += 0)
-        if j0 == 0:
-            Qj, Rjj = _hip.qr(W)
-        else:
-            Qp = Q[:, :, :j0]
-            C1 = _hip.gemm(Qp, W, transA=True)                 # j0 x w
-            _hip.gemm_axpby(Qp, C1, W, -1.0, 1.0)              # W -= Qp C1
-            Q1, R1 = _hip.qr(W)
-            C2 = _hip.gemm(Qp, Q1, transA=True)
-            _hip.gemm_axpby(Qp, C2, Q1, -1.0, 1.0)             # Q1 -= Qp C2
-            Qj, R2 = _hip.qr(Q1)
-            Rjj = _hip.gemm(R2, R1)
-            _hip.gemm_axpby(C2, R1, C1, 1.0, 1.0)              # C1 += C2 R1
+        W0 = A[:, :, j0:j1]
+        cn = torch.diagonal(_hip.gemm(W0, W0, transA=True), dim1=1, dim2=2).clamp_min(0).sqrt()  # column norms [Bt, w]
+        Qj, Rjj, C1, d = factor_panel(W0.contiguous(), j0)
+        collapsed = (d.abs() <= (32.0 * eps) * cn).any(dim=1)
+        if bool(collapsed.any().item()):  # (readback: control flow only)
+            W = W0.contiguous()
+            gen.manual_seed(0x5EED + j0)
+            noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
+            eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(),
+                                   scale=live * collapsed.to(A.dtype))
+            _hip.gemm_axpby(noise, eye, W, delta, 1.0)         # W += delta * noise (zero items: += 0; rank-keeping items: untouched)
+            Qj, Rjj, C1, _ = factor_panel(W, j0)
+        if C1 is not None:
             R[:, :j0, j0:j1] = C1
         Q[:, :, j0:j1] = Qj
         R[:, j0:j1, j0:j1] = Rjj
