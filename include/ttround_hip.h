@@ -433,10 +433,6 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      512-row (8-wave) blocks of the fp32 path (132 KB of LDS in fp64: one block per CU; measured 17 %
  *                      faster on config C2 all the same).  Set it BEFORE any workspace is sized (an A/B switch). */
 #define TTR_KNOB_QR_F64_NW4 5
-/*   TTR_KNOB_EIGH_TWO_WAVE  1 (default) = the tridiagonal eigensolver (n <= 64) runs TWO waves per matrix: wave 0 the
- *                      tridiagonalisation and the QL recurrence, wave 1 the Q formation (hidden under the tridiagonalisation)
- *                      and the replay of the rotations; 0 = the one-wave kernel of rounds 1-2 (A/B runs) */
-#define TTR_KNOB_EIGH_TWO_WAVE 6
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */

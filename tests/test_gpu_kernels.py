@@ -190,7 +190,7 @@ def test_qr_rank_deficient(dt, qr_variant):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("solver", [1, 2])
-@pytest.mark.parametrize("n", [1, 2, 5, 16, 63, 64, 100, 200])
+@pytest.mark.parametrize("n", [1, 2, 5, 16, 17, 18, 33, 49, 63, 64, 100, 200])  # 17, 18, 33, 49: reflector-block boundaries of the two-wave kernel
 def test_eigh(dt, n, solver):
     """solver 1 = Jacobi (LDS up to ~100, L2-resident workspace above), 2 = tridiagonal QL (n <= 64, else Jacobi)."""
     h = _hip()

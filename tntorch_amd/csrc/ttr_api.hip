@@ -324,7 +324,6 @@ extern int g_bj_inner_sweeps;
 extern int g_gemm_big;
 extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
-extern int g_eigh_two_wave;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -804,10 +803,6 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_QR_F64_NW4:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: fp64 block switch %d outside [0, 1]", value);
       g_qr_f64_nw4 = value;
-      return TTR_OK;
-    case TTR_KNOB_EIGH_TWO_WAVE:
-      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: eigensolver switch %d outside [0, 1]", value);
-      g_eigh_two_wave = value;
       return TTR_OK;
     case TTR_KNOB_GEMM_BIG:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: big-tile GEMM switch %d outside [0, 1]", value);

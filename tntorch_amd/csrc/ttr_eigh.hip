@@ -432,22 +432,20 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 }
 
 // ====================================================================================================
-// Tridiagonal QL eigensolver: ONE WAVE per matrix (n <= 64), no workgroup barriers.
+// Tridiagonal QL eigensolver (n <= 64): one workgroup of TWO waves per matrix (see the kernel below).
 // (Measured alternative: vectors / d / e / rotations in registers with v_readlane broadcasts instead of LDS
 // broadcast reads -- 0.81 -> 1.1 ms per launch of 2048 matrices; the LDS broadcast is the cheaper one.)
 //
-// Householder reduction to tridiagonal form, in-place accumulation of Q, implicit-shift QL with the
+// Householder reduction to tridiagonal form, accumulation of Q on the matrix cores, implicit-shift QL with the
 // rotations applied to Q's columns: ~10x fewer flops than cyclic Jacobi (n^3-class constant 4/3+4/3+~3
-// instead of ~50) and no cross-wave synchronisation, so many problems run per CU.  Absolute accuracy
+// instead of ~50), so many problems run per CU.  Absolute accuracy
 // O(eps * ||G||) (LAPACK steqr class): this is the pass-1 / 'eig' solver.  Pass 2 of the 'svd' algorithm
 // needs the relative accuracy of Jacobi on a graded matrix and keeps the Jacobi kernel.
 //   lane = row      for the reduction (symmetric mat-vec, rank-2 update) and for applying QL rotations
-//   lane = column   for forming Q (each lane reduces its own column: no cross-lane reductions)
-// The matrix is scaled by 1/max|G_ii| on load (fp32 Gram matrices of the metric workload reach 1e24, whose
+// The matrix is scaled by 1/max|entry| on load (fp32 Gram matrices of the metric workload reach 1e24, whose
 // squares overflow) and the eigenvalues are scaled back at the end.
-// r = sqrt(f^2 + g^2) and 1/r for the QL rotations.  The recurrence is computed redundantly by all 64 lanes and
-// is ~60 % of the kernel's VALU instructions (PMC: 254 k VALU instructions per 64 x 64 matrix, the kernel is
-// VALU-issue-bound), so fp32 uses the hardware rsq (1 ulp, 3 instructions) instead
+// r = sqrt(f^2 + g^2) and 1/r for the QL rotations.  The recurrence is computed redundantly by all 64 lanes of its wave and
+// sits on the kernel's critical chain, so fp32 uses the hardware rsq (1 ulp, 3 instructions) instead
 // of the IEEE sqrt and divide expansions (~25).
 __device__ __forceinline__ bool givens_norm(float f, float g, float& r, float& rinv) {
   // The matrix is scaled to max |G_ii| = 1, so x cannot overflow; below the normal range (x == 0 included) the rotation is
@@ -488,509 +486,6 @@ __device__ __forceinline__ void householder_scalars(double alpha, double ss, dou
   scale = 1.0 / (alpha - beta);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kWave) void eigh_tridiag_kernel(EighArgs<T> p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  const int64_t bt = blockIdx.x;
-  const int n = p.n;
-  const int ld = n + 1;
-  T* A = reinterpret_cast<T*>(smem_raw);     // [n][ld]  G -> reflectors -> Q -> eigenvectors
-  T* vs = A + n * ld + 3;                    // [64] epilogue scratch (sigma) ...
-  T* wsv = vs + 64;                          // [64] ... (sorted sigma)
-  T* cv = wsv + 64;                          // [64] ... (diagonal of G, TTR_EIG_MATCH_DIAG)
-  T* sv = cv + 64;                           // [64] ... (column order)
-  int* posv = reinterpret_cast<int*>(sv + 64);  // [64] ... (sort positions); vs .. posv together also hold S_b of the Q formation
-  T* dv = reinterpret_cast<T*>(posv + 64);   // [65] diagonal / eigenvalues
-  T* ev = dv + 66;                           // [65] sub-diagonal (ev[i] couples i, i+1)
-  T* tauv = ev + 66;                         // [64]
-  T* Tb = tauv + 64;                         // [16][17] compact-WY factor of a reflector block (Q formation)
-
-  const T* __restrict__ G = p.G + bt * p.strideG;
-  // ---- load + scale
-  if (n == 64 && p.ldg == 64 && (p.stride_gpart & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
-    // a contiguous 64 x 64 matrix (+ split partials, e.g. the 8 per-block Gram partials of ttr_qr_apply_pushed_gram): four
-    // elements per lane and load, the partials' loads of one position issued four at a time -- the element-wise loop below has
-    // one dependent load in flight per lane, which costs 20 us per partial and launch at B = 2048
-    typedef T VT __attribute__((ext_vector_type(4)));
-    for (int it = 0; it < 16; ++it) {
-      const int e = (it * kWave + lane) * 4;
-      const T* __restrict__ src = G + e;
-      VT acc = *reinterpret_cast<const VT*>(src);
-      int pt = 1;
-      for (; pt + 3 < p.gparts; pt += 4) {
-        const VT x0 = *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
-        const VT x1 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 1) * p.stride_gpart);
-        const VT x2 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 2) * p.stride_gpart);
-        const VT x3 = *reinterpret_cast<const VT*>(src + (int64_t)(pt + 3) * p.stride_gpart);
-        acc += x0; acc += x1; acc += x2; acc += x3;  // same summation order as the element-wise loop
-      }
-      for (; pt < p.gparts; ++pt) acc += *reinterpret_cast<const VT*>(src + (int64_t)pt * p.stride_gpart);
-      T* dst = &A[(e >> 6) * ld + (e & 63)];
-      dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
-    }
-  } else {
-    for (int idx = lane; idx < n * n; idx += kWave) {
-      const int i = idx / n, j = idx - i * n;
-      T gv = G[(int64_t)i * p.ldg + j];
-      for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
-      A[i * ld + j] = gv;
-    }
-  }
-  __syncthreads();
-  const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);
-  // scale by the largest |entry| (= the largest diagonal entry for a Gram matrix): afterwards every entry is <= 1 and
-  // ||A||_F <= n, so the squares formed by the QL rotations cannot overflow (their fast path has no range branch)
-  T gmax = T(0);
-  for (int idx = lane; idx < n * n; idx += kWave) {
-    const int i = idx / n, j = idx - i * n;
-    gmax = fmax(gmax, fabs(A[i * ld + j]));
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
-  const T ginv = gmax > T(0) ? T(1) / gmax : T(0);
-  for (int idx = lane; idx < n * n; idx += kWave) {
-    const int i = idx / n, j = idx - i * n;
-    A[i * ld + j] *= ginv;
-  }
-  __syncthreads();
-
-  // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k].
-  // lane = row, and every lane only ever touches ITS OWN row of A here: the reflector v and the vector w stay in
-  // registers (one entry per lane) and are broadcast with v_readlane instead of through LDS arrays, the row is walked in
-  // chunks of eight (loads, arithmetic, stores -- the element-by-element read-modify-write through LDS was serialised at
-  // the full LDS latency by the possible aliasing of A with the broadcast arrays), and the step needs no barrier.
-#ifdef TTR_EIGH_STAMPS
-  long long* const dbg = reinterpret_cast<long long*>(p.ws);  // diagnostics build: cycle stamps of matrix 0
-  int dbgi = 0;
-#define TTR_ESTAMP() do { if (dbg && bt == 0 && lane == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
-#else
-#define TTR_ESTAMP() do {} while (0)
-#endif
-  TTR_ESTAMP();
-  T* const rowp = A + lane * ld;
-  constexpr int CH = 8;
-  typedef T T2 __attribute__((ext_vector_type(2)));
-  typedef T T4 __attribute__((ext_vector_type(4)));
-  // broadcast arrays of the tridiagonalisation (v, w), 16-byte aligned inside the vs .. cv scratch (free until the Q formation)
-  // (offset arithmetic on the LDS pointer: a round trip through uintptr_t loses the address space and turns the reads into flat loads)
-  constexpr int kPer16 = 16 / (int)sizeof(T);
-  T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;
-  T* const wsh = vsh + 64;
-  T2* const csh = reinterpret_cast<T2*>(vsh);  // [64] (c, s) of the QL sweep being replayed (vsh / wsh are free by then)
-  for (int k = 0; k + 1 < n; ++k) {
-    const bool below = lane >= k + 2 && lane < n;
-    const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
-    const T x = below ? xr : T(0);
-    const T alpha = lane_get(xr, k + 1);
-    const T xn2 = wave_sum_dpp(x * x);
-    T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
-    if (xn2 != T(0)) {
-      T scale;
-      householder_scalars(alpha, xn2, beta, t, scale);
-      if (below) v = x * scale;
-    }
-    if (lane == 0) { ev[k] = beta; tauv[k] = t; }
-    if (t != T(0)) {
-      const bool act = lane >= k + 1 && lane < n;
-      // v (and below w) are broadcast through two 16-byte aligned LDS arrays: one ds_write per lane, then every lane reads
-      // the values of a chunk of eight columns with two 16-byte broadcast reads -- v_readlane costs one instruction (plus a
-      // hazard slot) per VALUE, 24 per chunk of the rank-2 update.  Chunks start at a multiple of eight at or below k + 1:
-      // v and w are exactly zero in the columns <= k, which are therefore re-written unchanged.
-      vsh[lane] = v;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int j0 = (k + 1) & ~(CH - 1), nfull = n & ~(CH - 1);
-      T pr = 0;
-      {
-        T2 p0 = {T(0), T(0)}, p1 = {T(0), T(0)};  // four chains
-        int j = j0;
-        for (; j < nfull; j += CH) {
-          T a8[CH];
-#pragma unroll
-          for (int u = 0; u < CH; ++u) a8[u] = rowp[j + u];
-          const T4 va = *reinterpret_cast<const T4*>(&vsh[j]), vb = *reinterpret_cast<const T4*>(&vsh[j + 4]);
-          p0 += T2{a8[0], a8[1]} * T2{va[0], va[1]};
-          p1 += T2{a8[2], a8[3]} * T2{va[2], va[3]};
-          p0 += T2{a8[4], a8[5]} * T2{vb[0], vb[1]};
-          p1 += T2{a8[6], a8[7]} * T2{vb[2], vb[3]};
-        }
-        for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) pr += rowp[j] * vsh[j];
-        pr += (p0[0] + p0[1]) + (p1[0] + p1[1]);
-      }
-      pr = act ? pr * t : T(0);
-      const T dot = wave_sum_dpp(pr * v);
-      const T w = pr - T(0.5) * t * dot * v;
-      wsh[lane] = w;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {
-        // a[j] -= v w_j + w v_j
-        struct Chunk { T a[CH]; T4 v0, v1, w0, w1; };
-        auto load = [&](int jj, Chunk& c) {
-#pragma unroll
-          for (int u = 0; u < CH; ++u) c.a[u] = rowp[jj + u];
-          c.v0 = *reinterpret_cast<const T4*>(&vsh[jj]); c.v1 = *reinterpret_cast<const T4*>(&vsh[jj + 4]);
-          c.w0 = *reinterpret_cast<const T4*>(&wsh[jj]); c.w1 = *reinterpret_cast<const T4*>(&wsh[jj + 4]);
-        };
-        const T2 mv = {-v, -v}, mw = {-w, -w};
-        auto proc = [&](int jj, Chunk& c) {
-          T2 r0 = T2{c.a[0], c.a[1]} + mv * T2{c.w0[0], c.w0[1]};
-          T2 r1 = T2{c.a[2], c.a[3]} + mv * T2{c.w0[2], c.w0[3]};
-          T2 r2 = T2{c.a[4], c.a[5]} + mv * T2{c.w1[0], c.w1[1]};
-          T2 r3 = T2{c.a[6], c.a[7]} + mv * T2{c.w1[2], c.w1[3]};
-          r0 += mw * T2{c.v0[0], c.v0[1]};
-          r1 += mw * T2{c.v0[2], c.v0[3]};
-          r2 += mw * T2{c.v1[0], c.v1[1]};
-          r3 += mw * T2{c.v1[2], c.v1[3]};
-          if (act) {
-            rowp[jj + 0] = r0[0]; rowp[jj + 1] = r0[1]; rowp[jj + 2] = r1[0]; rowp[jj + 3] = r1[1];
-            rowp[jj + 4] = r2[0]; rowp[jj + 5] = r2[1]; rowp[jj + 6] = r3[0]; rowp[jj + 7] = r3[1];
-          }
-        };
-        int j = j0;
-        for (; j + 2 * CH <= nfull; j += 2 * CH) {  // sixteen columns per trip: all loads before the first store
-          Chunk ca, cb;
-          load(j, ca);
-          load(j + CH, cb);
-          proc(j, ca);
-          proc(j + CH, cb);
-        }
-        if (j < nfull) {
-          Chunk ca;
-          load(j, ca);
-          proc(j, ca);
-          j += CH;
-        }
-        for (j = (j < k + 1) ? k + 1 : j; j < n; ++j) {
-          const T a1 = rowp[j] - (v * wsh[j] + w * vsh[j]);
-          if (act) rowp[j] = a1;
-        }
-      }
-    }
-    if (below) rowp[k] = v;  // keep the reflector below the sub-diagonal
-    if (lane == k) dv[k] = rowp[k];
-  }
-  if (lane == n - 1) { dv[n - 1] = rowp[n - 1]; ev[n - 1] = T(0); if (n == 1) tauv[0] = T(0); }
-  __syncthreads();
-
-  TTR_ESTAMP();
-  // ---- 2. Q = H_0 ... H_{n-2} on the matrix cores.  The reflectors (column k of A below the sub-diagonal) are grouped in
-  // blocks of 16: H_{16b} ... H_{16b+15} = I - V_b T_b V_b^T with T_b = (strict_upper(V_b^T V_b) + diag(1/tau))^-1 built by
-  // recursive doubling, and Z <- Z - V_b (T_b (V_b^T Z)) is applied for b = last .. 0 to Z = I, which lives in the wave's
-  // MFMA accumulators (16 tiles): the accumulator registers ARE the B operands of the next product (K-step s of a row
-  // tile = register s of every lane group), V_b is read straight from the reflector storage with its implicit unit /
-  // zeros.  ~150 MFMAs per block instead of two O(n^2) LDS walks per reflector (cycle stamps: 245 k of the kernel's
-  // 1.26 M cycles for n = 64).
-  {
-    using MF = Mfma<T>;
-    using Acc = typename MF::Acc;
-    const int cl = lane & 15;
-    T* const Ss = vs;  // [16][17] V_b^T V_b; its unused lower-left blocks are the scratch of the T construction
-    constexpr int SLD = 17;
-    auto vb = [&](int row, int c) -> T {  // V[row][c], c = reflector index
-      if (row >= n || c >= n - 1 || row <= c) return T(0);
-      return row == c + 1 ? T(1) : A[row * ld + c];
-    };
-    Acc Z[4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Z[tm][tn][r] = (16 * tm + MF::row(lane, r) == 16 * tn + cl) ? T(1) : T(0);
-    const int nblk = (n - 1 + 15) / 16;
-    for (int b = nblk - 1; b >= 0; --b) {
-      const int c0 = 16 * b;
-      {  // S = V_b^T V_b (rows <= c0 of V_b are zero: K starts at the block's first row tile)
-        Acc s4[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
-        for (int tm = b; tm < 4; ++tm)
-#pragma unroll
-          for (int sI = 0; sI < 4; ++sI) {
-            const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
-            s4[sI] = MF::mma(a, a, s4[sI]);
-          }
-        const Acc sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ss[MF::row(lane, r) * SLD + cl] = sacc[r];
-      }
-      for (int e = lane; e < 256; e += kWave) {
-        const int i = e >> 4, k = e & 15;
-        Tb[i * SLD + k] = (i == k && c0 + i < n - 1) ? tauv[c0 + i] : T(0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int h = 1; h < 16; h <<= 1) {  // T12 = -T11 S12 T22 (see the QR kernel); X = S12 T22 goes to S's lower-left block
-        const int hh = h * h;
-        const int bq = lane / hh, rr2 = lane % hh, i = rr2 / h, jx = rr2 % h;
-        const int o = bq * 2 * h;
-        const bool act = lane < 8 * h;
-        if (act) {
-          T x = T(0);
-#pragma unroll
-          for (int k = 0; k < h; ++k) x += Ss[(o + i) * SLD + o + h + k] * Tb[(o + h + k) * SLD + o + h + jx];
-          Ss[(o + h + i) * SLD + o + jx] = x;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (act) {
-          T t = T(0);
-#pragma unroll
-          for (int k = 0; k < h; ++k) t += Tb[(o + i) * SLD + o + k] * Ss[(o + h + k) * SLD + o + jx];
-          Tb[(o + i) * SLD + o + h + jx] = -t;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      // W = V_b^T Z (16 x 64): A[i][k] = V_b[row k][i], B = Z tiles from the accumulators
-      Acc W[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
-      for (int tm = b; tm < 4; ++tm)
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
-          const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn) {
-            // (static register index for Z: tm is a runtime loop variable, so select the tile explicitly)
-            const T zb = tm == 0 ? Z[0][tn][sI] : (tm == 1 ? Z[1][tn][sI] : (tm == 2 ? Z[2][tn][sI] : Z[3][tn][sI]));
-            W[tn] = MF::mma(a, zb, W[tn]);
-          }
-        }
-      // W2 = T_b W
-      Acc W2[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
-#pragma unroll
-      for (int sI = 0; sI < 4; ++sI) {
-        const T a = Tb[cl * SLD + MF::row(lane, sI)];
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) W2[tn] = MF::mma(a, W[tn][sI], W2[tn]);
-      }
-      // Z -= V_b W2 (row tiles above the block's first row are untouched: V_b is zero there)
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-        if (tm < b) continue;  // wave-uniform
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
-          const T a = -vb(16 * tm + cl, c0 + MF::row(lane, sI));
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tm + MF::row(lane, r), col = 16 * tn + cl;
-          if (row < n && col < n) A[row * ld + col] = Z[tm][tn][r];
-        }
-  }
-  __syncthreads();
-
-  TTR_ESTAMP();
-  // ---- 3. implicit-shift QL on (d, e); rotations applied to the columns of Q (lane = row).
-  // The recurrence is one serial chain per matrix (the wave repeats it in all lanes); cycle stamps put it at ~420 cycles
-  // per rotation for ~35 instructions, i.e. it runs at the latency of dependent instructions, LDS waits and branches.
-  // d[k] / e[k] and the recorded rotation (c, s)[k-1] therefore live in REGISTERS, one index per lane: operands are
-  // fetched with v_readlane (uniform index), results are merged with a lane-select -- no LDS access, no wait and no
-  // exec-masked store inside the rotation loop; d[i], d[i+1] are carried from rotation to rotation.
-  T ereg = (lane < n) ? ev[lane] : T(0), dreg = (lane < n) ? dv[lane] : T(0);
-  T creg = T(1), sreg = T(0);  // rotation i is kept in lane i + 1
-  const T eps = Num<T>::eps();
-  T an = fmax(fabs(dreg), fabs(ereg));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) an = fmax(an, __shfl_xor(an, off, 64));
-  const T floor_abs = eps * an;
-  int total_iter = 0;
-#ifdef TTR_EIGH_STAMPS
-  long long nrot_dbg = 0, qlrec_dbg = 0, qlapp_dbg = 0;
-#endif
-  for (int l = 0; l < n; ++l) {
-    for (int iter = 0; iter < 64; ++iter) {
-      // m = first index >= l with a negligible sub-diagonal (n-1 if none)
-      const T dnext = __shfl_down(dreg, 1, 64);
-      bool small = true;
-      if (lane >= l && lane < n - 1) {
-        const T el = fabs(ereg);
-        small = (el <= eps * (fabs(dreg) + fabs(dnext))) || (el <= floor_abs);
-      }
-      unsigned long long mask = __ballot(small && lane >= l);
-      const int m = __ffsll((long long)mask) - 1;  // lanes >= n-1 always report "small"
-      if (m <= l) break;
-      ++total_iter;
-      const T dl = lane_get(dreg, l), el0 = lane_get(ereg, l);
-      T g = (lane_get(dreg, l + 1) - dl) / (T(2) * el0);
-      T r = sqrt(g * g + T(1));
-      g = lane_get(dreg, m) - dl + el0 / (g + copysign(r, g));
-      T sn = T(1), cs = T(1), pp = T(0);
-      bool underflow = false;
-      int ilast = l;
-#ifdef TTR_EIGH_STAMPS
-      const long long tq0 = clock64();
-      nrot_dbg += m - l;
-#endif
-      T d_ip1 = lane_get(dreg, m);  // d[i + 1] (not yet touched by this sweep)
-      // Branch-free body, exit tests at the end.  Underflow (givens_norm returns false, rn = 0) needs no repair code: the body
-      // itself stores e[i+1] = rn = 0 and d[i+1] = g = d[i+1] - p_old -- exactly tql2's "d[i+1] -= p, e[m] = 0, abandon the
-      // sweep"; the garbage rotation it records is never replayed (ilast = i + 1) and the carried values die with the sweep.
-      // With the repair on an early exit every carried value went through a copy at the back edge and the rotation took
-      // three branches: 48 instructions; now ~36.
-      int i = m - 1;
-      bool zero;
-      for (;;) {
-        const T e_i = lane_get(ereg, i), d_i = lane_get(dreg, i);  // lanes <= i are untouched by this sweep so far
-        const T f = sn * e_i, b = cs * e_i;
-        T rn, rinv;
-        const bool ok = givens_norm(f, g, rn, rinv);  // rn = sqrt(f^2 + g^2) (0 in the underflow case), rinv ~ 1 / rn
-        const bool here = lane == i + 1;
-        sn = f * rinv; cs = g * rinv;
-        g = d_ip1 - pp;
-        r = fma(cs, b + b, (d_i - g) * sn);   // (d_i - g) s + 2 c b with 2 b off the chain
-        pp = sn * r;
-        ereg = here ? rn : ereg;                         // e[i + 1]
-        dreg = here ? (ok ? g + pp : g) : dreg;          // d[i + 1]   (underflow: d[i + 1] - p_old, nothing derived from rinv)
-        creg = here ? cs : creg;
-        sreg = here ? sn : sreg;
-        g = fma(cs, r, -b);
-        d_ip1 = d_i;
-        zero = !ok;
-        if (zero) break;
-        if (i == l) break;
-        --i;
-      }
-      if (zero) {
-        if (lane == m) ereg = T(0);
-        underflow = true;
-        ilast = i + 1;
-      } else {  // d_ip1 = d[l] here
-        if (lane == l) { dreg = d_ip1 - pp; ereg = g; }
-        if (lane == m) ereg = T(0);
-      }
-#ifdef TTR_EIGH_STAMPS
-      const long long tq1 = clock64();
-      qlrec_dbg += tq1 - tq0;
-#endif
-      // apply the recorded rotations (i = m-1 .. ilast) to row `lane` of Q, carrying the upper element.  The sweep's
-      // rotations are published once ((c, s) of rotation i sits in lane i + 1: one 8-byte store per lane) and read back as
-      // broadcast pairs -- v_readlane costs two instructions plus hazard slots per rotation and feeds SGPR operands, which
-      // the packed FMAs cannot take in pairs without extra moves.
-      if (lane < n) {  // (lanes >= n own no row: their `rowp` points into the scratch arrays that hold csh)
-        csh[lane] = T2{creg, sreg};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // (chunks of eight: the row elements are loaded ahead and stored behind the dependent chain through `hi`, which
-        // then consists of one FMA per rotation instead of an LDS round trip)
-        T hi = rowp[m];
-        int i = m - 1;
-        for (; i - (CH - 1) >= ilast; i -= CH) {
-          T lo8[CH], o8[CH];
-          T2 cs8[CH];
-#pragma unroll
-          for (int u = 0; u < CH; ++u) { lo8[u] = rowp[i - u]; cs8[u] = csh[i - u + 1]; }
-#pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            const T c2 = cs8[u][0], s2 = cs8[u][1];
-            const T cl = c2 * lo8[u], sl = s2 * lo8[u];  // off the chain
-            o8[u] = fma(c2, hi, sl);
-            hi = fma(-s2, hi, cl);                        // the chain: one FMA per rotation
-          }
-#pragma unroll
-          for (int u = 0; u < CH; ++u) rowp[i - u + 1] = o8[u];
-        }
-        for (; i >= ilast; --i) {
-          const T lo = rowp[i];
-          const T2 cs2 = csh[i + 1];
-          rowp[i + 1] = cs2[1] * lo + cs2[0] * hi;
-          hi = cs2[0] * lo - cs2[1] * hi;
-        }
-        rowp[ilast] = hi;
-      }
-#ifdef TTR_EIGH_STAMPS
-      qlapp_dbg += clock64() - tq1;
-#endif
-    }
-  }
-  __syncthreads();
-  if (lane < n) dv[lane] = dreg;  // eigenvalues for the epilogue
-  __syncthreads();
-  TTR_ESTAMP();
-#ifdef TTR_EIGH_STAMPS
-  if (dbg && bt == 0 && lane == 0) { dbg[dbgi++] = total_iter; dbg[dbgi++] = nrot_dbg; dbg[dbgi++] = qlrec_dbg; dbg[dbgi++] = qlapp_dbg; }
-#endif
-
-  // ---- 4. epilogue: un-scale, clamp / sqrt / sort, permuted write, rank rule (round.py:118-158)
-  T* sig = vs;          // reuse
-  T* sig_sorted = wsv;
-  if (lane < n) {
-    T w = dv[lane] * gmax;
-    if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
-    else { if (!(w > T(0))) w = T(0); }
-    sig[lane] = sqrt(w);
-  }
-  __syncthreads();
-  if (lane < n) {
-    const T si = sig[lane];
-    int pos = 0;
-    for (int j = 0; j < n; ++j) {
-      const T sj = sig[j];
-      pos += (sj > si) || (sj == si && j < lane);
-    }
-    sig_sorted[pos] = si;
-    posv[lane] = pos;
-  }
-  __syncthreads();
-  T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
-  if (p.eig_mode == TTR_EIG_MATCH_DIAG) {
-    // Column order for block-Jacobi drivers: the eigenvector of the r-th largest eigenvalue goes to the
-    // column holding the r-th largest diagonal entry of G, so that V -> I as G -> diagonal (no sorting
-    // swaps; this is what makes the outer block iteration converge).
-    int* colof = reinterpret_cast<int*>(sv);
-    cv[lane] = gdiag;
-    __syncthreads();
-    if (lane < n) {
-      int dpos = 0;
-      for (int j = 0; j < n; ++j) {
-        const T dj = cv[j];
-        dpos += (dj > gdiag) || (dj == gdiag && j < lane);
-      }
-      colof[dpos] = lane;
-    }
-    __syncthreads();
-    if (lane < n) {
-      const int c = colof[posv[lane]];
-      posv[lane] = c;
-      sout[c] = sig[lane];
-    }
-    __syncthreads();
-  } else if (lane < n) {
-    sout[lane] = sig_sorted[lane];
-  }
-  T* __restrict__ V = p.V + bt * p.strideV;
-  for (int idx = lane; idx < n * n; idx += kWave) {
-    const int row = idx / n, j = idx - row * n;
-    V[(int64_t)row * p.ldv + posv[j]] = A[row * ld + j];
-  }
-  if (lane == 0) {
-    int rank;
-    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
-    if (sig_sorted[0] < T(1e-13)) {
-      rank = 0;  // zero guard, round.py:137-145
-    } else if (!p.use_delta) {
-      rank = (int)(cap < 1 ? 1 : cap);
-    } else {
-      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
-      double acc = 0.0;
-      int tail = 0;
-      for (int k = n - 1; k >= 0; --k) {
-        acc += (double)(sig_sorted[k] * sig_sorted[k]);
-        if ((T)acc <= d2) tail = n - k; else break;
-      }
-      int64_t rk = n - tail;
-      if (rk > cap) rk = cap;
-      if (rk < 1) rk = 1;
-      rank = (int)rk;
-    }
-    p.info[bt] = rank;
-    if (p.sweeps) p.sweeps[bt] = total_iter;
-  }
-}
-
 // Wilkinson-type shift of a QL sweep: g = d[m] - d[l] + e[l] / (t + sign(t) sqrt(t^2 + 1)),  t = (d[l+1] - d[l]) / (2 e[l]).  Only the
 // convergence rate depends on its accuracy, so fp32 takes the 1-ulp hardware reciprocal / sqrt: the two IEEE divisions and the
 // sqrt are ~30 instructions per sweep on the wave's serial chain.  e[l] is not deflated here (> eps * max(|d|, |e|) of a matrix
@@ -1008,9 +503,11 @@ __device__ __forceinline__ double ql_shift(double dl, double dl1, double dm, dou
 
 // Two waves per matrix.  A single wave issues one VALU instruction per ~8 clocks whatever its dependencies (tools/microbench:
 // independent and dependent FMA chains both 8.0-8.5; four waves per SIMD: 2.4 per instruction), and at B <= 2048 there are at
-// most two matrices per SIMD -- the one-wave kernel above is bound by the INSTRUCTION COUNT of its single wave (cycle
-// stamps, B = 1 and B = 2048 alike: 163 k tridiagonalisation + 75 k Q formation + 309 k QL recurrence + 96 k rotation replay),
-// not by the chip.  Here the work that does not sit on the recurrence's chain runs on a second wave of the same workgroup:
+// most two matrices per SIMD -- the one-wave kernel of rounds 1-2 (everything below on one wave, Q formed backwards after the
+// tridiagonalisation) was bound by the INSTRUCTION COUNT of its single wave (cycle stamps, B = 1 and B = 2048 alike: 163 k
+// tridiagonalisation + 75 k Q formation + 309 k QL recurrence + 96 k rotation replay = 318 us for one matrix), not by the
+// chip.  Here the work that does not sit on the recurrence's chain runs on a second wave of the same workgroup (255 us;
+// profiles/r03_eigh_two_wave_ab.txt, A/B at commit a699024):
 //   wave 0   tridiagonalisation, then the QL recurrence on (d, e); each sweep's rotations are published to LDS (two buffers)
 //   wave 1   Q^T = H_{n-2} ... H_0, accumulated FORWARD (X <- (I - V_b T_b^T V_b^T) X for b = 0, 1, ...: block b only needs the
 //            reflectors of the 16 steps wave 0 has just finished, so the Q formation hides under the tridiagonalisation
@@ -1019,7 +516,7 @@ __device__ __forceinline__ double ql_shift(double dl, double dl1, double dm, dou
 // computing sweep s, wave 1 before replaying it, so wave 0 runs at most two sweeps ahead and never overwrites a buffer
 // that is still being replayed); the number of sweeps is data dependent, so every barrier's sweep carries a `done` word.
 template <typename T>
-__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_tridiag2_kernel(EighArgs<T> p) {
+__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1043,7 +540,10 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale (both waves)
   if (n == 64 && p.ldg == 64 && (p.stride_gpart & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
-    typedef T VT __attribute__((ext_vector_type(4)));  // (see the one-wave kernel)
+    // a contiguous 64 x 64 matrix (+ split partials, e.g. the 8 per-block Gram partials of ttr_qr_apply_pushed_gram): four
+    // elements per lane and load, the partials' loads of one position issued four at a time -- an element-wise loop has
+    // one dependent load in flight per lane, which costs 20 us per partial and launch at B = 2048
+    typedef T VT __attribute__((ext_vector_type(4)));
     for (int it = 0; it < 8; ++it) {
       const int e = (it * 2 * kWave + tid) * 4;
       const T* __restrict__ src = G + e;
@@ -1070,6 +570,8 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   }
   __syncthreads();
   const T gdiag = (lane < n) ? A[lane * ld + lane] : T(0);
+  // scale by the largest |entry| (= the largest diagonal entry for a Gram matrix): afterwards every entry is <= 1 and
+  // ||A||_F <= n, so the squares formed by the QL rotations cannot overflow (their fast path has no range branch)
   T gmax = T(0);  // (each wave over the whole matrix: the same value in both, no exchange)
   for (int idx = lane; idx < n * n; idx += kWave) {
     const int i = idx / n, j = idx - i * n;
@@ -1088,17 +590,19 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
 #ifdef TTR_EIGH_STAMPS
   long long* const dbg = reinterpret_cast<long long*>(p.ws);  // diagnostics build: cycle stamps of matrix 0 (wave 0)
   int dbgi = 0;
-#define TTR_ESTAMP2() do { if (dbg && bt == 0 && tid == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
+#define TTR_ESTAMP() do { if (dbg && bt == 0 && tid == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
 #else
-#define TTR_ESTAMP2() do {} while (0)
+#define TTR_ESTAMP() do {} while (0)
 #endif
-  TTR_ESTAMP2();
+  TTR_ESTAMP();
   T* const rowp = A + lane * ld;
   constexpr int CH = 8;
   typedef T T2 __attribute__((ext_vector_type(2)));
   typedef T T4 __attribute__((ext_vector_type(4)));
   constexpr int kPer16 = 16 / (int)sizeof(T);
-  T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;  // 16-byte aligned (offset arithmetic on the LDS pointer, see above)
+  // broadcast arrays of the tridiagonalisation (v, w), 16-byte aligned (offset arithmetic on the LDS pointer: a round trip
+  // through uintptr_t loses the address space and turns the reads into flat loads)
+  T* const vsh = vs + (kPer16 - (n * ld + 3) % kPer16) % kPer16;
   T* const wsh = vsh + 64;
   T2* const cs0 = reinterpret_cast<T2*>(vsh);                                // rotation buffers: (c, s) of rotation i at [i + 1]
   T2* const cs1 = reinterpret_cast<T2*>(dv + ((n * ld + 3 + 408) & 1));
@@ -1111,7 +615,12 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   if (n == 1 && tid == 0) { dv[0] = A[0]; ev[0] = T(0); tauv[0] = T(0); }
 
   if (wv == 0) {
-    // ---- 1. Householder tridiagonalisation (see the one-wave kernel); a barrier after every block of 16 reflectors
+    // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k]; a barrier after every block of 16
+    // reflectors hands the block to wave 1.
+    // lane = row, and every lane only ever touches ITS OWN row of A here: the reflector v and the vector w stay in
+    // registers (one entry per lane) and are broadcast through LDS arrays, the row is walked in
+    // chunks of eight (loads, arithmetic, stores -- the element-by-element read-modify-write through LDS was serialised at
+    // the full LDS latency by the possible aliasing of A with the broadcast arrays).
     for (int k = 0; k + 1 < n; ++k) {
       const bool below = lane >= k + 2 && lane < n;
       const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
@@ -1205,9 +714,13 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
       if (k == n - 2 && lane == n - 1) { dv[n - 1] = rowp[n - 1]; ev[n - 1] = T(0); }  // (before the barrier: wave 1 overwrites A with Q)
       if ((k & 15) == 15 || k == n - 2) __syncthreads();
     }
-    TTR_ESTAMP2();
-    TTR_ESTAMP2();
-    // ---- 3. implicit-shift QL on (d, e) in registers (see the one-wave kernel); every sweep is published and replayed by wave 1
+    TTR_ESTAMP();
+    TTR_ESTAMP();
+    // ---- 3. implicit-shift QL on (d, e); every sweep's rotations are published and replayed on Q's rows by wave 1.
+    // The recurrence is one serial chain per matrix (the wave repeats it in all lanes): it runs at the issue rate of a
+    // single wave.  d[k] / e[k] and the recorded rotation (c, s)[k-1] therefore live in REGISTERS, one index per lane:
+    // operands are fetched with v_readlane (uniform index), results are merged with a lane-select -- no LDS access, no wait
+    // and no exec-masked store inside the rotation loop; d[i], d[i+1] are carried from rotation to rotation.
     ereg = (lane < n) ? ev[lane] : T(0);
     dreg = (lane < n) ? dv[lane] : T(0);
     T creg = T(1), sreg = T(0);  // rotation i is kept in lane i + 1
@@ -1436,7 +949,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     }
   }
   __syncthreads();
-  TTR_ESTAMP2();
+  TTR_ESTAMP();
 #ifdef TTR_EIGH_STAMPS
   if (dbg && bt == 0 && tid == 0) { dbg[dbgi++] = total_iter; dbg[dbgi++] = nrot_dbg; dbg[dbgi++] = qlrec_dbg; dbg[dbgi++] = 0; }
 #endif
@@ -1518,15 +1031,10 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   }
 }
 
-static size_t eigh_tridiag2_lds_bytes(size_t elem, int64_t n) {  // A, 3 pad, 408 scratch, d / e (66 each), tau, T_b, 8 control words
+static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {  // A, 3 pad, 408 scratch, d / e (66 each), tau, T_b, 8 control words
   return (((size_t)n * (n + 1) + 3 + 408 + 66 * 2 + 64 + 16 * 17 + 8) * elem + 15) & ~size_t(15);
 }
 
-int g_eigh_two_wave = 1;  // ttr_debug_set_knob(TTR_KNOB_EIGH_TWO_WAVE): 1 = two waves per matrix (default), 0 = the one-wave kernel
-
-static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {
-  return (((size_t)n * (n + 1) + 3 + 64 * 5 + 66 * 2 + 16 * 17) * elem + 64 * sizeof(int) + 15) & ~size_t(15);
-}
 
 static size_t eigh_lds_bytes(size_t elem, int64_t n, bool ldsres) {
   const int np = (int)((n + 1) / 2), npad = (np + 7) & ~7;
@@ -1581,10 +1089,7 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.sweeps = sweeps;
   if (abs_floor == TTR_SOLVER_TRIDIAG && n <= 64) {  // tridiagonal QL, one wave per matrix
     ProfScope prof(TTR_PROF_EIGH, stream);
-    if (g_eigh_two_wave)
-      hipLaunchKernelGGL(eigh_tridiag2_kernel<T>, dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag2_lds_bytes(sizeof(T), n), stream, p);
-    else
-      hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
+    hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     return TTR_OK;
   }
