@@ -202,10 +202,15 @@ constexpr int UBLK = 16 * V1LD;     // 1312 >= 16 * KLD
 __device__ __forceinline__ int urow(int k) { return (k >> 4) * UBLK + (k & 15) * KLD; }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_kernel(SweepArgs<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
-  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];   // V2[:, :ro] as [m][i], zero padded (prologue only)
+  // V2[:, :ro] as [m][i], zero padded (prologue only: leading dimension 72 instead of the conflict-free 80 -- with it the three
+  // arrays take 39.7 KB, FOUR workgroups per CU instead of three; the main loop has no software prefetch (stores sit between
+  // its loads, and a prefetched step's loads then wait in the same in-order counter: measured 416 -> 700 us), so the HBM
+  // round trip is covered by the number of resident waves alone)
+  constexpr int V2LD = 72;
+  __shared__ __attribute__((aligned(16))) T V2l[64 * V2LD];
   __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];  // V1 as [k][m]; wave w then overwrites ITS rows 16 w .. 16 w + 15
   T* Ul = V1l;                                               // with U rows (urow()): no other wave reads them before
   __shared__ T isg[64];  // 1 / sigma of the output rows (TTR_SCALE_DIV semantics: 0 below the smallest normal), or 1
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
   // ---- prologue: U = V1 V2[:, :ro] on the matrix cores (or U = V2[:, :ro]); split 0 also emits left = U diag(sigma)
   for (int idx = tid; idx < 64 * 64; idx += kThreads) {
     const int m = idx >> 6, i = idx & 63;
-    V2l[m * KLD + i] = (m < R && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
+    V2l[m * V2LD + i] = (m < R && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
   }
   if (tid < 64) {
     T sc = T(1);
@@ -244,10 +249,10 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const T a = V1l[(16 * wave + cl) * V1LD + 4 * ks + g];
-      u0 = M::mma(a, V2l[(4 * ks + g) * KLD + cl], u0);
-      u1 = M::mma(a, V2l[(4 * ks + g) * KLD + 16 + cl], u1);
-      u2 = M::mma(a, V2l[(4 * ks + g) * KLD + 32 + cl], u2);
-      u3 = M::mma(a, V2l[(4 * ks + g) * KLD + 48 + cl], u3);
+      u0 = M::mma(a, V2l[(4 * ks + g) * V2LD + cl], u0);
+      u1 = M::mma(a, V2l[(4 * ks + g) * V2LD + 16 + cl], u1);
+      u2 = M::mma(a, V2l[(4 * ks + g) * V2LD + 32 + cl], u2);
+      u3 = M::mma(a, V2l[(4 * ks + g) * V2LD + 48 + cl], u3);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(SweepArgs<T> p) {
     __syncthreads();
     for (int idx = tid; idx < 64 * 64; idx += kThreads) {
       const int k = idx >> 6, i = idx & 63;
-      Ul[urow(k) + i] = V2l[k * KLD + i];
+      Ul[urow(k) + i] = V2l[k * V2LD + i];
     }
   }
   __syncthreads();
