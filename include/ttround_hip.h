@@ -54,7 +54,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
    ttr_eigh_trunc = 2; round 3 additions = 3).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 3
+#define TTR_ABI_VERSION 4
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -227,7 +227,7 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
                    int abs_floor, int32_t* sweeps,
                    const int32_t* skip_items, const void* sigma_in, int64_t stride_sigma_in,
                    void* workspace, int64_t workspace_bytes, void* stream);
-/* `skip_items` / `sigma_in` (optional; Jacobi solvers, use_delta = 0): pass-through items of the two-pass truncation, see
+/* `skip_items` / `sigma_in` (optional; Jacobi solvers): pass-through items of the two-pass truncation, see
  * ttr_spectrum_flat below.
  * `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
  * of `delta2` -- tensor.py:2039-2051 computes delta from the norm of the last core and reads it back (`.item()`); an
@@ -329,13 +329,18 @@ int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
  * sigma_i)^2 / 2: the second pass exists for kept singular values far below sigma_1.  When the `keep` kept ones lie within
  * a factor 1 / thr of each other (the host shim uses thr = 1/8; measured with the kernels' accumulation order emulated
  * on the CPU: right-orthonormality 8e-7 / relative sigma error 4e-7 after one pass against 4e-7 / 2e-7 after two at
- * sigma_keep = sigma_1 / 8), one pass already is in the accuracy class of the two.  ttr_spectrum_flat writes flat[b] = (sigma[b][keep - 1] >= thr * sigma[b][0] > 0) from pass 1's sigma (sorted
- * decreasing); ttr_rotgram skips items with skip[b] != 0 (their G is not written) and ttr_eigh_trunc passes them through
- * (`skip_items`: V = I, sigma = sigma_in, rank rule without delta).  Only meaningful without delta (batch mode:
- * round.py:149-150), where the rank does not depend on the small singular values.
+ * sigma_keep = sigma_1 / 8), one pass already is in the accuracy class of the two.  ttr_spectrum_flat writes
+ * flat[b] = (sigma[b][r - 1] >= thr * sigma[b][0] > 0) from pass 1's sigma (sorted decreasing), r = the rank the item will get:
+ *   use_delta = 0 or delta^2 = 0 (batch mode, round.py:149-150, or no eps): r = keep = min(rank cap, n);
+ *   use_delta = 1 (delta2, or *delta2_dev when given): r from the tail-energy rule of round.py:147-158 on pass 1's sigma, and the
+ *     item only qualifies when that decision is robust against pass 1's absolute error E = 64 n eps sigma_1^2 of a tail energy:
+ *     tail(r) <= delta^2 - E and tail(r - 1) > delta^2 + E (rank cap binding, r = keep: only the latter) -- pass 2 would select
+ *     the same rank.  (fp32 with eps = 1e-4: E exceeds delta^2, nothing qualifies; fp64 trains do.)
+ * ttr_rotgram skips items with skip[b] != 0 (their G is not written) and ttr_eigh_trunc passes them through
+ * (`skip_items`: V = I, sigma = sigma_in, rank rule as usual on sigma_in).
  */
 int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
-                      int32_t* flat, void* stream);
+                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, void* stream);
 int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
                 const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1,

@@ -396,9 +396,9 @@ def test_qr_blocked_rank_deficient(dt):
     assert (Q @ R - A.double()).abs().max() / A.abs().max() < tol(dt, 2e-5, 1e-12)
 
 
-def test_qr_blocked_perturbs_only_collapsing_panels(monkeypatch):
-    """Full-rank panels are factored as they are (rounds 1-2 added seeded 8-eps noise to every panel); the noise is only
-    drawn for a panel whose projected remainder collapses, and only the collapsing items of the batch receive it."""
+def test_qr_blocked_perturbs_only_collapsing_items(monkeypatch):
+    """Full-rank inputs are factored as they are (rounds 1-2 added seeded 8-eps noise to every panel of everything); the noise is
+    only drawn when some panel's projected remainder collapses, and only the collapsing items of the batch receive it."""
     from tntorch_amd import _hipops
     g = torch.Generator().manual_seed(21)
     full = torch.randn(2, 500, 150, generator=g, dtype=torch.float64)

@@ -1211,3 +1211,43 @@ def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
         t.round_tt(rmax=12)
         out[thr] = to_list(t.cores)
     assert all(torch.equal(x, y) for x, y in zip(out[0.25], out[0.0]))
+
+
+def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
+    """eps mode (non-batch): the rank comes from the tail energies, so an item only takes the one-pass shortcut when the rank rule's
+    decision on pass 1's sigma is robust against pass 1's absolute error E = 64 n eps sigma_1^2 (ttr_spectrum_flat with use_delta).
+    Flag logic on hand-made spectra, then an fp64 rank-deficient train (config C2's structure): the shortcut must trigger on every
+    interior bond and give the two-pass result (ranks identical, cores to 1e-11), i.e. the oracle's."""
+    from tntorch_amd import _hip, _hipops
+    d2 = 1e-8
+    sg = torch.tensor([[1.0, 0.8, 0.6, 0.5, 1e-9, 1e-9, 1e-9, 1e-9],      # clear gap: rank 4, kept values within a factor 2
+                       [1.0, 0.8, 0.6, 0.5, 1e-4, 1e-9, 1e-9, 1e-9],      # sigma_5^2 = delta^2: the decision is not robust
+                       [1.0, 0.8, 0.6, 0.05, 1e-9, 1e-9, 1e-9, 1e-9],     # robust rank 4, but sigma_4 < sigma_1 / 8
+                       [1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3]], dtype=torch.float64).cuda()  # nothing to cut, all kept values flat
+    assert _hip.spectrum_flat(sg, 8, 0.125, True, d2).tolist() == [1, 0, 0, 1]
+    assert _hip.spectrum_flat(sg, 2, 0.125, True, d2).tolist() == [1, 1, 1, 1]      # the cap decides: tail(1) > delta^2 + E everywhere
+    # eps = 1e-14 (the default of round_tt(rmax=r), tensor.py:2008-2014) on a spectrum with a noise tail: the cap binds robustly
+    assert _hip.spectrum_flat(sg, 4, 0.125, True, 1e-29).tolist() == [1, 1, 0, 1]
+    d2_dev = torch.tensor([d2], dtype=torch.float64).cuda()
+    assert _hip.spectrum_flat(sg, 8, 0.125, True, 0.0, d2_dev).tolist() == [1, 0, 0, 1]
+    assert _hip.spectrum_flat(sg, 8, 0.125, True, 0.0).tolist() == [0, 0, 0, 1]     # delta = 0: the batch criterion at keep = 8
+    # fp32: E = 64 * 8 * 1.2e-7 = 6e-5 > delta^2 -- what is cut cannot be certified, only the nothing-to-cut item qualifies
+    assert _hip.spectrum_flat(sg.float(), 8, 0.125, True, d2).tolist() == [0, 0, 0, 1]
+
+    torch.manual_seed(3)
+    g = oracle.tt_randn([24] * 6, 12, dtype=torch.float64)
+    inp = oracle.tt_add(g, g)   # TT ranks 24, numerical ranks 12
+    calls = []
+    orig = _hip.spectrum_flat
+    monkeypatch.setattr(_hip, "spectrum_flat", lambda *a: calls.append(orig(*a)) or calls[-1])
+    res = {}
+    for thr in (0.125, 0.0):
+        monkeypatch.setattr(_hipops, "FLAT_SPECTRUM_THR", thr)
+        t = gpu_tensor(inp)
+        t.round_tt(eps=1e-6)
+        res[thr] = [c.cpu() for c in t.cores]
+    assert len(calls) == 5 and sum(int(c.sum().item()) for c in calls) >= 2   # (sigma_12 / sigma_1 of a random train is not above 1/8 on every bond)
+    assert ranks(res[0.125]) == ranks(res[0.0]) == [1, 12, 12, 12, 12, 12, 1]
+    assert tt_rel_err(res[0.125], res[0.0]) <= 1e-11
+    ref = oracle.round_tt([c.clone() for c in inp], eps=1e-6, algorithm="svd")
+    assert ranks(res[0.125]) == ranks(ref) and tt_rel_err(res[0.125], ref) <= 1e-10

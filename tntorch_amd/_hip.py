@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 3  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 4  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -102,7 +102,7 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
          c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
-    "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p]),
+    "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_bj_solve": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_apply": (
@@ -656,13 +656,17 @@ def sweep_fused_ok(M: torch.Tensor) -> bool:
 
 
 @_on_device
-def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float) -> torch.Tensor:
-    """int32 [batch]: 1 where sigma[b, keep - 1] >= thr * sigma[b, 0] > 0 (sigma [batch, n] sorted decreasing; ttr_spectrum_flat)."""
+def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float, use_delta: bool = False, delta2: float = 0.0,
+                  delta2_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [batch]: 1 where sigma[b, r - 1] >= thr * sigma[b, 0] > 0 (sigma [batch, n] sorted decreasing), r = keep, or with
+    ``use_delta`` the rank the tail-energy rule selects from these sigma provided that decision is robust (ttr_spectrum_flat)."""
     sigma = sigma.contiguous()
     batch, n = sigma.shape
     flat = torch.empty((batch,), dtype=torch.int32, device=sigma.device)
     if batch:
         _check(lib().ttr_spectrum_flat(dtype_code(sigma.dtype), n, batch, sigma.data_ptr(), n, int(keep), float(thr),
+                                       int(bool(use_delta)), float(delta2),
+                                       delta2_dev.data_ptr() if delta2_dev is not None else None,
                                        flat.data_ptr(), _stream()), "ttr_spectrum_flat")
     return flat
 

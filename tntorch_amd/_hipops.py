@@ -67,64 +67,71 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         Q, RL = qr(A[:, :, :m].contiguous())
         return Q, torch.cat([RL, _hip.gemm(Q, A[:, :, m:], transA=True)], dim=2)
     pw = _hip.max_qr_cols(A.dtype)
-    R = torch.zeros((Bt, n, n), dtype=A.dtype, device=A.device)
-    Q = torch.empty((Bt, m, n), dtype=A.dtype, device=A.device)
     # Exactly dependent / exactly zero columns (block-structured sums such as t + t have them) leave an exactly
     # zero remainder after the projection; the Householder kernel then completes the panel with unit vectors
-    # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  A panel whose remainder
-    # COLLAPSES (some |R_ii| of the projected panel <= 32 eps x that column's norm before the projection) is therefore
-    # redone with a perturbation at the rounding level of its OWN batch item (8 eps * rms(A[b]), seeded, deterministic;
-    # only the collapsing items of the batch receive it): zero remainders become generic directions, which the two
-    # projection passes make orthogonal to the finished Q; A = Q R still holds to O(eps ||A[b]||).  Panels that keep
-    # their rank -- every panel of a full-rank input -- are factored exactly as they are (rounds 1-2 perturbed all of
-    # them).  Per item: every item is first brought to ||A[b]|| in [0.5, 1) by an exact power of two
-    # (ttr_pow2_normalize; given back to R at the end), so one delta serves the whole batch and an item 1e-6 times
-    # smaller than its neighbours is not swamped by their noise level.  The collapse test costs one readback per panel
-    # (control flow; this path only exists for TT ranks above the kernel's 64 columns).
+    # e_0, e_1, ... -- the SAME ones in every such panel, and already inside span(Q).  An item with a panel whose
+    # remainder COLLAPSES (some |R_ii| of the projected panel <= 32 eps x that column's norm before the projection) is
+    # therefore factored again with a perturbation of EVERY panel at the rounding level of the item (8 eps * rms(A[b]),
+    # seeded, deterministic): zero remainders become generic directions, which the two projection passes make orthogonal
+    # to the finished Q; A = Q R still holds to O(eps ||A[b]||).  (All panels, not only the collapsing ones: with an exactly
+    # block-structured input the unperturbed leading panels have exactly zero rows, a later panel's rounding-level remainder
+    # then lies entirely inside the span that is already taken, and Q loses orthogonality -- measured 2.7e-13 against 4.9e-15 in
+    # fp64 on a 136 x 136 rank-68 unfolding.)  Items that keep their rank in every panel -- every full-rank input -- are
+    # factored exactly as they are (rounds 1-2 perturbed everything); in a mixed batch they come out of the second run
+    # bit-identical (their perturbation is scaled by zero).  Per item: every item is first brought to ||A[b]|| in
+    # [0.5, 1) by an exact power of two (ttr_pow2_normalize; given back to R at the end), so one delta serves the whole
+    # batch and an item 1e-6 times smaller than its neighbours is not swamped by their noise level.  The collapse test costs
+    # ONE readback (control flow; this path only exists for TT ranks above the kernel's 64 columns).
     A, a_exp = _hip.pow2_normalize(A)
     eps = torch.finfo(A.dtype).eps
     delta = 8.0 * eps / math.sqrt(max(1, m * n))
     # (an all-zero item keeps exponent 0: its perturbation is scaled down by 1e-20 -- still generic directions for the
-    # panels, the QR kernel factors every block at its own exponent, but R comes back at 1e-28 instead of 1e-8.  A
-    # [Bt]-element mask and the [Bt, w] collapse test: the only torch arithmetic here.)
+    # panels, the QR kernel factors every block at its own exponent, but R comes back at 1e-28 instead of 1e-8.  [Bt]-element
+    # masks and the [Bt, w] collapse test: the only torch arithmetic here.)
     live = torch.sign(_hip.norm(A.reshape(Bt, -1))).clamp_min(1e-20)
     gen = torch.Generator(device=A.device)
 
-    def factor_panel(W, j0):
-        """BCGS2 step for the (contiguous, overwritten) panel W against Q[:, :, :j0] -> (Q_j, R_jj, R_0j, diag of the projected panel's R)."""
-        if j0 == 0:
-            Qj, Rjj = _hip.qr(W)
-            return Qj, Rjj, None, torch.diagonal(Rjj, dim1=1, dim2=2)
-        Qp = Q[:, :, :j0]
-        C1 = _hip.gemm(Qp, W, transA=True)                 # j0 x w
-        _hip.gemm_axpby(Qp, C1, W, -1.0, 1.0)              # W -= Qp C1
-        Q1, R1 = _hip.qr(W)
-        C2 = _hip.gemm(Qp, Q1, transA=True)
-        _hip.gemm_axpby(Qp, C2, Q1, -1.0, 1.0)             # Q1 -= Qp C2
-        Qj, R2 = _hip.qr(Q1)
-        Rjj = _hip.gemm(R2, R1)
-        _hip.gemm_axpby(C2, R1, C1, 1.0, 1.0)              # C1 += C2 R1
-        return Qj, Rjj, C1, torch.diagonal(R1, dim1=1, dim2=2)
-
-    for j0 in range(0, n, pw):
-        j1 = min(j0 + pw, n)
-        w = j1 - j0
-        W0 = A[:, :, j0:j1]
-        cn = torch.diagonal(_hip.gemm(W0, W0, transA=True), dim1=1, dim2=2).clamp_min(0).sqrt()  # column norms [Bt, w]
-        Qj, Rjj, C1, d = factor_panel(W0.contiguous(), j0)
-        collapsed = (d.abs() <= (32.0 * eps) * cn).any(dim=1)
-        if bool(collapsed.any().item()):  # (readback: control flow only)
+    def factor(perturb):
+        """BCGS2 over the panels; ``perturb``: None or the [Bt] scale of the items' perturbation.  -> Q, R, [Bt] collapse flags."""
+        R = torch.zeros((Bt, n, n), dtype=A.dtype, device=A.device)
+        Q = torch.empty((Bt, m, n), dtype=A.dtype, device=A.device)
+        collapsed = torch.zeros(Bt, dtype=torch.bool, device=A.device)
+        for j0 in range(0, n, pw):
+            j1 = min(j0 + pw, n)
+            w = j1 - j0
+            W0 = A[:, :, j0:j1]
             W = W0.contiguous()
-            gen.manual_seed(0x5EED + j0)
-            noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
-            eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(),
-                                   scale=live * collapsed.to(A.dtype))
-            _hip.gemm_axpby(noise, eye, W, delta, 1.0)         # W += delta * noise (zero items: += 0; rank-keeping items: untouched)
-            Qj, Rjj, C1, _ = factor_panel(W, j0)
-        if C1 is not None:
-            R[:, :j0, j0:j1] = C1
-        Q[:, :, j0:j1] = Qj
-        R[:, j0:j1, j0:j1] = Rjj
+            if perturb is not None:
+                gen.manual_seed(0x5EED + j0)
+                noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
+                eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(), scale=perturb)
+                _hip.gemm_axpby(noise, eye, W, delta, 1.0)         # W += delta * noise (zero items: += 0; rank-keeping items: untouched)
+            else:
+                cn = torch.diagonal(_hip.gemm(W0, W0, transA=True), dim1=1, dim2=2).clamp_min(0).sqrt()  # column norms [Bt, w]
+            if j0 == 0:
+                Qj, Rjj = _hip.qr(W)
+                d = torch.diagonal(Rjj, dim1=1, dim2=2)
+            else:
+                Qp = Q[:, :, :j0]
+                C1 = _hip.gemm(Qp, W, transA=True)                 # j0 x w
+                _hip.gemm_axpby(Qp, C1, W, -1.0, 1.0)              # W -= Qp C1
+                Q1, R1 = _hip.qr(W)
+                d = torch.diagonal(R1, dim1=1, dim2=2)
+                C2 = _hip.gemm(Qp, Q1, transA=True)
+                _hip.gemm_axpby(Qp, C2, Q1, -1.0, 1.0)             # Q1 -= Qp C2
+                Qj, R2 = _hip.qr(Q1)
+                Rjj = _hip.gemm(R2, R1)
+                _hip.gemm_axpby(C2, R1, C1, 1.0, 1.0)              # C1 += C2 R1
+                R[:, :j0, j0:j1] = C1
+            if perturb is None:
+                collapsed |= (d.abs() <= (32.0 * eps) * cn).any(dim=1)
+            Q[:, :, j0:j1] = Qj
+            R[:, j0:j1, j0:j1] = Rjj
+        return Q, R, collapsed
+
+    Q, R, collapsed = factor(None)
+    if bool(collapsed.any().item()):  # (readback: control flow only)
+        Q, R, _ = factor(live * collapsed.to(A.dtype))
     return Q, _hip.scale_batch(R, expo=a_exp, expo_sign=+1)
 
 
@@ -394,12 +401,14 @@ def truncate(
         if algorithm == "svd":
             V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             flat = None
-            if batch and FLAT_SPECTRUM_THR > 0:
+            if FLAT_SPECTRUM_THR > 0:
                 # items whose KEPT singular values lie within a factor 8 of each other do not need the second pass (the first
                 # Gram matrix already carries them to a few eps; include/ttround_hip.h: ttr_spectrum_flat): their rotated
                 # Gram matrix is not formed and the pass-2 solver hands pass 1's result through.  Decided per item, on the
-                # device; batch mode only (the rank does not depend on the small singular values there).
-                flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR)
+                # device.  Batch mode: the rank does not depend on the small singular values.  eps mode: the rank rule is
+                # evaluated on pass 1's sigma and the item only qualifies when pass 2 provably selects the same rank (fp64
+                # trains: config C2; in fp32 the error margin of pass 1's tail energies exceeds a delta of 1e-4 ||T||).
+                flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, use_delta, delta2, delta2_dev)
             V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev,
                                            skip_items=flat, sigma_in=sig1 if flat is not None else None)

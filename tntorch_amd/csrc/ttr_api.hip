@@ -138,12 +138,43 @@ __global__ __launch_bounds__(kThreads) void mask_cols_kernel(int64_t rows, int64
 // flat[b] = 1 when the `keep` largest singular values of item b (sigma sorted decreasing) lie within a factor 1 / thr of
 // each other: sigma[keep - 1] >= thr * sigma[0] > 0
 template <typename T>
-__global__ void spectrum_flat_kernel(int64_t batch, int keep, T thr, const T* __restrict__ sigma, int64_t stride_sigma,
-                                     int32_t* __restrict__ flat) {
+__global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, const T* __restrict__ sigma, int64_t stride_sigma,
+                                     int use_delta, double delta2, const double* __restrict__ delta2_dev, int32_t* __restrict__ flat) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  const T s0 = sigma[b * stride_sigma], sk = sigma[b * stride_sigma + keep - 1];
-  flat[b] = (s0 > T(0) && sk >= thr * s0) ? 1 : 0;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const T s0 = sg[0];
+  int kp = keep;
+  bool ok = s0 > T(0);
+  const double d2 = use_delta ? (delta2_dev ? *delta2_dev : delta2) : 0.0;
+  if (ok && d2 > 0.0) {
+    // eps mode: the rank comes from the tail energies of pass 1's sigma, which carry an absolute error of up to E = 64 n eps sigma_1^2
+    // (n values, each c eps sigma_1^2 off); the item only qualifies when the rule's decision is the same for every spectrum within E
+    // of this one -- tail(r) <= delta^2 - E and tail(r - 1) > delta^2 + E at the selected rank r (rank cap binding: only the latter)
+    const double E = 64.0 * n * (double)Num<T>::eps() * (double)s0 * (double)s0;
+    double acc = 0.0, tail_r = 0.0;
+    int tail = 0;
+    for (int k = n - 1; k >= 0; --k) {
+      acc += (double)sg[k] * (double)sg[k];
+      if (acc <= d2) { tail = n - k; tail_r = acc; } else break;
+    }
+    int r = n - tail;
+    if (r < 1) r = 1;
+    if (r > keep) {  // the cap decides as long as the rule cannot cut the keep-th value: tail(keep - 1) > delta^2 + E
+      double tc = 0.0;
+      for (int k = n - 1; k >= keep - 1; --k) tc += (double)sg[k] * (double)sg[k];
+      ok = tc > d2 + E;
+      kp = keep;
+    } else {
+      const int rr = n - tail;  // the rule's rank before the ">= 1" clamp
+      const bool cut_safe = tail == 0 || tail_r <= d2 - E;  // what is cut stays cut
+      bool keep_safe = true;                                 // the last kept value cannot be cut as well (rr = 0: rank 1 either way)
+      if (rr >= 1) keep_safe = tail_r + (double)sg[rr - 1] * (double)sg[rr - 1] > d2 + E;
+      ok = cut_safe && keep_safe;
+      kp = r;
+    }
+  }
+  flat[b] = (ok && sg[kp - 1] >= thr * s0) ? 1 : 0;
 }
 
 // Block-wide sum of doubles (256 threads), result in every thread.
@@ -632,9 +663,9 @@ int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
 }
 
 int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
-                      int32_t* flat, void* stream) {
+                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_spectrum_flat: bad dtype %d", dtype);
-  TTR_REQUIRE(n >= 1 && keep >= 1 && keep <= n && batch >= 0 && thr > 0.0 && thr <= 1.0, TTR_E_INVALID,
+  TTR_REQUIRE(n >= 1 && keep >= 1 && keep <= n && batch >= 0 && thr > 0.0 && thr <= 1.0 && delta2 >= 0.0, TTR_E_INVALID,
               "ttr_spectrum_flat: bad arguments");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(sigma && flat, TTR_E_INVALID, "ttr_spectrum_flat: null pointer");
@@ -642,11 +673,11 @@ int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, in
   const unsigned gx = (unsigned)ceil_div(batch, kThreads);
   ProfScope prof(TTR_PROF_MISC, s);
   if (dtype == TTR_F32)
-    hipLaunchKernelGGL(spectrum_flat_kernel<float>, dim3(gx), dim3(kThreads), 0, s, batch, (int)keep, (float)thr, (const float*)sigma,
-                       stride_sigma, flat);
+    hipLaunchKernelGGL(spectrum_flat_kernel<float>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, (float)thr,
+                       (const float*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat);
   else
-    hipLaunchKernelGGL(spectrum_flat_kernel<double>, dim3(gx), dim3(kThreads), 0, s, batch, (int)keep, thr, (const double*)sigma,
-                       stride_sigma, flat);
+    hipLaunchKernelGGL(spectrum_flat_kernel<double>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, thr,
+                       (const double*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }

@@ -112,9 +112,27 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
     const T* __restrict__ si = p.sigma_in + bt * p.stride_sigma_in;
     for (int i = tid; i < n; i += kThreads) p.sigma[bt * p.stride_sigma + i] = si[i];
-    if (tid == 0) {
+    if (tid == 0) {  // the rank rule of the regular epilogue, on pass 1's sigma (ttr_spectrum_flat made sure pass 2 would agree)
       const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
-      p.info[bt] = si[0] < T(1e-13) ? 0 : (int)(cap < 1 ? 1 : cap);  // (only used without delta: batch mode)
+      int rank;
+      if (si[0] < T(1e-13)) {
+        rank = 0;
+      } else if (!p.use_delta) {
+        rank = (int)(cap < 1 ? 1 : cap);
+      } else {
+        const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
+        double acc = 0.0;
+        int tail = 0;
+        for (int k = n - 1; k >= 0; --k) {
+          acc += (double)(si[k] * si[k]);
+          if ((T)acc <= d2) tail = n - k; else break;
+        }
+        int64_t rk = n - tail;
+        if (rk > cap) rk = cap;
+        if (rk < 1) rk = 1;
+        rank = (int)rk;
+      }
+      p.info[bt] = rank;
       if (p.sweeps) p.sweeps[bt] = 0;
     }
     return;
@@ -1074,8 +1092,8 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   EighArgs<T> p{};
   p.delta2_dev = delta2_dev;
   p.skip_items = skip_items; p.sigma_in = (const T*)sigma_in; p.stride_sigma_in = stride_sigma_in;
-  TTR_REQUIRE(!skip_items || (sigma_in && !use_delta && !(abs_floor == TTR_SOLVER_TRIDIAG && n <= 64)), TTR_E_INVALID,
-              "ttr_eigh_trunc: skip_items needs sigma_in, use_delta = 0 and a Jacobi solver");
+  TTR_REQUIRE(!skip_items || (sigma_in && !(abs_floor == TTR_SOLVER_TRIDIAG && n <= 64)), TTR_E_INVALID,
+              "ttr_eigh_trunc: skip_items needs sigma_in and a Jacobi solver");
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG;
   p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
