@@ -1235,8 +1235,8 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
     assert _hip.spectrum_flat(sg.float(), 8, 0.125, True, d2).tolist() == [0, 0, 0, 1]
 
     torch.manual_seed(3)
-    g = oracle.tt_randn([24] * 6, 12, dtype=torch.float64)
-    inp = oracle.tt_add(g, g)   # TT ranks 24, numerical ranks 12
+    g = oracle.tt_randn([12] * 6, 6, dtype=torch.float64)
+    inp = oracle.tt_add(g, g)   # TT ranks 12, numerical ranks 6 (3e6 entries: compared densely -- tt_rel_err resolves 1e-8)
     calls = []
     orig = _hip.spectrum_flat
     monkeypatch.setattr(_hip, "spectrum_flat", lambda *a: calls.append(orig(*a)) or calls[-1])
@@ -1247,7 +1247,7 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
         t.round_tt(eps=1e-6)
         res[thr] = [c.cpu() for c in t.cores]
     assert len(calls) == 5 and sum(int(c.sum().item()) for c in calls) >= 2   # (sigma_12 / sigma_1 of a random train is not above 1/8 on every bond)
-    assert ranks(res[0.125]) == ranks(res[0.0]) == [1, 12, 12, 12, 12, 12, 1]
-    assert tt_rel_err(res[0.125], res[0.0]) <= 1e-11
+    assert ranks(res[0.125]) == ranks(res[0.0]) == [1, 6, 6, 6, 6, 6, 1]
+    assert rel_diff(dense(res[0.125]), dense(res[0.0])) <= 1e-12
     ref = oracle.round_tt([c.clone() for c in inp], eps=1e-6, algorithm="svd")
-    assert ranks(res[0.125]) == ranks(ref) and tt_rel_err(res[0.125], ref) <= 1e-10
+    assert ranks(res[0.125]) == ranks(ref) and rel_diff(dense(res[0.125]), dense(ref)) <= 1e-12

@@ -477,9 +477,18 @@ __device__ __forceinline__ bool givens_norm(float f, float g, float& r, float& r
   return ok;
 }
 __device__ __forceinline__ bool givens_norm(double f, double g, double& r, double& rinv) {
-  r = sqrt(f * f + g * g);
-  const bool ok = r > 0.;
-  rinv = ok ? 1.0 / r : 0.;
+  // fp64: the hardware rsq estimate + two Newton steps for 1 / sqrt(x) (12 instructions; the IEEE sqrt and the division
+  // that used to sit here expand to ~30 on the recurrence's chain -- the fp64 rotation was 75 instructions).  x <= 1 by the
+  // scaling; below 1e-290 the rotation is the sweep's underflow case, as in fp32.
+  const double x = fma(f, f, g * g);
+  const bool ok = x > 1e-290;
+  double y = __builtin_amdgcn_rsq(x);
+  double h = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, h, y);
+  h = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, h, y);
+  rinv = y;
+  r = ok ? x * y : 0.;
   return ok;
 }
 
