@@ -499,7 +499,9 @@ def main():
                     t = tn.Tensor(small, batch=True)
                     t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
                     return t
-                el, _, _ = timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)
+                # (fastest of three timed blocks: a step of a few ms is enqueue-bound on the host, and one disturbed block -- the
+                # parity check's LAPACK threads winding down -- moved the figure by 50 % between otherwise identical runs)
+                el = min(timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)[0] for _ in range(3))
                 extras[label] = {"tensors_per_step": Bx, "ms_per_step": el / st * 1e3, "cores_per_s": Bx * N_CORES * st / el}
             if B == 2048:
                 # a larger resident batch (26 GB of cores): what the headline's B leaves on the table (tail effects of the
