@@ -153,46 +153,51 @@ __device__ __forceinline__ void dpp_add_bcast31(float& a, float& b) {
   asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
                "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-// a, b <- their sums over the 64 lanes (wave-uniform).  Two interleaved DPP chains: an instruction of the other chain sits
-// in every DPP hazard slot (12 DPP + 2 v_readlane).
+// a, b <- their sums over the 64 lanes (wave-uniform).  Round 3: ONE half exchange folds both values into one register
+// (v_permlane32_swap a, b leaves [a.lo | b.lo] in a and [a.hi | b.hi] in b: their sum holds a's 32 pair sums in lanes 0-31 and b's in
+// lanes 32-63), then one DPP chain reduces both halves at once: 1 swap + 1 add + 5 DPP + 2 v_readlane = 9 issue slots instead of
+// the 14 of two interleaved chains (12 DPP + 2 v_readlane) -- a lone wave issues one instruction per ~8 clocks, so on the
+// Householder chain slots ARE latency.  (inline asm: hipcc 7.2 miscompiles the swap builtin when both operands hold the same
+// value, and the asm keeps the swap in place, without operand copies.)
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
-  a += dpp_mov<0xB1>(a);   b += dpp_mov<0xB1>(b);    // quad_perm [1,0,3,2]
-  a += dpp_mov<0x4E>(a);   b += dpp_mov<0x4E>(b);    // quad_perm [2,3,0,1]
-  a += dpp_mov<0x141>(a);  b += dpp_mov<0x141>(b);   // row_half_mirror
-  a += dpp_mov<0x140>(a);  b += dpp_mov<0x140>(b);   // row_mirror
-  dpp_add_bcast15(a, b);  // row_bcast:15 -> rows 1, 3
-  dpp_add_bcast31(a, b);  // row_bcast:31 -> rows 2, 3
-  a = lane_get(a, 63);
-  b = lane_get(b, 63);
+  float w = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_add_f32 %0, %0, %1\n\ts_nop 1" : "+v"(w), "+v"(b));
+  w += dpp_mov<0xB1>(w);   // quad_perm [1,0,3,2]
+  w += dpp_mov<0x4E>(w);   // quad_perm [2,3,0,1]
+  w += dpp_mov<0x141>(w);  // row_half_mirror
+  w += dpp_mov<0x140>(w);  // row_mirror: every lane holds its row's sum
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1" : "+v"(w));  // rows 1, 3 += rows 0, 2
+  a = lane_get(w, 31);
+  b = lane_get(w, 63);
 }
 __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   a = wave_sum_dpp(a);
   b = wave_sum_dpp(b);
 }
-// v[0..3] <- their sums over the 64 lanes (wave-uniform): four interleaved DPP chains, every hazard slot filled by the
-// other chains (24 DPP + 4 v_readlane, no s_nop)
+// v[0..3] <- their sums over the 64 lanes (wave-uniform).  Round 3: two half exchanges fold (v0, v1) and (v2, v3) into one register
+// each ([V0 | V1], [V2 | V3] by halves), one row exchange (v_permlane16_swap: odd rows of the first with even rows of the second
+// operand) folds those into ONE register whose four rows carry V0, V2, V1, V3, and a single 4-step DPP row reduction finishes all
+// four: 3 swaps + 3 adds + 4 DPP + 4 v_readlane = 14 issue slots instead of 28 (24 DPP + 4 v_readlane).
 __device__ __forceinline__ void wave_sum4(float (&v)[4]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0xB1>(v[c]);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x4E>(v[c]);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x141>(v[c]);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) v[c] += dpp_mov<0x140>(v[c]);
-  asm volatile("s_nop 0\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "s_nop 1"
-               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-  for (int c = 0; c < 4; ++c) v[c] = lane_get(v[c], 63);
+  float x = v[0], y = v[2];
+  asm volatile("s_nop 1\n\t"
+               "v_permlane32_swap_b32 %0, %2\n\t"
+               "v_permlane32_swap_b32 %1, %3\n\t"
+               "v_add_f32 %0, %0, %2\n\t"
+               "v_add_f32 %1, %1, %3\n\t"
+               "s_nop 1\n\t"
+               "v_permlane16_swap_b32 %0, %1\n\t"
+               "v_add_f32 %0, %0, %1\n\t"
+               "s_nop 1"   // (the compiler cannot see that the asm ends on a VALU write the DPP step below reads)
+               : "+v"(x), "+v"(y), "+v"(v[1]), "+v"(v[3]));
+  x += dpp_mov<0xB1>(x);
+  x += dpp_mov<0x4E>(x);
+  x += dpp_mov<0x141>(x);
+  x += dpp_mov<0x140>(x);
+  v[0] = lane_get(x, 0);
+  v[2] = lane_get(x, 16);
+  v[1] = lane_get(x, 32);
+  v[3] = lane_get(x, 48);
 }
 __device__ __forceinline__ void wave_sum4(double (&v)[4]) { wave_sum_dpp4(v); }
 
