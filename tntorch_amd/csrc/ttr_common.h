@@ -117,7 +117,6 @@ __device__ __forceinline__ T wave_sum_dpp(T v) {
   v += dpp_mov<0x140>(v);  // row_mirror
   return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
-
 // Four independent wave sums at once: the DPP / readlane chains of the four values interleave.
 template <typename T>
 __device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
@@ -135,24 +134,11 @@ __device__ __forceinline__ void wave_sum_dpp4(T (&v)[4]) {
 
 // ------------------------------------------------------------------ multi-value wave reductions
 // A wave issues at most one VALU instruction per ~8 cycles (measured: 8.0 cycles per independent v_fma for a wave alone on
-// its SIMD), so on the sequential Householder chain the number of issue slots of a reduction IS its latency.  Round 2
-// first folded several values into one register with gfx950's v_permlane32/16_swap (3 swaps + one DPP row reduction for four
-// values, ~27-32 slots with the hazard s_nops); the interleaved DPP chains below need 17 / 28.
+// its SIMD), so on the sequential Householder chain the number of issue slots of a reduction IS its latency.  Round 2's first
+// attempt at folding several values into one register with gfx950's v_permlane32/16_swap went through the builtins (operand
+// copies around every swap: ~27-32 slots for four values) and lost against interleaved DPP chains (14 / 28 slots for two / four
+// values); written as in-place inline asm the folds need 9 / 14 (round 3, below).
 //
-// Row-broadcast DPP steps of the classic GFX9 wave reduction: after the four row steps every lane holds its row's sum;
-// row_bcast:15 adds lane 15 of rows 0 / 2 into rows 1 / 3, row_bcast:31 adds lane 31 (rows 0 + 1) into rows 2 / 3, so that
-// lane 63 ends up with the sum over all 64 lanes.
-// (inline asm: with a partial row mask the compiler does not fuse update_dpp + add into one v_add_f32_dpp -- it emits
-// v_mov_dpp, v_add and a re-zeroing v_mov per step.  Rows outside the mask keep their value, which is what "+= 0" means.
-// The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see inside the asm.)
-__device__ __forceinline__ void dpp_add_bcast15(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void dpp_add_bcast31(float& a, float& b) {
-  asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
 // a, b <- their sums over the 64 lanes (wave-uniform).  Round 3: ONE half exchange folds both values into one register
 // (v_permlane32_swap a, b leaves [a.lo | b.lo] in a and [a.hi | b.hi] in b: their sum holds a's 32 pair sums in lanes 0-31 and b's in
 // lanes 32-63), then one DPP chain reduces both halves at once: 1 swap + 1 add + 5 DPP + 2 v_readlane = 9 issue slots instead of
