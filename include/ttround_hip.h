@@ -203,7 +203,7 @@ int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t
  * accuracy on graded, accurately formed Gram matrices -- pass 2 of the 'svd' algorithm).  abs_floor = 1
  * additionally skips |G_pq| <= sqrt(n)*eps*max|G_ii| (for a plain Gram matrix, whose entries are only
  * accurate to eps*||G||).  abs_floor = 2 selects, for n <= 64, the tridiagonal solver instead (Householder
- * reduction + implicit-shift QL, one wave per matrix, absolute accuracy O(eps*||G||) like LAPACK steqr):
+ * reduction + implicit-shift QL, two waves per matrix, absolute accuracy O(eps*||G||) like LAPACK steqr):
  * ~10x fewer flops, used for the first pass / 'eig'; larger n falls back to Jacobi with abs_floor = 1.
  * abs_floor = TTR_SOLVER_JACOBI_LIVE (pass 2 of the two-pass 'svd' truncation): purely relative rotation test among
  * the LIVE indices; indices with G_ii <= (n eps)^2 max G_ii (the numerical null space of the input) are frozen.  Every

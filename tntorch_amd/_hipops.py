@@ -139,9 +139,11 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 # Symmetric eigenproblems too large for one workgroup: block Jacobi over the whole GPU.
 #
 # G (n x n) is cut into blocks of b <= 32 columns; a round pairs the blocks (round-robin), the 2b x 2b
-# diagonal pair problems are diagonalised by the single-wave tridiagonal-QL kernel (batched over pairs and
-# matrices) and the pair rotations are applied with the MFMA GEMM:  G <- W^T G W,  V <- V W.  Pairs are kept
-# physically adjacent by permuting the block order between rounds (gather copies -- layout only).
+# diagonal pair problems are diagonalised by the LDS-resident Jacobi kernel (batched over pairs and matrices, diagonal-matched
+# column order) and the pair rotations are applied on the matrix cores:  G <- W^T G W,  V <- V W.  Device-resident driver
+# (`_hip.bj_sweeps`): the blocks are never moved, the pair problems are gathered through a device pair table; the host-driven
+# loop below (odd block counts, cross-check in tests) keeps the pairs physically adjacent by permuting the block order between
+# rounds (gather copies -- layout only).
 _BJ_MAX_SWEEPS = 12
 _BJ_MAX_SWEEPS_DEVICE = 24   # (launches after convergence return at once: a generous bound is free)
 
@@ -228,7 +230,7 @@ def eigh_block_jacobi(G: torch.Tensor, relative: bool = False, prerotation: bool
             Gv = G[:, : npairs * w, : npairs * w].reshape(Bt, npairs, w, npairs, w)
             S = torch.stack([Gv[:, p, :, p, :] for p in range(npairs)], dim=1).reshape(Bt * npairs, w, w)
             # pair problems: the 4-wave Jacobi kernel with the diagonal-matched column order.  Measured against the
-            # one-wave tridiagonal kernel it is 1.2x (8192 pair problems per round) to 2.7x (16) faster here: its
+            # tridiagonal kernel (rounds 1-2: one wave per matrix) it is 1.2x (8192 pair problems per round) to 2.7x (16) faster here: its
             # pre-check makes converged pairs free, so every outer sweep is cheaper than the one before.
             nsw = torch.zeros(Bt * npairs, dtype=torch.int32, device=dev) if relative else None
             W, _, _ = _hip.eigh_trunc(S.contiguous(), _hip.EIG_MATCH_DIAG, False, 0.0, w,
