@@ -54,7 +54,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
    ttr_eigh_trunc = 2; round 3 additions = 3).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 4
+#define TTR_ABI_VERSION 5
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -232,6 +232,27 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  * `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
  * of `delta2` -- tensor.py:2039-2051 computes delta from the norm of the last core and reads it back (`.item()`); an
  * eps-mode sweep that keeps it on the device enqueues every bond without a host synchronisation. */
+
+/*
+ * Selected eigenpairs of symmetric matrices with 64 < n <= ttr_eigsel_max_n() (512): the k <= 64 LARGEST eigenvalues and their
+ * eigenvectors -- torch.linalg.eigh / svd of round.py:96, 115 on the Gram matrix of a dense TT-SVD bond when only the top of the
+ * spectrum is looked at (batch mode with a rank cap far below n: BASELINE config C3, n = 256, rmax = 8).  LAPACK syevx class:
+ *   ttr_tridiag       A[b] (n x n symmetric, leading dimension lda, DESTROYED) = Q T Q^T by Householder reflectors, one
+ *                     workgroup per matrix; d[b][n], e[b][n] (e[i] couples i and i + 1, e[n-1] = 0), tau[b][n]; reflector k is
+ *                     left in row k of A (columns k+1 .., leading 1 stored)
+ *   ttr_tri_eigsel    lam[b][k] = the k largest eigenvalues of T (descending; Sturm-count multisection) and Z[b][n][k] their
+ *                     unit eigenvectors (twisted factorisation: close eigenvalues leave them only NEARLY orthogonal -- the host
+ *                     shim orthonormalises Z with ttr_qr and falls back when a column collapses);
+ *                     scratch: ttr_eigsel_scratch_bytes(dtype, n, batch)
+ *   ttr_tridiag_back  Z[b] <- Q[b] Z[b] (in place), A / tau as left by ttr_tridiag
+ */
+int ttr_eigsel_max_n(void);
+int64_t ttr_eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch);
+int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau, void* stream);
+int ttr_tri_eigsel(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,
+                   int64_t scratch_bytes, void* stream);
+int ttr_tridiag_back(int dtype, int64_t n, int64_t batch, int64_t k, const void* A, int64_t lda, int64_t strideA, const void* tau,
+                     void* Z, void* stream);
 
 /*
  * Block-Jacobi driver for symmetric eigenproblems above the single-workgroup limit -- torch.linalg.eigh / svd of

@@ -750,3 +750,26 @@ def test_qr_apply_pushed_gram(Rin, I, n):
     # shapes the fused epilogue does not cover fall back to (Out, None)
     out5, G5 = h.qr_apply(f, C[:, :, :5].contiguous(), want_gram=True)
     assert G5 is None and out5.shape == (B, k * I, 5)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n,k,B,graded", [(256, 8, 3, False), (128, 16, 2, False), (200, 5, 2, True), (512, 32, 1, False),
+                                          (65, 64, 1, False), (256, 1, 2, True), (256, 40, 2, True)])
+def test_eigh_topk(dt, n, k, B, graded):
+    """Selected eigenpairs above one workgroup (ttr_tridiag -> ttr_tri_eigsel -> ttr_qr -> ttr_tridiag_back): the k largest
+    eigenvalues vs LAPACK, orthonormality and residual of the vectors; flat (Marchenko-Pastur) and graded spectra."""
+    h = _hip()
+    g = torch.Generator().manual_seed(7 * n + k)
+    Mx = torch.randn(B, n, 3 * n + 1, generator=g, dtype=torch.float64)
+    if graded:
+        Mx = Mx * (0.9 ** torch.arange(n, dtype=torch.float64))[None, :, None]
+    G = (Mx @ Mx.transpose(1, 2)).to(dt)
+    X, lam, rmin = h.eigh_topk(G.cuda(), k)
+    X, lam, rmin = X.cpu().double(), lam.cpu().double(), rmin.cpu().double()
+    wref = torch.linalg.eigvalsh(G.double()).flip(-1)
+    assert X.shape == (B, n, k) and lam.shape == (B, k)
+    assert ((lam - wref[:, :k]).abs().max(dim=1).values / wref[:, 0]).max() < tol(dt, 3e-6, 1e-13)
+    assert (X.transpose(1, 2) @ X - torch.eye(k, dtype=torch.float64)).abs().max() < tol(dt, 5e-6, 1e-12)
+    resid = (G.double() @ X - X * lam[:, None, :]).abs().max() / wref.max()
+    assert resid < tol(dt, 2e-5, 1e-11)
+    assert rmin.min() > 0.5

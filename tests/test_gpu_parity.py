@@ -1251,3 +1251,28 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
     assert rel_diff(dense(res[0.125]), dense(res[0.0])) <= 1e-12
     ref = oracle.round_tt([c.clone() for c in inp], eps=1e-6, algorithm="svd")
     assert ranks(res[0.125]) == ranks(ref) and rel_diff(dense(res[0.125]), dense(ref)) <= 1e-12
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e18, 1e-18])
+def test_dense_batch_range_guard_from_the_first_gram_matrix(scale, monkeypatch):
+    """Batch-mode dense -> TT in fp32: from 256 MB on the range guard is read off the trace of the first bond's Gram matrix instead of
+    a norm pass over the input (forced here on a small input).  In range: the same kernels on the same data, bit-identical; out of
+    range (Gram entries overflow / fall into the denormals): the sweep restarts on the scaled input and agrees with the eager guard."""
+    from tntorch_amd import _hipops
+    torch.manual_seed(6)
+    X = (torch.randn(3, 12, 11, 10, 9, dtype=torch.float64) * scale).float().cuda()
+    out = {}
+    for lazy, limit in (("lazy", 0), ("eager", 1 << 60)):
+        monkeypatch.setattr(_hipops, "_LAZY_GUARD_BYTES", limit)
+        t = tn.Tensor(X, ranks_tt=4, batch=True)
+        out[lazy] = [c.cpu() for c in t.cores]
+        assert all(torch.isfinite(c).all() for c in out[lazy])
+    if scale == 1.0:
+        assert all(torch.equal(a, b) for a, b in zip(out["lazy"], out["eager"]))
+    for i in range(3):
+        a = dense([c[i].double() for c in out["lazy"]]) / scale
+        b = dense([c[i].double() for c in out["eager"]]) / scale
+        assert rel_diff(a, b) <= 1e-5
+        ref = oracle.dense_to_tt((X[i].cpu().double() / scale).float(), 4)
+        e_o, e_r = rel_diff(a, X[i].cpu().double() / scale), rel_diff(dense(ref), (X[i].cpu().double() / scale))
+        assert abs(e_o - e_r) <= 1e-5

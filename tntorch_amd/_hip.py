@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 4  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 5  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -103,6 +103,11 @@ _SIGNATURES = {
          c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
     "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "ttr_eigsel_max_n": (c_int, []),
+    "ttr_eigsel_scratch_bytes": (c_int64, [c_int, c_int64, c_int64]),
+    "ttr_tridiag": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ttr_tri_eigsel": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ttr_tridiag_back": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_bj_solve": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_apply": (
@@ -549,6 +554,36 @@ def eigh_trunc(
     return V, sigma, info
 
 
+@_on_device
+def eigh_topk(G: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The k largest eigenpairs of symmetric [batch, n, n] (64 < n <= ttr_eigsel_max_n(), k <= 64): tridiagonalisation,
+    multisection + twisted factorisation on the tridiagonal matrix, TSQR of the k vectors, back-transformation (ttr_tridiag,
+    ttr_tri_eigsel, ttr_qr, ttr_tridiag_back).  Returns (X [batch, n, k] orthonormal, lam [batch, k] descending,
+    rmin [batch] = the smallest |R_jj| of the orthonormalisation: well below 1 when two of the k vectors nearly coincided --
+    clustered or multiple eigenvalues, which this solver does not resolve; the caller decides)."""
+    L = lib()
+    dt = dtype_code(G.dtype)
+    batch, n, _ = G.shape
+    A = G.contiguous().clone()  # destroyed by the reduction
+    d = torch.empty((batch, n), dtype=G.dtype, device=G.device)
+    e = torch.empty_like(d)
+    tau = torch.empty_like(d)
+    lam = torch.empty((batch, k), dtype=G.dtype, device=G.device)
+    Z = torch.empty((batch, n, k), dtype=G.dtype, device=G.device)
+    if batch == 0:
+        return Z, lam, torch.empty((0,), dtype=G.dtype, device=G.device)
+    _check(L.ttr_tridiag(dt, n, batch, A.data_ptr(), n, n * n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), _stream()), "ttr_tridiag")
+    sb = L.ttr_eigsel_scratch_bytes(dt, n, batch)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=G.device)
+    _check(L.ttr_tri_eigsel(dt, n, batch, int(k), d.data_ptr(), e.data_ptr(), lam.data_ptr(), Z.data_ptr(), scratch.data_ptr(), sb,
+                            _stream()), "ttr_tri_eigsel")
+    Zq, R = qr(Z)
+    rmin = torch.diagonal(R, dim1=1, dim2=2).abs().amin(dim=1)
+    Zq = Zq.contiguous()
+    _check(L.ttr_tridiag_back(dt, n, batch, int(k), A.data_ptr(), n, n * n, tau.data_ptr(), Zq.data_ptr(), _stream()), "ttr_tridiag_back")
+    return Zq, lam, rmin
+
+
 _BJ_TABLES: dict = {}
 
 
@@ -764,6 +799,11 @@ def colproject(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, si
     batch, rows, n = M.shape
     V2, ldv2, sV2 = _mat(V2)
     v1p, ldv1, sV1 = None, 0, 0
+    if V1 is not None and rows >= 4096:
+        # tall inputs: U = V1 V2[:, :ro] as one small GEMM up front -- the kernel without the prologue product keeps a third of
+        # the LDS and three times the workgroups per CU (its main loop covers the HBM latency with resident waves alone)
+        V2, ldv2, sV2 = _mat(gemm(V1, V2[:, :, :ro]))
+        V1 = None
     if V1 is not None:
         V1, ldv1, sV1 = _mat(V1)
         v1p = V1.data_ptr()

@@ -308,14 +308,43 @@ def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, ca
     return _hip.gemm(Vs, P2), sig, info
 
 
+# Selected eigenpairs instead of a full decomposition (csrc/ttr_eigsel.hip): batch mode with a rank cap far below the size of the
+# bond's Gram matrix -- only the top of the spectrum is ever looked at (BASELINE config C3: n = 256, rmax = 8; the block-Jacobi
+# driver needs ~170 launches per such bond).  TTR_EIGH_TOPK=0 switches it off.
+EIGH_TOPK_ENABLED = os.environ.get("TTR_EIGH_TOPK", "1") != "0"
+_TOPK_MAX_RANK = 32
+
+
+def _topk_one_pass(G: torch.Tensor, r: int):
+    """Pass 1 of a batch-mode 'svd' truncation as the answer, from the r largest eigenpairs of the Gram matrix alone: returns
+    (V [B, n, r], sigma [B, r], info [B]) when EVERY item's kept singular values are flat (sigma_r >= FLAT_SPECTRUM_THR sigma_1:
+    the first Gram pass carries them to a few eps, see ``truncate``) and the solver resolved them (no collapsed vector: clustered
+    or multiple eigenvalues are the block-Jacobi driver's job), else None.  One flag readback, like the full-decomposition variant
+    of the same decision."""
+    Bt, n, _ = G.shape
+    if not EIGH_TOPK_ENABLED or n <= 64 or n > _hip.lib().ttr_eigsel_max_n() or r > _TOPK_MAX_RANK or 4 * r > n:
+        return None
+    Gn, ex = _hip.pow2_normalize(G)                    # ||G[b]|| in [0.5, 1): the reduction squares the entries
+    X, lam, rmin = _hip.eigh_topk(Gn, r)
+    lam = _hip.scale_batch(lam, expo=ex, expo_sign=+1)  # exact
+    sig = lam.clamp_min(0).sqrt()                      # ([B, r]: epilogue of the solver, as the eigensolver kernels' own sqrt)
+    ok = _hip.spectrum_flat(sig, r, FLAT_SPECTRUM_THR) * (rmin > 0.5).to(torch.int32)
+    zero = sig[:, 0] < 1e-13                           # zero guard, round.py:137-145 (an all-zero item is "flat" as well)
+    if int((ok + zero.to(torch.int32)).amin().item()) < 1:  # (readback: control flow only)
+        return None
+    info = torch.where(zero, 0, r).to(torch.int32)
+    return X, sig, info
+
+
 class Truncation:
     """Result of ``truncate``: ``left_core`` (m x r), optional column scale, ``right`` (r x n)."""
 
-    __slots__ = ("left", "colscale", "right", "rank", "zero", "info")
+    __slots__ = ("left", "colscale", "right", "rank", "zero", "info", "gtrace")
 
-    def __init__(self, left, colscale, right, rank, zero=False, info=None):
+    def __init__(self, left, colscale, right, rank, zero=False, info=None, gtrace=None):
         self.left, self.colscale, self.right, self.rank, self.zero = left, colscale, right, rank, zero
         self.info = info  # [B] int32 from the eigensolver epilogue: the item's rank by the rank rule, 0 = zero guard (round.py:137-145)
+        self.gtrace = gtrace  # [B] trace of the first Gram matrix = ||M[b]||_F^2 (device; ``want_trace``): the fp32 range guard without a pass over M
 
     def left_scaled(self) -> torch.Tensor:
         if self.colscale is None:
@@ -348,6 +377,11 @@ def _deferred_readback(x: torch.Tensor):
 FLAT_SPECTRUM_THR = float(os.environ.get("TTR_FLAT_SPECTRUM_THR", "0.125"))
 
 
+def _gram_trace(G: torch.Tensor) -> torch.Tensor:
+    """[B] trace of a Gram matrix [B, n, n] or of its split partials [B, parts, n, n] (a few hundred numbers: the only arithmetic)."""
+    return torch.diagonal(G, dim1=-2, dim2=-1).reshape(G.shape[0], -1).sum(dim=1)
+
+
 def _select_rank(info: torch.Tensor, batch: bool, rmax: Optional[int], k: int) -> int:
     if batch:  # round.py:149-150: no eps truncation, no device->host sync
         return _rank_cap(rmax, k)
@@ -369,6 +403,7 @@ def truncate(
     scratch_ok: bool = False,
     gram: Optional[torch.Tensor] = None,
     delta2_dev: Optional[torch.Tensor] = None,
+    want_trace: bool = False,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
@@ -380,6 +415,9 @@ def truncate(
     from device memory, the factors are computed at the rank cap ``min(rmax, k)``, the selected rank stays on the device
     (``Truncation.info``) and the columns of ``left`` beyond it are zeroed there (``ttr_mask_cols``): the caller slices the
     cores once, at the end of its sweep, after ONE readback of all ranks.
+
+    ``want_trace``: also return ``Truncation.gtrace`` = trace of the first Gram matrix (the tall column sweep and the GEMM
+    path: the shapes of a dense TT-SVD's first steps).
 
     ``left_ortho=False`` (the branch round_tt uses): ``right`` has orthonormal rows,
     ``left * colscale`` carries the singular values.  ``left_ortho=True``: ``left`` is
@@ -439,37 +477,47 @@ def truncate(
         # kernels with the contraction over the rows.  The unfolding is read three times ('eig': twice) and only the
         # carry (r / n of its size) is written -- no rotated copy of the input.
         V1 = None
+        G0 = _hip.colgram(M)
+        gtr = _gram_trace(G0) if want_trace else None
         if algorithm == "svd":
-            V1, sig1, _ = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            V1, sig1, _ = _hip.eigh_trunc(G0, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR) if (batch and FLAT_SPECTRUM_THR > 0) else None
             V, sig, info = _hip.eigh_trunc(_hip.colgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE,
                                            skip_items=flat, sigma_in=sig1 if flat is not None else None)  # (as the row sweep above)
         else:
-            V, sig, info = _hip.eigh_trunc(_hip.colgram(M), _hip.EIG_REF, use_delta, delta2, cap,
+            V, sig, info = _hip.eigh_trunc(G0, _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG)
         r = _select_rank(info, batch, rmax, k)
         if r == 0:
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
-                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True)
+                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True, gtrace=gtr)
         left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
         if algorithm == "svd" and left_ortho:
             _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
-        return Truncation(left, None, right, r, info=info)
+        return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
     one_pass = None
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+        gtr = _gram_trace(G) if want_trace else None
         # Batch mode: pass 1 is run to full accuracy and, when EVERY item's kept singular values lie within 1 / FLAT_SPECTRUM_THR
         # of each other, it is the answer (see the fused path above) -- the rotation GEMM, the second Gram matrix and the
         # second eigenproblem, i.e. two of the three passes over M, are not enqueued at all.  The decision concerns launches
         # on the host, hence one flag readback per such bond (dense batches: BASELINE config C3; the bonds of a TT-to-TT
         # rounding have <= 64 rows and decide per item on the device).  Otherwise pass 1 is a pre-rotation.
         try_flat = batch and FLAT_SPECTRUM_THR > 0
-        V1, sig1, info1 = _eigh_any(G, _hip.EIG_RAW, False, 0.0, cap if try_flat else k, _hip.SOLVER_TRIDIAG,
-                                    prerotation=not try_flat)
-        if try_flat and int(_hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR).amin().item()) == 1:
+        if try_flat:
+            one_pass = _topk_one_pass(G, _rank_cap(rmax, k))
+        if one_pass is not None:
+            V1, Mw = None, M
+        else:
+            V1, sig1, info1 = _eigh_any(G, _hip.EIG_RAW, False, 0.0, cap if try_flat else k, _hip.SOLVER_TRIDIAG,
+                                        prerotation=not try_flat)
+        if one_pass is not None:
+            pass
+        elif try_flat and int(_hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR).amin().item()) == 1:
             one_pass = (V1, sig1, info1)
             V1, Mw = None, M
         elif left_side:
@@ -491,6 +539,7 @@ def truncate(
         V1 = None
         Mw = M
         G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+        gtr = _gram_trace(G) if want_trace else None
 
     # 'eig' (and pass 1 above): absolute accuracy is all a plain Gram matrix carries -> tridiagonal QL solver;
     # pass 2 of 'svd': graded, accurately formed Gram matrix -> Jacobi (relative accuracy of the small sigmas)
@@ -508,7 +557,7 @@ def truncate(
     if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
         z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)
         z_r = torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device)
-        return Truncation(z_l, None, z_r, 1, zero=True)
+        return Truncation(z_l, None, z_r, 1, zero=True, gtrace=gtr)
     Vr = V[:, :, :r]
 
     if left_side:
@@ -521,7 +570,7 @@ def truncate(
             if dead_rel is not None:
                 _hip.orth_fixup(right, sig, r, dead_rel)
         U = _hip.gemm(V1, Vr) if V1 is not None else Vr
-        return Truncation(U, None if left_ortho else sig, right, r, info=info)
+        return Truncation(U, None if left_ortho else sig, right, r, info=info, gtrace=gtr)
     # right side: left = Mw Vr (= U sigma); right = (V1 Vr)^T
     if left_ortho:
         left = _hip.gemm(Mw, Vr, colscale=sig, colscale_mode=_hip.SCALE_DIV)
@@ -537,7 +586,7 @@ def truncate(
             right = _hip.gemm(Vr, V1, transA=True, transB=True)
         else:
             right = Vr.transpose(1, 2).contiguous()
-    return Truncation(left, None, right, r, info=info)
+    return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
 
 def _scale_batch(X: torch.Tensor, e: torch.Tensor, sign: int) -> torch.Tensor:
@@ -1096,12 +1145,16 @@ def dense_tucker_tt(X: torch.Tensor, ranks_tucker, ranks_tt, algorithm, batch):
     return dense_tt_svd(X, 1e-14, list(ranks_tt), algorithm, batch), Us
 
 
+_LAZY_GUARD_BYTES = 1 << 28   # dense inputs from 256 MB: the fp32 range guard of a batch-mode TT-SVD comes from the first Gram matrix
+
+
 def dense_tt_svd(
     X: torch.Tensor,
     eps: float,
     rmax: Sequence[Optional[int]],
     algorithm: str,
     batch: bool,
+    _guard_scaled: Optional[torch.Tensor] = None,
 ) -> List[torch.Tensor]:
     """Dense [B, I_1..I_N] -> TT cores [B, r, I, r'] by a right-to-left TT-SVD on the unfoldings.
 
@@ -1115,22 +1168,37 @@ def dense_tt_svd(
     N = len(shape)
     if N == 1:
         return [X.reshape(Bt, 1, shape[0], 1).clone()]
-    nr = _hip.norm(X.reshape(Bt, -1))  # ONE pass over the input: delta and the fp32 range guard both come from it
-    if batch:
-        delta = None
-    else:
-        delta = eps / max(1.0, math.sqrt(N - 1)) * float(nr[0].item())
-    e = _range_guard_from_norms(nr)
-    if e is not None:  # ||X|| outside 2^+-40 in fp32: every bond's Gram matrix would leave the range
-        X = _scale_batch(X, e, -1)
-        if delta is not None:
-            delta = delta * 2.0 ** (-int(e[0].item()))
+    # Batch mode needs no delta, and the fp32 range guard can be read off the first bond's Gram matrix (its trace is ||X[b]||^2):
+    # a config-scale input is then not read a third time for its norm (C3: 1.2 of 15 ms, C1: 33 of 730).  The first truncation is
+    # enqueued optimistically; an out-of-range trace (rare) restarts the sweep on the scaled input.
+    lazy_guard = _guard_scaled is None and batch and X.dtype == torch.float32 and X.numel() * X.element_size() >= _LAZY_GUARD_BYTES
+    e = _guard_scaled
+    delta = None
+    if not lazy_guard and _guard_scaled is None and (not batch or X.dtype == torch.float32):
+        nr = _hip.norm(X.reshape(Bt, -1))  # ONE pass over the input: delta and the fp32 range guard both come from it
+        if not batch:
+            delta = eps / max(1.0, math.sqrt(N - 1)) * float(nr[0].item())
+        e = _range_guard_from_norms(nr)
+        if e is not None:  # ||X|| outside 2^+-40 in fp32: every bond's Gram matrix would leave the range
+            X = _scale_batch(X, e, -1)
+            if delta is not None:
+                delta = delta * 2.0 ** (-int(e[0].item()))
     cores: List[Optional[torch.Tensor]] = [None] * N
     C = X.reshape(Bt, -1, shape[-1])
     rn = 1
     for kdim in range(N - 1, 0, -1):
         Mk = C.reshape(Bt, -1, shape[kdim] * rn)
-        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1)  # C is our own carry
+        first = lazy_guard and kdim == N - 1
+        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1, want_trace=first)  # C is our own carry
+        if first:
+            tr = t.gtrace
+            bad = tr is None or bool(((~torch.isfinite(tr)) | (tr >= 2.0 ** 80) | ((tr > 0) & (tr <= 2.0 ** -80))).any().item())
+            if bad:  # (readback: control flow only) redo with the norm pass and the scaled input
+                nr = _hip.norm(X.reshape(Bt, -1))
+                e2 = _range_guard_from_norms(nr)
+                if e2 is None:  # (the trace was unavailable or overflowed by accumulation only)
+                    e2 = torch.zeros(Bt, dtype=torch.int32, device=X.device)
+                return dense_tt_svd(_scale_batch(X, e2, -1), eps, rmax, algorithm, batch, _guard_scaled=e2)
         cores[kdim] = t.right.reshape(Bt, t.rank, shape[kdim], rn)
         C = t.left_scaled()
         rn = t.rank

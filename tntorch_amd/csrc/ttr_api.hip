@@ -327,6 +327,14 @@ int bj_apply_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, void*
                       hipStream_t stream);
 int bj_control_dispatch(int dtype, int64_t items, int32_t* ctrl, double* state, const void* gnorm, int relative, double tol,
                         hipStream_t stream);
+int64_t eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch);
+int eigsel_max_n();
+int tridiag_dispatch(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau,
+                     hipStream_t stream);
+int eigsel_dispatch(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,
+                    hipStream_t stream);
+int tridiag_back_dispatch(int dtype, int64_t n, int64_t batch, int64_t k, const void* A, int64_t lda, int64_t strideA, const void* tau,
+                          void* Z, hipStream_t stream);
 int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int eigh_max_n(int dtype);
 int eigh_max_n_lds(int dtype);
@@ -660,6 +668,46 @@ int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && G && V1, TTR_E_INVALID, "ttr_rotgram: null pointer");
   return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream, skip);
+}
+
+int ttr_eigsel_max_n(void) { return eigsel_max_n(); }
+
+int64_t ttr_eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch) {
+  if (!dtype_ok(dtype) || n < 1 || batch < 0) return -1;
+  return eigsel_scratch_bytes(dtype, n, batch);
+}
+
+int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_tridiag: bad dtype %d", dtype);
+  TTR_REQUIRE(n >= 2 && n <= eigsel_max_n(), TTR_E_UNSUPPORTED, "ttr_tridiag: n = %lld outside [2, %d]", (long long)n, eigsel_max_n());
+  TTR_REQUIRE(batch >= 0 && lda >= n, TTR_E_INVALID, "ttr_tridiag: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(A && d && e && tau, TTR_E_INVALID, "ttr_tridiag: null pointer");
+  return tridiag_dispatch(dtype, n, batch, A, lda, strideA, d, e, tau, (hipStream_t)stream);
+}
+
+int ttr_tri_eigsel(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,
+                   int64_t scratch_bytes, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_tri_eigsel: bad dtype %d", dtype);
+  TTR_REQUIRE(n >= 2 && n <= eigsel_max_n() && k >= 1 && k <= 64 && k <= n, TTR_E_UNSUPPORTED,
+              "ttr_tri_eigsel: n = %lld, k = %lld outside n in [2, %d], k in [1, min(64, n)]", (long long)n, (long long)k, eigsel_max_n());
+  TTR_REQUIRE(batch >= 0, TTR_E_INVALID, "ttr_tri_eigsel: bad batch");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(d && e && lam && Z && scratch, TTR_E_INVALID, "ttr_tri_eigsel: null pointer");
+  TTR_REQUIRE(scratch_bytes >= eigsel_scratch_bytes(dtype, n, batch), TTR_E_WORKSPACE, "ttr_tri_eigsel: scratch %lld < %lld bytes",
+              (long long)scratch_bytes, (long long)eigsel_scratch_bytes(dtype, n, batch));
+  return eigsel_dispatch(dtype, n, batch, k, d, e, lam, Z, scratch, (hipStream_t)stream);
+}
+
+int ttr_tridiag_back(int dtype, int64_t n, int64_t batch, int64_t k, const void* A, int64_t lda, int64_t strideA, const void* tau,
+                     void* Z, void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_tridiag_back: bad dtype %d", dtype);
+  TTR_REQUIRE(n >= 2 && n <= eigsel_max_n() && k >= 1 && k <= 64, TTR_E_UNSUPPORTED, "ttr_tridiag_back: n = %lld, k = %lld unsupported",
+              (long long)n, (long long)k);
+  TTR_REQUIRE(batch >= 0 && lda >= n, TTR_E_INVALID, "ttr_tridiag_back: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(A && tau && Z, TTR_E_INVALID, "ttr_tridiag_back: null pointer");
+  return tridiag_back_dispatch(dtype, n, batch, k, A, lda, strideA, tau, Z, (hipStream_t)stream);
 }
 
 int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,

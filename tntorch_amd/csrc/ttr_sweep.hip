@@ -363,7 +363,7 @@ struct ColArgs {
 };
 
 template <typename T, bool ROT>
-__global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? (ROT ? 3 : 4) : 1)) void colgram_kernel(ColArgs<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
   constexpr int RED = 4 * 10 * 256;
@@ -390,11 +390,25 @@ __global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
   int64_t cb, ce;
   split_range((p.rows + 15) / 16, p.nsplit, split, cb, ce);
   const bool al = ((p.ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0);
-  for (int64_t c = cb + wave; c < ce; c += 4) {
-    const int64_t r0 = c * 16;
-    Acc mw[4];
-    if constexpr (!ROT) {
-      // lane (g, cl), register r <-> M[r0 + 4 g + r][16 t + cl]
+  const int ntl = (n + 15) >> 4;  // column tiles that exist: the Gram tiles beyond them are zero (n = 32: 3 of the 10 tile pairs)
+  auto gram_update = [&](const Acc (&mw)[4]) {
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < 4; ++tj) {
+        if (tj < ntl) {  // (wave-uniform)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
+        }
+        ++idx;
+      }
+  };
+  if constexpr (!ROT) {
+    // lane (g, cl), register r <-> M[r0 + 4 g + r][16 t + cl]; the next slab's loads are issued before this slab's MFMAs (the
+    // loop has no stores: the loads of two slabs per wave are in flight -- four workgroups per CU do not cover an HBM round trip)
+    auto load_slab = [&](int64_t c, Acc (&mw)[4]) {
+      const int64_t r0 = c * 16;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -403,7 +417,31 @@ __global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
           const int col = 16 * t + cl;
           mw[t][r] = (row < p.rows && col < n) ? Mp[row * p.ldm + col] : T(0);
         }
+    };
+    if (ntl <= 2) {  // (measured: at n = 32 the prefetch gives 2.6 -> 4.4 TB/s together with the tile skip; at n = 64 it costs 7 %)
+      Acc cur[4], nxt[4];
+      int64_t c = cb + wave;
+      if (c < ce) load_slab(c, cur);
+      for (; c < ce; c += 4) {
+        const bool more = c + 4 < ce;
+        if (more) load_slab(c + 4, nxt);
+        gram_update(cur);
+        if (more) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+        }
+      }
     } else {
+      for (int64_t c = cb + wave; c < ce; c += 4) {
+        Acc mw[4];
+        load_slab(c, mw);
+        gram_update(mw);
+      }
+    }
+  } else {
+    for (int64_t c = cb + wave; c < ce; c += 4) {
+      const int64_t r0 = c * 16;
+      Acc mw[4];
       // A operand: lane (i = cl, g) holds M[r0 + cl][16 kk + 4 g + u]; K step (kk, u) <-> k = 16 kk + 4 g + u
       T a[4][4];
       const int64_t row = r0 + cl;
@@ -422,16 +460,8 @@ __global__ __launch_bounds__(kThreads) void colgram_kernel(ColArgs<T> p) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) mw[t] = M::mma(a[kk][u], Vl[(16 * kk + 4 * g + u) * CLD + 16 * t + cl], mw[t]);
       }
+      gram_update(mw);
     }
-    int idx = 0;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int tj = ti; tj < 4; ++tj) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
-        ++idx;
-      }
   }
   __syncthreads();
 #pragma unroll
@@ -465,13 +495,17 @@ __global__ __launch_bounds__(kThreads) void sum_parts_kernel(const T* __restrict
   }
 }
 
-template <typename T>
+// HASV1 = false (U = V2[:, :ro] given: no prologue product): the kernel keeps 17 KB of LDS instead of 55 KB -- six workgroups per
+// CU instead of two.  Its main loop cannot prefetch (the step's stores sit between the loads and their use in one in-order
+// counter, see project_kernel), so the HBM round trip is covered by resident waves alone; the host shim forms U with one small
+// GEMM for tall inputs.
+template <typename T, bool HASV1>
 __global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
   using M = Mfma<T>;
   using Acc = typename M::Acc;
   constexpr int V1LD = 66;
-  __shared__ __attribute__((aligned(16))) T V2l[64 * KLD];   // V2[:, :ro] as [m][i] (prologue only)
-  __shared__ __attribute__((aligned(16))) T V1l[64 * V1LD];  // V1 as [k][m] (prologue only)
+  __shared__ __attribute__((aligned(16))) T V2l[HASV1 ? 64 * KLD : 4];   // V2[:, :ro] as [m][i] (prologue only)
+  __shared__ __attribute__((aligned(16))) T V1l[HASV1 ? 64 * V1LD : 4];  // V1 as [k][m] (prologue only)
   __shared__ __attribute__((aligned(16))) T Ul[64 * CLD];    // U = V1 V2[:, :ro] as [k][i], zero padded
   __shared__ T csc[64];                                      // column scale of left (1 / sigma or 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
@@ -483,15 +517,20 @@ __global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
   const T* __restrict__ V2 = p.V2 + b * p.strideV2;
   const T* __restrict__ sg = p.sigma ? p.sigma + b * p.stride_sigma : nullptr;
   T* __restrict__ Rt = (p.right && split == 0) ? p.right + b * p.strideR : nullptr;
-  for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-    const int m = idx >> 6, i = idx & 63;
-    V2l[m * KLD + i] = (m < n && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
-  }
-  if (p.V1) {
+  if constexpr (HASV1) {
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int m = idx >> 6, i = idx & 63;
+      V2l[m * KLD + i] = (m < n && i < ro) ? V2[(int64_t)m * p.ldv2 + i] : T(0);
+    }
     const T* __restrict__ V1 = p.V1 + b * p.strideV1;
     for (int idx = tid; idx < 64 * 64; idx += kThreads) {
       const int k = idx >> 6, m = idx & 63;
       V1l[k * V1LD + m] = (k < n && m < n) ? V1[(int64_t)k * p.ldv1 + m] : T(0);
+    }
+  } else {
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+      const int k = idx >> 6, i = idx & 63;
+      Ul[k * CLD + i] = (k < n && i < ro) ? V2[(int64_t)k * p.ldv2 + i] : T(0);
     }
   }
   if (tid < 64) {
@@ -503,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
     csc[tid] = sc;
   }
   __syncthreads();
-  if (p.V1) {  // wave w: rows 16 w .. 16 w + 15 of U, straight from the accumulators to LDS
+  if constexpr (HASV1) {  // wave w: rows 16 w .. 16 w + 15 of U, straight from the accumulators to LDS
     Acc u0 = M::zero(), u1 = M::zero(), u2 = M::zero(), u3 = M::zero();
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -521,13 +560,8 @@ __global__ __launch_bounds__(kThreads) void colproject_kernel(ColArgs<T> p) {
       dst[32] = u2[r];
       dst[48] = u3[r];
     }
-  } else {
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-      const int k = idx >> 6, i = idx & 63;
-      Ul[k * CLD + i] = V2l[k * KLD + i];
-    }
+    __syncthreads();
   }
-  __syncthreads();
   if (Rt) {  // right = [diag(sigma)] U^T, coalesced, from the LDS image
     for (int idx = tid; idx < ro * n; idx += kThreads) {
       const int i = idx / n, k = idx - i * n;
@@ -648,7 +682,8 @@ static int colproject_typed(int64_t rows, int64_t n, int64_t ro, int64_t batch, 
     if (sigma) q.sigma = p.sigma + b0 * stride_sigma;
     q.left = p.left + b0 * strideL;
     if (right) q.right = p.right + b0 * strideR;
-    hipLaunchKernelGGL(colproject_kernel<T>, dim3((unsigned)p.nsplit, (unsigned)nb), dim3(kThreads), 0, stream, q);
+    if (q.V1) hipLaunchKernelGGL((colproject_kernel<T, true>), dim3((unsigned)p.nsplit, (unsigned)nb), dim3(kThreads), 0, stream, q);
+    else hipLaunchKernelGGL((colproject_kernel<T, false>), dim3((unsigned)p.nsplit, (unsigned)nb), dim3(kThreads), 0, stream, q);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
