@@ -234,7 +234,7 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  * eps-mode sweep that keeps it on the device enqueues every bond without a host synchronisation. */
 
 /*
- * Selected eigenpairs of symmetric matrices with 64 < n <= ttr_eigsel_max_n() (512): the k <= 64 LARGEST eigenvalues and their
+ * Selected eigenpairs of symmetric matrices with 64 < n <= ttr_eigsel_max_n() (1024): the k <= 64 LARGEST eigenvalues and their
  * eigenvectors -- torch.linalg.eigh / svd of round.py:96, 115 on the Gram matrix of a dense TT-SVD bond when only the top of the
  * spectrum is looked at (batch mode with a rank cap far below n: BASELINE config C3, n = 256, rmax = 8).  LAPACK syevx class:
  *   ttr_tridiag       A[b] (n x n symmetric, leading dimension lda, DESTROYED) = Q T Q^T by Householder reflectors, one

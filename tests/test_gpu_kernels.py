@@ -754,7 +754,7 @@ def test_qr_apply_pushed_gram(Rin, I, n):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("n,k,B,graded", [(256, 8, 3, False), (128, 16, 2, False), (200, 5, 2, True), (512, 32, 1, False),
-                                          (65, 64, 1, False), (256, 1, 2, True), (256, 40, 2, True)])
+                                          (65, 64, 1, False), (256, 1, 2, True), (256, 40, 2, True), (1024, 16, 1, False)])
 def test_eigh_topk(dt, n, k, B, graded):
     """Selected eigenpairs above one workgroup (ttr_tridiag -> ttr_tri_eigsel -> ttr_qr -> ttr_tridiag_back): the k largest
     eigenvalues vs LAPACK, orthonormality and residual of the vectors; flat (Marchenko-Pastur) and graded spectra."""

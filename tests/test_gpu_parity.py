@@ -1254,6 +1254,28 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e18, 1e-18])
+def test_dense_single_norm_from_the_first_gram_matrix(scale, monkeypatch):
+    """A single config-scale dense tensor (forced here on a small one): ||X|| -- delta and the fp32 range guard -- comes from the trace
+    of the first bond's Gram matrix, which is handed on to the first truncation; out of range it falls back to the norm pass and
+    the scaled input.  Same result as the eager path (in range: delta differs by fp32 rounding of the trace only)."""
+    from tntorch_amd import _hipops
+    torch.manual_seed(8)
+    low = oracle.tt_to_dense(oracle.tt_randn([12, 11, 10, 9], 3, dtype=torch.float64))
+    X = ((low / low.norm() + 1e-4 * torch.randn(low.shape, dtype=torch.float64) / math.sqrt(low.numel())) * scale).float()
+    out = {}
+    for mode, limit in (("lazy", 0), ("eager", 1 << 60)):
+        monkeypatch.setattr(_hipops, "_LAZY_GUARD_BYTES", limit)
+        for kw in ({"ranks_tt": 3}, {"eps": 1e-3}):
+            t = tn.Tensor(X.cuda(), **kw)
+            out[mode, tuple(kw)] = [c.cpu() for c in t.cores]
+            assert all(torch.isfinite(c).all() for c in out[mode, tuple(kw)])
+    for kw in (("ranks_tt",), ("eps",)):
+        a, b = out["lazy", kw], out["eager", kw]
+        assert ranks(a) == ranks(b)
+        assert rel_diff(dense([c.double() for c in a]) / scale, dense([c.double() for c in b]) / scale) <= 1e-5
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e18, 1e-18])
 def test_dense_batch_range_guard_from_the_first_gram_matrix(scale, monkeypatch):
     """Batch-mode dense -> TT in fp32: from 256 MB on the range guard is read off the trace of the first bond's Gram matrix instead of
     a norm pass over the input (forced here on a small input).  In range: the same kernels on the same data, bit-identical; out of
@@ -1276,3 +1298,40 @@ def test_dense_batch_range_guard_from_the_first_gram_matrix(scale, monkeypatch):
         ref = oracle.dense_to_tt((X[i].cpu().double() / scale).float(), 4)
         e_o, e_r = rel_diff(a, X[i].cpu().double() / scale), rel_diff(dense(ref), (X[i].cpu().double() / scale))
         assert abs(e_o - e_r) <= 1e-5
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_big_bond_truncation_from_selected_eigenpairs(batch, monkeypatch):
+    """Bonds whose Gram matrix is larger than one workgroup (here 144 x 144) with a rank cap far below: a flat spectrum (dense
+    random data) is decided by the r largest eigenpairs alone (ttr_tridiag / ttr_tri_eigsel / ttr_tridiag_back) -- in batch mode
+    and, when the cap provably binds, for a single tensor in eps mode; a decaying spectrum (low rank + noise) is not flat and
+    takes the block-Jacobi path as before (bit-identical to the solver switched off).  Against the oracle either way."""
+    from tntorch_amd import _hip, _hipops
+    torch.manual_seed(9)
+    shape, r = [12, 12, 40, 9], 4
+    Xr = torch.randn(shape, dtype=torch.float64).float()
+    low = oracle.tt_to_dense(oracle.tt_randn(shape, 3, dtype=torch.float64))
+    Xl = (low / low.norm() + 1e-3 * torch.randn(shape, dtype=torch.float64) / math.sqrt(low.numel())).float()
+    calls = []
+    orig = _hip.eigh_topk
+    monkeypatch.setattr(_hip, "eigh_topk", lambda G, k: calls.append(tuple(G.shape)) or orig(G, k))
+
+    def run(X):
+        if batch:
+            t = tn.Tensor(torch.stack([X, 2 * X]).cuda(), ranks_tt=r, batch=True)
+            return [c[0].cpu() for c in t.cores]
+        return [c.cpu() for c in tn.Tensor(X.cuda(), ranks_tt=r).cores]
+
+    for X, flat in ((Xr, True), (Xl, False)):
+        calls.clear()
+        monkeypatch.setattr(_hipops, "EIGH_TOPK_ENABLED", True)
+        ours = run(X)
+        assert any(s[-1] == 144 for s in calls)          # the solver was tried on the 144 x 144 bond ...
+        monkeypatch.setattr(_hipops, "EIGH_TOPK_ENABLED", False)
+        base = run(X)
+        if not flat:                                      # ... and its answer declined: nothing changes
+            assert all(torch.equal(a, b) for a, b in zip(ours, base))
+        ref = oracle.dense_to_tt(X, r)
+        assert ranks(ours) == ranks(ref)
+        e_o, e_b, e_r = rel_diff(dense(ours), X), rel_diff(dense(base), X), rel_diff(dense(ref), X)
+        assert abs(e_o - e_r) <= 1e-5 and abs(e_b - e_r) <= 1e-5

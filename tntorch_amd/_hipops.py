@@ -315,21 +315,28 @@ EIGH_TOPK_ENABLED = os.environ.get("TTR_EIGH_TOPK", "1") != "0"
 _TOPK_MAX_RANK = 32
 
 
-def _topk_one_pass(G: torch.Tensor, r: int):
-    """Pass 1 of a batch-mode 'svd' truncation as the answer, from the r largest eigenpairs of the Gram matrix alone: returns
+def _topk_one_pass(G: torch.Tensor, r: int, use_delta: bool = False, delta2: float = 0.0):
+    """Pass 1 of an 'svd' truncation as the answer, from the r largest eigenpairs of the Gram matrix alone: returns
     (V [B, n, r], sigma [B, r], info [B]) when EVERY item's kept singular values are flat (sigma_r >= FLAT_SPECTRUM_THR sigma_1:
-    the first Gram pass carries them to a few eps, see ``truncate``) and the solver resolved them (no collapsed vector: clustered
-    or multiple eigenvalues are the block-Jacobi driver's job), else None.  One flag readback, like the full-decomposition variant
-    of the same decision."""
+    the first Gram pass carries them to a few eps, see ``truncate``), the solver resolved them (no collapsed vector: clustered
+    or multiple eigenvalues are the block-Jacobi driver's job) and -- in eps mode -- the rank cap provably binds: the tail
+    energy beyond the cap, trace(G) - sum of the r largest eigenvalues, exceeds delta^2 by more than the error margin
+    E = 64 n eps sigma_1^2 of a pass-1 tail energy (the criterion of ttr_spectrum_flat with use_delta).  Else None.  One flag
+    readback, like the full-decomposition variant of the same decision."""
     Bt, n, _ = G.shape
     if not EIGH_TOPK_ENABLED or n <= 64 or n > _hip.lib().ttr_eigsel_max_n() or r > _TOPK_MAX_RANK or 4 * r > n:
         return None
     Gn, ex = _hip.pow2_normalize(G)                    # ||G[b]|| in [0.5, 1): the reduction squares the entries
-    X, lam, rmin = _hip.eigh_topk(Gn, r)
-    lam = _hip.scale_batch(lam, expo=ex, expo_sign=+1)  # exact
+    X, lam_n, rmin = _hip.eigh_topk(Gn, r)
+    lam = _hip.scale_batch(lam_n, expo=ex, expo_sign=+1)  # exact
     sig = lam.clamp_min(0).sqrt()                      # ([B, r]: epilogue of the solver, as the eigensolver kernels' own sqrt)
     ok = _hip.spectrum_flat(sig, r, FLAT_SPECTRUM_THR) * (rmin > 0.5).to(torch.int32)
     zero = sig[:, 0] < 1e-13                           # zero guard, round.py:137-145 (an all-zero item is "flat" as well)
+    if use_delta and delta2 > 0.0:
+        # (a few [B]-sized device scalars, in double: tail beyond the cap against delta^2 + E, everything in G's own units)
+        tail = _gram_trace(G).double() - lam.double().sum(dim=1)
+        margin = 64.0 * n * torch.finfo(G.dtype).eps * lam[:, 0].double().clamp_min(0)
+        ok = ok * (tail > delta2 + margin).to(torch.int32)
     if int((ok + zero.to(torch.int32)).amin().item()) < 1:  # (readback: control flow only)
         return None
     info = torch.where(zero, 0, r).to(torch.int32)
@@ -409,8 +416,8 @@ def truncate(
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
     ``scratch_ok``: M is a temporary of the caller (the carry of a dense TT-SVD) and may be overwritten: a tall M with
     more than 64 columns is then rotated IN PLACE (row chunks) instead of into a second tensor of its size.
-    ``gram``: split partials of M M^T already accumulated by the kernel that produced M (``qr_apply(want_gram=True)``);
-    saves the first of the three passes over M.
+    ``gram``: the first Gram matrix, already formed -- split partials of M M^T accumulated by the kernel that produced M
+    (``qr_apply(want_gram=True)``), or what ``first_gram`` returns (a dense TT-SVD takes ||X|| from its trace).
     ``delta2_dev`` (device double [1], fused <= 64-row path only): eps mode WITHOUT a readback -- the rank rule takes its bound
     from device memory, the factors are computed at the rank cap ``min(rmax, k)``, the selected rank stays on the device
     (``Truncation.info``) and the columns of ``left`` beyond it are zeroed there (``ttr_mask_cols``): the caller slices the
@@ -477,11 +484,12 @@ def truncate(
         # kernels with the contraction over the rows.  The unfolding is read three times ('eig': twice) and only the
         # carry (r / n of its size) is written -- no rotated copy of the input.
         V1 = None
-        G0 = _hip.colgram(M)
+        G0 = gram if gram is not None else _hip.colgram(M)
         gtr = _gram_trace(G0) if want_trace else None
         if algorithm == "svd":
             V1, sig1, _ = _hip.eigh_trunc(G0, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
-            flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR) if (batch and FLAT_SPECTRUM_THR > 0) else None
+            # (batch mode, or eps mode with the rank decision certified on pass 1's sigma: see the row sweep above)
+            flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, use_delta, delta2) if FLAT_SPECTRUM_THR > 0 else None
             V, sig, info = _hip.eigh_trunc(_hip.colgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE,
                                            skip_items=flat, sigma_in=sig1 if flat is not None else None)  # (as the row sweep above)
@@ -500,7 +508,7 @@ def truncate(
     one_pass = None
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
-        G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+        G = gram if gram is not None else (_hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True))
         gtr = _gram_trace(G) if want_trace else None
         # Batch mode: pass 1 is run to full accuracy and, when EVERY item's kept singular values lie within 1 / FLAT_SPECTRUM_THR
         # of each other, it is the answer (see the fused path above) -- the rotation GEMM, the second Gram matrix and the
@@ -508,8 +516,9 @@ def truncate(
         # on the host, hence one flag readback per such bond (dense batches: BASELINE config C3; the bonds of a TT-to-TT
         # rounding have <= 64 rows and decide per item on the device).  Otherwise pass 1 is a pre-rotation.
         try_flat = batch and FLAT_SPECTRUM_THR > 0
-        if try_flat:
-            one_pass = _topk_one_pass(G, _rank_cap(rmax, k))
+        if FLAT_SPECTRUM_THR > 0 and (batch or rmax is not None):
+            # (eps mode with a rank cap -- a single dense tensor to given ranks, BASELINE config C1: only when the cap provably binds)
+            one_pass = _topk_one_pass(G, _rank_cap(rmax, k), use_delta, delta2)
         if one_pass is not None:
             V1, Mw = None, M
         else:
@@ -538,7 +547,7 @@ def truncate(
     else:
         V1 = None
         Mw = M
-        G = _hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True)
+        G = gram if gram is not None else (_hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True))
         gtr = _gram_trace(G) if want_trace else None
 
     # 'eig' (and pass 1 above): absolute accuracy is all a plain Gram matrix carries -> tridiagonal QL solver;
@@ -1145,6 +1154,16 @@ def dense_tucker_tt(X: torch.Tensor, ranks_tucker, ranks_tt, algorithm, batch):
     return dense_tt_svd(X, 1e-14, list(ranks_tt), algorithm, batch), Us
 
 
+def first_gram(M: torch.Tensor) -> torch.Tensor:
+    """The Gram matrix ``truncate`` forms first for M [B, m, n], by the kernel its path selection would use (``gram=``)."""
+    Bt, m, n = M.shape
+    if m <= n and _hip.sweep_fused_ok(M):
+        return _hip.rowgram(M)
+    if m > n and _hip.colsweep_fused_ok(M):
+        return _hip.colgram(M)
+    return _hip.gemm(M, M, transB=True) if m <= n else _hip.gemm(M, M, transA=True)
+
+
 _LAZY_GUARD_BYTES = 1 << 28   # dense inputs from 256 MB: the fp32 range guard of a batch-mode TT-SVD comes from the first Gram matrix
 
 
@@ -1171,10 +1190,21 @@ def dense_tt_svd(
     # Batch mode needs no delta, and the fp32 range guard can be read off the first bond's Gram matrix (its trace is ||X[b]||^2):
     # a config-scale input is then not read a third time for its norm (C3: 1.2 of 15 ms, C1: 33 of 730).  The first truncation is
     # enqueued optimistically; an out-of-range trace (rare) restarts the sweep on the scaled input.
-    lazy_guard = _guard_scaled is None and batch and X.dtype == torch.float32 and X.numel() * X.element_size() >= _LAZY_GUARD_BYTES
+    big = X.numel() * X.element_size() >= _LAZY_GUARD_BYTES
+    lazy_guard = _guard_scaled is None and batch and X.dtype == torch.float32 and big
     e = _guard_scaled
     delta = None
-    if not lazy_guard and _guard_scaled is None and (not batch or X.dtype == torch.float32):
+    gram0 = None
+    if _guard_scaled is None and not batch and big:
+        # a single config-scale tensor (BASELINE C1: 128-192 GiB): ||X||^2 -- delta and the range guard -- is the trace of the first
+        # bond's Gram matrix, which the first truncation needs anyway: formed here, handed on (``gram=``), no pass for the norm
+        gram0 = first_gram(X.reshape(Bt, -1, shape[-1]))
+        tr = float(_gram_trace(gram0)[0].item())      # (readback: delta, as tensor.py:2039-2051)
+        if not math.isfinite(tr) or (X.dtype == torch.float32 and (tr >= 2.0 ** 80 or 0.0 < tr <= 2.0 ** -80)):
+            gram0 = None                               # out of range: the norm pass and the scaled input (below)
+        else:
+            delta = eps / max(1.0, math.sqrt(N - 1)) * math.sqrt(max(tr, 0.0))
+    if gram0 is None and not lazy_guard and _guard_scaled is None and (not batch or X.dtype == torch.float32):
         nr = _hip.norm(X.reshape(Bt, -1))  # ONE pass over the input: delta and the fp32 range guard both come from it
         if not batch:
             delta = eps / max(1.0, math.sqrt(N - 1)) * float(nr[0].item())
@@ -1189,7 +1219,8 @@ def dense_tt_svd(
     for kdim in range(N - 1, 0, -1):
         Mk = C.reshape(Bt, -1, shape[kdim] * rn)
         first = lazy_guard and kdim == N - 1
-        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1, want_trace=first)  # C is our own carry
+        t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1, want_trace=first,
+                     gram=gram0 if kdim == N - 1 else None)  # C is our own carry
         if first:
             tr = t.gtrace
             bad = tr is None or bool(((~torch.isfinite(tr)) | (tr >= 2.0 ** 80) | ((tr > 0) & (tr <= 2.0 ** -80))).any().item())

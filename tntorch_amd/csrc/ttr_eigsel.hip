@@ -1,5 +1,5 @@
 // Selected eigenpairs of symmetric matrices above the single-workgroup eigensolvers (gfx950): the k LARGEST eigenvalues and
-// their eigenvectors of G (n x n, 64 < n <= 512), one workgroup per matrix.
+// their eigenvectors of G (n x n, 64 < n <= 1024), one workgroup per matrix.
 //
 // Where it is used: the Gram matrix of a dense TT-SVD bond (round.py:104-115 at n = I r: BASELINE config C3 has n = 256,
 // rank cap 8) in batch mode, where the rank is the cap and only the top of the spectrum is ever looked at.  The block-Jacobi
@@ -330,7 +330,7 @@ struct BackArgs {
 
 template <typename T>
 __global__ __launch_bounds__(kTdThreads) void tridiag_back_kernel(BackArgs<T> p) {
-  constexpr int RPL = 512 / kWave;  // rows per lane (n <= 512)
+  constexpr int RPL = 1024 / kWave;  // rows per lane (n <= 1024)
   const int n = p.n, k = p.k, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* __restrict__ A = p.A + (int64_t)blockIdx.x * p.strideA;
   const T* __restrict__ tt = p.tau + (int64_t)blockIdx.x * n;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kTdThreads) void tridiag_back_kernel(BackArgs<T> p)
 
 // ---------------------------------------------------------------- dispatch
 int64_t eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch) { return batch * 3 * n * kWave * (dtype == TTR_F64 ? 8 : 4); }
-int eigsel_max_n() { return 512; }
+int eigsel_max_n() { return 1024; }
 
 template <typename T>
 static int tridiag_typed(int64_t n, int64_t batch, T* A, int64_t lda, int64_t strideA, T* d, T* e, T* tau, hipStream_t stream) {
