@@ -54,7 +54,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
    ttr_eigh_trunc = 2; round 3 additions = 3).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 5
+#define TTR_ABI_VERSION 6
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -239,7 +239,9 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  * spectrum is looked at (batch mode with a rank cap far below n: BASELINE config C3, n = 256, rmax = 8).  LAPACK syevx class:
  *   ttr_tridiag       A[b] (n x n symmetric, leading dimension lda, DESTROYED) = Q T Q^T by Householder reflectors, one
  *                     workgroup per matrix; d[b][n], e[b][n] (e[i] couples i and i + 1, e[n-1] = 0), tau[b][n]; reflector k is
- *                     left in row k of A (columns k+1 .., leading 1 stored)
+ *                     left in row k of A (columns k+1 .., leading 1 stored).  `workspace` (optional, ttr_tridiag_workspace_bytes):
+ *                     with it, few (<= 4) big (n >= 512) matrices are reduced by 2 n - 1 launches that spread every step's pass
+ *                     over the whole chip instead of one workgroup per matrix
  *   ttr_tri_eigsel    lam[b][k] = the k largest eigenvalues of T (descending; Sturm-count multisection) and Z[b][n][k] their
  *                     unit eigenvectors (twisted factorisation: close eigenvalues leave them only NEARLY orthogonal -- the host
  *                     shim orthonormalises Z with ttr_qr and falls back when a column collapses);
@@ -248,7 +250,9 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  */
 int ttr_eigsel_max_n(void);
 int64_t ttr_eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch);
-int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau, void* stream);
+int64_t ttr_tridiag_workspace_bytes(int dtype, int64_t n, int64_t batch);
+int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau,
+                void* workspace, int64_t workspace_bytes, void* stream);
 int ttr_tri_eigsel(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,
                    int64_t scratch_bytes, void* stream);
 int ttr_tridiag_back(int dtype, int64_t n, int64_t batch, int64_t k, const void* A, int64_t lda, int64_t strideA, const void* tau,

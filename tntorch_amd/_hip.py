@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 5  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 6  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -105,7 +105,8 @@ _SIGNATURES = {
     "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "ttr_eigsel_max_n": (c_int, []),
     "ttr_eigsel_scratch_bytes": (c_int64, [c_int, c_int64, c_int64]),
-    "ttr_tridiag": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ttr_tridiag_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
+    "ttr_tridiag": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ttr_tri_eigsel": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ttr_tridiag_back": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "ttr_bj_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
@@ -572,7 +573,10 @@ def eigh_topk(G: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torc
     Z = torch.empty((batch, n, k), dtype=G.dtype, device=G.device)
     if batch == 0:
         return Z, lam, torch.empty((0,), dtype=G.dtype, device=G.device)
-    _check(L.ttr_tridiag(dt, n, batch, A.data_ptr(), n, n * n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), _stream()), "ttr_tridiag")
+    wsb = L.ttr_tridiag_workspace_bytes(dt, n, batch)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=G.device)
+    _check(L.ttr_tridiag(dt, n, batch, A.data_ptr(), n, n * n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), ws.data_ptr(), wsb, _stream()),
+           "ttr_tridiag")
     sb = L.ttr_eigsel_scratch_bytes(dt, n, batch)
     scratch = torch.empty(sb, dtype=torch.uint8, device=G.device)
     _check(L.ttr_tri_eigsel(dt, n, batch, int(k), d.data_ptr(), e.data_ptr(), lam.data_ptr(), Z.data_ptr(), scratch.data_ptr(), sb,

@@ -329,8 +329,9 @@ int bj_control_dispatch(int dtype, int64_t items, int32_t* ctrl, double* state, 
                         hipStream_t stream);
 int64_t eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch);
 int eigsel_max_n();
+int64_t tridiag_workspace_bytes(int dtype, int64_t n, int64_t batch);
 int tridiag_dispatch(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau,
-                     hipStream_t stream);
+                     void* ws, hipStream_t stream);
 int eigsel_dispatch(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,
                     hipStream_t stream);
 int tridiag_back_dispatch(int dtype, int64_t n, int64_t batch, int64_t k, const void* A, int64_t lda, int64_t strideA, const void* tau,
@@ -677,13 +678,21 @@ int64_t ttr_eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch) {
   return eigsel_scratch_bytes(dtype, n, batch);
 }
 
-int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau, void* stream) {
+int64_t ttr_tridiag_workspace_bytes(int dtype, int64_t n, int64_t batch) {
+  if (!dtype_ok(dtype) || n < 1 || batch < 0) return -1;
+  return tridiag_workspace_bytes(dtype, n, batch);
+}
+
+int ttr_tridiag(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau,
+                void* workspace, int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_tridiag: bad dtype %d", dtype);
   TTR_REQUIRE(n >= 2 && n <= eigsel_max_n(), TTR_E_UNSUPPORTED, "ttr_tridiag: n = %lld outside [2, %d]", (long long)n, eigsel_max_n());
   TTR_REQUIRE(batch >= 0 && lda >= n, TTR_E_INVALID, "ttr_tridiag: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(A && d && e && tau, TTR_E_INVALID, "ttr_tridiag: null pointer");
-  return tridiag_dispatch(dtype, n, batch, A, lda, strideA, d, e, tau, (hipStream_t)stream);
+  TTR_REQUIRE(!workspace || workspace_bytes >= tridiag_workspace_bytes(dtype, n, batch), TTR_E_WORKSPACE,
+              "ttr_tridiag: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)tridiag_workspace_bytes(dtype, n, batch));
+  return tridiag_dispatch(dtype, n, batch, A, lda, strideA, d, e, tau, workspace, (hipStream_t)stream);
 }
 
 int ttr_tri_eigsel(int dtype, int64_t n, int64_t batch, int64_t k, const void* d, const void* e, void* lam, void* Z, void* scratch,

@@ -186,6 +186,136 @@ __global__ __launch_bounds__(kTdThreads) void tridiag_big_kernel(TridiagArgs<T> 
   }
 }
 
+// ---------------------------------------------------------------- the same reduction spread over the chip (few big matrices)
+// One workgroup per matrix leaves 255 of the 256 CUs idle when there is ONE matrix (config C1: three n = 1024 bonds, ~30 ms each
+// on a single CU).  The fused pass is row- and column-parallel, so here it is a launch of its own over (8-row group) x (256-column
+// chunk) workgroups of one wave each, and what happens between two passes -- w of the previous step from the chunks' partial
+// products, the next reflector from the updated row -- is a one-workgroup launch: 2 n - 1 launches per matrix, no device-side grid
+// synchronisation.  State between launches: v / w of two consecutive steps and the partial products, 8 n elements per matrix.
+template <typename T>
+struct TdmArgs {
+  int n, k;
+  T* A;
+  int64_t lda, strideA;
+  T* d;
+  T* e;
+  T* tau;
+  T* ws;  // [batch][8][n]: V[2][n], W[2][n] (by step parity), PP[4][n]
+};
+constexpr int kTdmCols = 256;  // columns per pass workgroup
+
+// between two passes (one workgroup per matrix).  k = 0: first reflector from the raw row 0.  1 <= k <= n-2: w_{k-1} from the
+// partial products of pass k - 1, then reflector k from the updated row k.  k = n-1: w_{n-2}, last diagonal entry.
+template <typename T>
+__global__ __launch_bounds__(kTdThreads) void tdm_mid_kernel(TdmArgs<T> p) {
+  __shared__ T red[kTdWaves + 1];
+  const int n = p.n, k = p.k, tid = threadIdx.x;
+  const int64_t lda = p.lda;
+  T* __restrict__ A = p.A + (int64_t)blockIdx.x * p.strideA;
+  T* __restrict__ dd = p.d + (int64_t)blockIdx.x * n;
+  T* __restrict__ ee = p.e + (int64_t)blockIdx.x * n;
+  T* __restrict__ tt = p.tau + (int64_t)blockIdx.x * n;
+  T* __restrict__ W0 = p.ws + (int64_t)blockIdx.x * 8 * n;
+  T* Vp = W0 + ((k - 1) & 1) * n;          // v_{k-1}, index 0 <-> row k
+  T* Wp = W0 + (2 + ((k - 1) & 1)) * n;    // w_{k-1}
+  T* Vk = W0 + (k & 1) * n;                // v_k, index 0 <-> row k + 1
+  const T* PP = W0 + 4 * n;
+  T v0 = T(0), w0 = T(0), vmine = T(0), wmine = T(0);  // (v, w)_{k-1} at index 0 and at index 1 + tid
+  if (k >= 1) {
+    const int mo = n - k;  // support of v_{k-1}
+    const int ncc = (mo + kTdmCols - 1) / kTdmCols;
+    T pv = T(0);
+    if (tid < mo)
+      for (int cc = 0; cc < ncc; ++cc) pv += PP[cc * n + tid];
+    const T taup = tt[k - 1];
+    const T vt = tid < mo ? Vp[tid] : T(0);
+    const T dot = td_block_sum(pv * vt, red);
+    const T wt = pv - T(0.5) * taup * dot * vt;
+    if (tid < mo) Wp[tid] = wt;
+    if (tid == 0) { red[kTdWaves] = wt; }
+    __syncthreads();
+    w0 = red[kTdWaves];
+    v0 = T(1);  // (the leading component of every reflector)
+    __syncthreads();
+    // (v, w)_{k-1} at index 1 + tid: the neighbour's values, through global memory (written above by this workgroup)
+    if (tid + 1 < mo) { vmine = Vp[tid + 1]; wmine = Wp[tid + 1]; }
+  }
+  if (k == n - 1) {
+    if (tid == 0) { dd[k] = A[(int64_t)k * lda + k] - T(2) * v0 * w0; ee[k] = T(0); tt[k] = T(0); }
+    return;
+  }
+  const int m = n - k - 1;
+  if (tid == 0) dd[k] = A[(int64_t)k * lda + k] - T(2) * v0 * w0;
+  const T x = tid < m ? A[(int64_t)k * lda + (k + 1) + tid] - (v0 * wmine + w0 * vmine) : T(0);
+  if (tid == 0) red[kTdWaves] = x;
+  const T ss = td_block_sum((tid >= 1 && tid < m) ? x * x : T(0), red);
+  const T alpha = red[kTdWaves];
+  T beta = alpha, tau = T(0), scale = T(0);
+  if (ss != T(0)) {
+    beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+    tau = (beta - alpha) / beta;
+    scale = T(1) / (alpha - beta);
+  }
+  const T v = tid == 0 ? T(1) : x * scale;
+  if (tid < m) {
+    Vk[tid] = v;
+    A[(int64_t)k * lda + (k + 1) + tid] = v;
+  }
+  if (tid == 0) { ee[k] = beta; tt[k] = tau; }
+}
+
+// pass k over the trailing block (rows / columns k+1 ..): a <- a - (v_r w_c + w_r v_c) with (v, w)_{k-1} (k >= 1), and the chunk's
+// share of tau_k A v_k.  One wave per workgroup: UR rows x kTdmCols columns.
+template <typename T>
+__global__ __launch_bounds__(kWave) void tdm_pass_kernel(TdmArgs<T> p) {
+  const int n = p.n, k = p.k, lane = threadIdx.x;
+  const int m = n - k - 1;
+  const int ncc = (m + kTdmCols - 1) / kTdmCols;
+  const int rg = blockIdx.x / ncc, cc = blockIdx.x - rg * ncc;
+  const int r0 = rg * UR, c0 = cc * kTdmCols;
+  const int64_t lda = p.lda;
+  T* __restrict__ A22 = p.A + (int64_t)blockIdx.y * p.strideA + (int64_t)(k + 1) * lda + (k + 1);
+  T* __restrict__ W0 = p.ws + (int64_t)blockIdx.y * 8 * n;
+  const T* __restrict__ Vp = W0 + ((k - 1) & 1) * n;
+  const T* __restrict__ Wp = W0 + (2 + ((k - 1) & 1)) * n;
+  const T* __restrict__ Vk = W0 + (k & 1) * n;
+  T* __restrict__ PP = W0 + 4 * n;
+  const T tau = p.tau[(int64_t)blockIdx.y * n + k];
+  const bool upd = k >= 1;
+  T acc[UR], vr[UR], wr[UR];
+#pragma unroll
+  for (int u = 0; u < UR; ++u) {
+    acc[u] = T(0);
+    const int r = r0 + u < m ? r0 + u : m - 1;
+    vr[u] = upd ? Vp[1 + r] : T(0);
+    wr[u] = upd ? Wp[1 + r] : T(0);
+  }
+  for (int c = c0 + lane; c < m && c < c0 + kTdmCols; c += kWave) {
+    const T vc = upd ? Vp[1 + c] : T(0), wc = upd ? Wp[1 + c] : T(0), nc = Vk[c];
+    T a[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) a[u] = (r0 + u < m) ? A22[(int64_t)(r0 + u) * lda + c] : T(0);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (upd) {
+        a[u] -= vr[u] * wc + wr[u] * vc;
+        if (r0 + u < m) A22[(int64_t)(r0 + u) * lda + c] = a[u];
+      }
+      acc[u] += a[u] * nc;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UR; u += 4) {
+    T q4[4] = {acc[u], acc[u + 1], acc[u + 2], acc[u + 3]};
+    wave_sum4(q4);
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (r0 + u + t < m) PP[cc * n + r0 + u + t] = tau * q4[t];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- k largest eigenpairs of the tridiagonal matrix
 template <typename T>
 struct EigSelArgs {
@@ -369,20 +499,40 @@ __global__ __launch_bounds__(kTdThreads) void tridiag_back_kernel(BackArgs<T> p)
 int64_t eigsel_scratch_bytes(int dtype, int64_t n, int64_t batch) { return batch * 3 * n * kWave * (dtype == TTR_F64 ? 8 : 4); }
 int eigsel_max_n() { return 1024; }
 
+int64_t tridiag_workspace_bytes(int dtype, int64_t n, int64_t batch) { return batch * 8 * n * (dtype == TTR_F64 ? 8 : 4); }
+
+// few big matrices: the multi-launch variant (one matrix per workgroup keeps at most `batch` CUs busy)
+static bool tridiag_spread(int64_t n, int64_t batch) { return n >= 512 && batch <= 4; }
+
 template <typename T>
-static int tridiag_typed(int64_t n, int64_t batch, T* A, int64_t lda, int64_t strideA, T* d, T* e, T* tau, hipStream_t stream) {
+static int tridiag_typed(int64_t n, int64_t batch, T* A, int64_t lda, int64_t strideA, T* d, T* e, T* tau, T* ws, hipStream_t stream) {
+  ProfScope prof(TTR_PROF_EIGH, stream);
+  if (ws && tridiag_spread(n, batch)) {
+    TdmArgs<T> q;
+    q.n = (int)n; q.A = A; q.lda = lda; q.strideA = strideA; q.d = d; q.e = e; q.tau = tau; q.ws = ws;
+    for (int k = 0; k < (int)n; ++k) {
+      q.k = k;
+      hipLaunchKernelGGL(tdm_mid_kernel<T>, dim3((unsigned)batch), dim3(kTdThreads), 0, stream, q);
+      if (k + 1 < (int)n) {
+        const int m = (int)n - k - 1;
+        const unsigned gx = (unsigned)(((m + UR - 1) / UR) * ((m + kTdmCols - 1) / kTdmCols));
+        hipLaunchKernelGGL(tdm_pass_kernel<T>, dim3(gx, (unsigned)batch), dim3(kWave), 0, stream, q);
+      }
+    }
+    TTR_HIP_CHECK(hipGetLastError());
+    return TTR_OK;
+  }
   TridiagArgs<T> p;
   p.n = (int)n; p.A = A; p.lda = lda; p.strideA = strideA; p.d = d; p.e = e; p.tau = tau;
   const size_t lds = ((4 * (size_t)n + kTdWaves + 1) * sizeof(T) + 15) & ~size_t(15);
-  ProfScope prof(TTR_PROF_EIGH, stream);
   hipLaunchKernelGGL(tridiag_big_kernel<T>, dim3((unsigned)batch), dim3(kTdThreads), lds, stream, p);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
 int tridiag_dispatch(int dtype, int64_t n, int64_t batch, void* A, int64_t lda, int64_t strideA, void* d, void* e, void* tau,
-                     hipStream_t stream) {
-  if (dtype == TTR_F32) return tridiag_typed<float>(n, batch, (float*)A, lda, strideA, (float*)d, (float*)e, (float*)tau, stream);
-  return tridiag_typed<double>(n, batch, (double*)A, lda, strideA, (double*)d, (double*)e, (double*)tau, stream);
+                     void* ws, hipStream_t stream) {
+  if (dtype == TTR_F32) return tridiag_typed<float>(n, batch, (float*)A, lda, strideA, (float*)d, (float*)e, (float*)tau, (float*)ws, stream);
+  return tridiag_typed<double>(n, batch, (double*)A, lda, strideA, (double*)d, (double*)e, (double*)tau, (double*)ws, stream);
 }
 
 template <typename T>

@@ -39,9 +39,10 @@ A = Gn.clone(); d = torch.empty(B, n, device="cuda"); e = torch.empty_like(d); t
 lam = torch.empty(B, k, device="cuda"); Z = torch.empty(B, n, k, device="cuda")
 sb = L.ttr_eigsel_scratch_bytes(dt, n, B); scratch = torch.empty(sb, dtype=torch.uint8, device="cuda")
 st = _hip._stream()
+twsb = L.ttr_tridiag_workspace_bytes(dt, n, B); tws = torch.empty(twsb, dtype=torch.uint8, device="cuda")
 def s1():
     A.copy_(Gn)
-    assert L.ttr_tridiag(dt, n, B, A.data_ptr(), n, n * n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), st) == 0
+    assert L.ttr_tridiag(dt, n, B, A.data_ptr(), n, n * n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), tws.data_ptr(), twsb, st) == 0
 def s2():
     assert L.ttr_tri_eigsel(dt, n, B, k, d.data_ptr(), e.data_ptr(), lam.data_ptr(), Z.data_ptr(), scratch.data_ptr(), sb, st) == 0
 def s3():
