@@ -773,3 +773,27 @@ def test_eigh_topk(dt, n, k, B, graded):
     resid = (G.double() @ X - X * lam[:, None, :]).abs().max() / wref.max()
     assert resid < tol(dt, 2e-5, 1e-11)
     assert rmin.min() > 0.5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_eigh_topk_multiple_eigenvalues_are_declined_or_spanned(dt):
+    """A threefold largest eigenvalue: the twisted factorisation returns the same vector three times, the TSQR's min |R_jj| reports the
+    collapse and the truncation's shortcut (`_topk_one_pass`) declines -- the block-Jacobi driver takes the bond.  A well separated
+    spectrum next to it is accepted.  Whatever is accepted must span an invariant subspace."""
+    from tntorch_amd import _hipops
+    h = _hip()
+    g = torch.Generator().manual_seed(3)
+    n, k = 128, 4
+    Q = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0]
+    tail = torch.linspace(1.0, 0.1, n - 3, dtype=torch.float64)
+    Gc = (Q * torch.cat([torch.tensor([5.0, 5.0, 5.0], dtype=torch.float64), tail])) @ Q.T       # lambda = 5, 5, 5, 1, ...
+    Gs = (Q * torch.cat([torch.tensor([5.0, 4.0, 3.0], dtype=torch.float64), tail])) @ Q.T       # lambda = 5, 4, 3, 1, ...
+    G = torch.stack([Gc, Gs]).to(dt).cuda()
+    X, lam, rmin = h.eigh_topk(G, k)
+    assert float(rmin[0]) < 0.5 and float(rmin[1]) > 0.5
+    Xs = X[1].cpu().double()
+    assert (Xs.T @ Xs - torch.eye(k, dtype=torch.float64)).abs().max() < tol(dt, 5e-6, 1e-12)
+    assert (Gs @ Xs - Xs * lam[1].cpu().double()).abs().max() / 5.0 < tol(dt, 2e-5, 1e-11)
+    assert _hipops._topk_one_pass(G, k) is None            # one collapsed item declines the batch ...
+    res = _hipops._topk_one_pass(G[1:2], 3)                # ... the separated one alone is flat within a factor 8 at r = 3: accepted
+    assert res is not None and res[2].tolist() == [3]
