@@ -101,17 +101,33 @@ def kernel_model():
     }
 
 
-def source_sha():
-    """Hash of the kernel sources: PMC numbers in profiles/pmc_latest.json only describe the build they were taken from."""
+def source_sha(files=None):
+    """Hash of the kernel sources: PMC numbers in profiles/pmc_latest.json only describe the build they were taken from.
+    ``files``: restrict to these translation units (+ every header) -- see ``KIND_SOURCES``."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tntorch_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith(".h") or (f.endswith(".hip") and (files is None or f in files)):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
+# The translation unit(s) every kernel kind is compiled from (one object file each, tntorch_amd/csrc/Makefile): the counters of a
+# kind stay valid as long as ITS sources (and the shared header) are byte-identical, whatever happens to the other files.
+KIND_SOURCES = {
+    "qr_factor": ["ttr_qr.hip"], "qr_apply": ["ttr_qr.hip"],
+    "rowgram": ["ttr_sweep.hip"], "rotgram": ["ttr_sweep.hip"], "project": ["ttr_sweep.hip"],
+    "eigh": ["ttr_eigh.hip"], "gemm": ["ttr_gemm.hip", "ttr_bjacobi.hip"], "misc": None,
+}
+
+
+def kind_shas():
+    return {k: source_sha(v) for k, v in KIND_SOURCES.items()}
+
+
 def load_pmc():
+    """profiles/pmc_latest.json restricted to the kinds whose sources are unchanged since the counters were collected
+    (``kind_sha``; files without it: all or nothing on ``source_sha``).  -> (dict or None, note or None)"""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_latest.json"
@@ -119,10 +135,18 @@ def load_pmc():
         pmc = json.load(open(path))
     except Exception as e:  # noqa: BLE001
         return None, f"unreadable pmc_latest.json: {e!r}"
-    if pmc.get("source_sha") != source_sha():
+    if pmc.get("source_sha") == source_sha():
+        return pmc, None
+    now, then = kind_shas(), pmc.get("kind_sha") or {}
+    stale = sorted(k for k in KIND_SOURCES if k in pmc and then.get(k) != now[k])
+    if len(stale) == sum(1 for k in KIND_SOURCES if k in pmc):
         print("bench.py: WARNING: profiles/pmc_latest.json was collected from a different kernel build "
               f"({pmc.get('source_sha')} != {source_sha()}): `traffic` / `mfma_util` are reported as null", file=sys.stderr)
         return None, "stale: collected from a different kernel build"
+    for k in stale:
+        del pmc[k]
+    print(f"bench.py: note: counters of {stale} in profiles/pmc_latest.json predate a change of their sources and are not used",
+          file=sys.stderr)
     return pmc, None
 
 

@@ -52,9 +52,9 @@ extern "C" {
                                 driver for n above the single-workgroup limit. */
 
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
-   ttr_eigh_trunc = 2; round 3 additions = 3).  ttr_version() returns the value the library was built with; the Python
+   ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 6
+#define TTR_ABI_VERSION 7
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -232,6 +232,26 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  * `delta2_dev` (optional, device pointer to ONE double): the bound delta^2 of the rank rule taken from device memory instead
  * of `delta2` -- tensor.py:2039-2051 computes delta from the norm of the last core and reads it back (`.item()`); an
  * eps-mode sweep that keeps it on the device enqueues every bond without a host synchronisation. */
+
+/*
+ * Pass 1 of a batch-mode bond with 40 <= n <= 64 rows and a rank cap r <= 32, r < n (ttr_eigh_top_ok): round.py:96, 147-158 with
+ * the rank fixed to rmax never looks below sigma_r.  Two waves per matrix: Householder tridiagonalisation + forward formation of Q as
+ * in ttr_eigh_trunc's tridiagonal solver, then -- instead of the QL iteration over the whole spectrum -- Sturm-count multisection
+ * for lambda_1..r, one twisted factorisation per eigenvalue (MRRR getvec), Z^T Z -> two Newton-Schulz steps for orthonormality,
+ * V[:, :r] = Q Z (Z^T Z)^{-1/2} on MFMA.
+ * The kernel decides PER ITEM whether that result can be trusted: the kept spectrum must be flat (sigma_r >= thr sigma_1 > 0, the
+ * criterion of ttr_spectrum_flat) and free of close pairs (neighbouring kept eigenvalues >= 512 eps lambda_1 apart: inverse
+ * iteration on isolated eigenvalues needs no reorthogonalisation beyond the Newton-Schulz polish).  flat[b] = 1: V[b][:, :r],
+ * sigma[b][:r] = sqrt(lambda) (descending), the rest of V[b] / sigma[b] zero, info[b] = r.  flat[b] = 0: the item fell through to
+ * the QL phase of the same launch and carries the full decomposition, exactly what ttr_eigh_trunc(eig_mode = TTR_EIG_RAW,
+ * abs_floor = TTR_SOLVER_TRIDIAG, rmax = n) returns.  `flat` is optional.
+ */
+int ttr_eigh_top_ok(int64_t n, int64_t r);
+int ttr_eigh_top(int dtype, int64_t n, int64_t batch,
+                 const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
+                 void* V, int64_t ldv, int64_t strideV,
+                 void* sigma, int64_t stride_sigma,
+                 int32_t* info, int64_t r, double thr, int32_t* flat, void* stream);
 
 /*
  * Selected eigenpairs of symmetric matrices with 64 < n <= ttr_eigsel_max_n() (1024): the k <= 64 LARGEST eigenvalues and their

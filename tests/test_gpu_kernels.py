@@ -775,6 +775,84 @@ def test_eigh_topk(dt, n, k, B, graded):
     assert rmin.min() > 0.5
 
 
+def _top_errors(G, V, sig, cols):
+    """(orthogonality, residual / ||G||, sigma error / sigma_1) of the first `cols` eigenpairs, in fp64 on the host."""
+    Gd, Vd, s = G.cpu().double(), V.cpu().double()[:, :, :cols], sig.cpu().double()[:, :cols]
+    lam = torch.linalg.eigvalsh(Gd).flip(-1)[:, :cols]
+    orth = (Vd.transpose(1, 2) @ Vd - torch.eye(cols, dtype=torch.float64)).abs().max().item()
+    res = ((Gd @ Vd - Vd * (s * s)[:, None, :]).norm(dim=(1, 2)) / Gd.norm(dim=(1, 2))).max().item()
+    serr = ((s - lam.clamp_min(0).sqrt()).abs().amax(dim=1) / s[:, 0]).max().item()
+    return orth, res, serr
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n,r", [(64, 32), (64, 16), (64, 3), (64, 1), (48, 24), (40, 32), (57, 20)])
+def test_eigh_top(dt, n, r):
+    """Pass 1 of a batch-mode bond (ttr_eigh_top): on flat spectra without close pairs the r largest eigenpairs come from
+    multisection + twisted factorisations + Newton-Schulz (flag 1: zeros beyond r, info = r) and match LAPACK; items the path
+    declines carry the full QL decomposition (flag 0)."""
+    h = _hip()
+    assert h.eigh_top_ok(n, r) and not h.eigh_top_ok(n, 33) and not h.eigh_top_ok(39, 8) and not h.eigh_top_ok(65, 8) and not h.eigh_top_ok(n, n)
+    B = 24
+    g = torch.Generator().manual_seed(11 * n + r)
+    Mx = torch.randn(B, n, 3 * n + 1, generator=g, dtype=torch.float64)
+    G = (Mx @ Mx.transpose(1, 2)).to(dt).cuda()
+    V, sig, info, flat = h.eigh_top(G, r, 0.125)
+    assert V.shape == (B, n, n) and sig.shape == (B, n) and flat.dtype == torch.int32
+    it, iq = flat.nonzero()[:, 0], (flat == 0).nonzero()[:, 0]
+    assert len(it) >= B - 2                                  # (a pair closer than 512 eps lambda_1 is possible, not likely)
+    orth, res, serr = _top_errors(G[it], V[it], sig[it], r)
+    assert orth < tol(dt, 3e-6, 1e-14) and res < tol(dt, 3e-6, 1e-14) and serr < tol(dt, 3e-6, 1e-14)
+    assert float(V[it][:, :, r:].abs().max()) == 0.0 and float(sig[it][:, r:].abs().max()) == 0.0
+    assert info[it].unique().tolist() == [r]
+    if len(iq):
+        orth, res, serr = _top_errors(G[iq], V[iq], sig[iq], n)
+        assert orth < tol(dt, 2e-5, 1e-13) and res < tol(dt, 2e-5, 1e-13)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_eigh_top_declines_what_it_cannot_certify(dt):
+    """Graded kept spectra, exactly and nearly multiple eigenvalues, identity, zero: flag 0 and the QL phase of the same launch
+    delivers what ttr_eigh_trunc's tridiagonal solver delivers.  Pairs / triples just ABOVE the admitted distance (512 eps lambda_1)
+    are taken by the top-r path and must come out orthonormal (two Newton-Schulz steps in fp32, three in fp64)."""
+    h = _hip()
+    n, r, B = 64, 32, 6
+    e = torch.finfo(dt).eps
+    g = torch.Generator().manual_seed(5)
+    Q = torch.linalg.qr(torch.randn(B, n, n, generator=g, dtype=torch.float64))[0]
+
+    def gram(spectrum):
+        lam = torch.tensor(spectrum, dtype=torch.float64) ** 2
+        return ((Q * lam) @ Q.transpose(1, 2)).to(dt).cuda()
+
+    declined = {
+        "graded": gram([0.5 ** i for i in range(n)]),
+        "double": gram([1.0, 1.0] + [0.9 - 0.01 * i for i in range(n - 2)]),
+        "pairs at 100 eps": gram([(1.0 - 0.02 * (i // 2)) * (1.0 + 100 * e * (i % 2)) for i in range(n)]),
+        "identity": torch.eye(n, dtype=dt).repeat(B, 1, 1).cuda(),
+    }
+    for name, G in declined.items():
+        V, sig, info, flat = h.eigh_top(G, r, 0.125)
+        assert flat.tolist() == [0] * B, name
+        Vq, sq, iq = h.eigh_trunc(G, h.EIG_RAW, False, 0.0, n, abs_floor=h.SOLVER_TRIDIAG)
+        assert torch.equal(info, iq), name
+        assert ((sig - sq).abs().max() / sq.max()).item() < tol(dt, 1e-6, 1e-14), name
+        orth, res, _ = _top_errors(G, V, sig, n)
+        assert orth < tol(dt, 2e-5, 1e-13) and res < tol(dt, 2e-5, 1e-13), name
+    Z = torch.zeros(B, n, n, dtype=dt).cuda()
+    V, sig, info, flat = h.eigh_top(Z, r, 0.125)
+    assert flat.tolist() == [0] * B and info.tolist() == [0] * B and float(sig.abs().max()) == 0.0
+    taken = {
+        "pairs at 2000 eps": gram([(1.0 - 0.02 * (i // 2)) * (1.0 + 2000 * e * (i % 2)) for i in range(n)]),
+        "triples at 600 eps": gram([(1.0 - 0.03 * (i // 3)) * (1.0 + 600 * e * (i % 3)) for i in range(n)]),
+    }
+    for name, G in taken.items():
+        V, sig, info, flat = h.eigh_top(G, r, 0.125)
+        assert flat.tolist() == [1] * B, name
+        orth, res, serr = _top_errors(G, V, sig, r)
+        assert orth < tol(dt, 3e-6, 1e-14) and res < tol(dt, 3e-6, 1e-14) and serr < tol(dt, 3e-6, 1e-14), name
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_eigh_topk_multiple_eigenvalues_are_declined_or_spanned(dt):
     """A threefold largest eigenvalue: the twisted factorisation returns the same vector three times, the TSQR's min |R_jj| reports the

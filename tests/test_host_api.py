@@ -260,12 +260,13 @@ def test_host_cp_als_golden():
     for name in ("r3_it1", "r3_it25", "r5_it4"):
         t = tn.Tensor(g["inp"], ranks_cp=runs[name]["R"], max_iter=runs[name]["max_iter"])
         assert all(c.dim() == 2 for c in t.cores) and tuple(t.shape) == (12, 10, 9, 11)
-        # (MKL's lstsq / eigh are not bit-reproducible across thread schedules; 25 ALS sweeps amplify that noise)
+        # (MKL's lstsq / eigh are not bit-reproducible from run to run, not even single-threaded: the factors of identical calls differ
+        # by 0 ... 8e-11 here -- mostly exactly 0, the rank-5 case is the sensitive one -- and the reconstruction by up to 2e-13)
         assert max((a - b).abs().max().item() for a, b in zip(t.cores, g[name])) < 1e-7
         assert abs(tn.relative_error(g["inp"], t).item() - runs[name]["relerr"]) < 1e-10
     # CP factors behave as TT cores with diagonal slices everywhere else (tensor.py:1717-1769)
     ref = oracle.cp_to_dense(g["r5_it4"])
-    assert (t.torch() - ref).norm() / ref.norm() < 1e-13
+    assert (t.torch() - ref).norm() / ref.norm() < 1e-10   # (0 on most runs; 2.2e-13 seen once in ~30: see above)
     assert t.ranks_tt.tolist() == [5, 5, 5, 5, 5]
     u = t.clone()
     u.round_tt(eps=1e-10)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 6  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 7  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -103,6 +103,12 @@ _SIGNATURES = {
          c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
     "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "ttr_eigh_top_ok": (c_int, [c_int64, c_int64]),
+    "ttr_eigh_top": (
+        c_int,
+        [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+         c_void_p, c_int64, c_double, c_void_p, c_void_p],
+    ),
     "ttr_eigsel_max_n": (c_int, []),
     "ttr_eigsel_scratch_bytes": (c_int64, [c_int, c_int64, c_int64]),
     "ttr_tridiag_workspace_bytes": (c_int64, [c_int, c_int64, c_int64]),
@@ -553,6 +559,35 @@ def eigh_trunc(
     )
     _check(code, "ttr_eigh_trunc")
     return V, sigma, info
+
+
+def eigh_top_ok(n: int, r: int) -> bool:
+    return bool(lib().ttr_eigh_top_ok(int(n), int(r)))
+
+
+@_on_device
+def eigh_top(G: torch.Tensor, r: int, thr: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Pass 1 of a batch-mode bond: symmetric [batch, n, n] (or split partials [batch, parts, n, n]), 40 <= n <= 64, rank cap
+    r <= 32 (ttr_eigh_top).  Returns (V, sigma, info, flat): items with flat[b] = 1 carry their r largest eigenpairs (V[b][:, :r],
+    sigma[b][:r], zeros beyond), the others the full decomposition of ``eigh_trunc(G, EIG_RAW, ..., abs_floor=SOLVER_TRIDIAG)``."""
+    L = lib()
+    dt = dtype_code(G.dtype)
+    gparts, sGp = 1, 0
+    if G.dim() == 4:
+        G = G.contiguous()
+        batch, gparts, n, _ = G.shape
+        ldg, sG, sGp = n, gparts * n * n, n * n
+    else:
+        G, ldg, sG = _mat(G)
+        batch, n, _ = G.shape
+    V = torch.empty((batch, n, n), dtype=G.dtype, device=G.device)
+    sigma = torch.empty((batch, n), dtype=G.dtype, device=G.device)
+    info = torch.empty((batch,), dtype=torch.int32, device=G.device)
+    flat = torch.empty((batch,), dtype=torch.int32, device=G.device)
+    if batch:
+        _check(L.ttr_eigh_top(dt, n, batch, G.data_ptr(), ldg, sG, gparts, sGp, V.data_ptr(), n, n * n, sigma.data_ptr(), n,
+                              info.data_ptr(), int(r), float(thr), flat.data_ptr(), _stream()), "ttr_eigh_top")
+    return V, sigma, info, flat
 
 
 @_on_device

@@ -312,6 +312,9 @@ def _eigh_any(G: torch.Tensor, eig_mode: int, use_delta: bool, delta2: float, ca
 # bond's Gram matrix -- only the top of the spectrum is ever looked at (BASELINE config C3: n = 256, rmax = 8; the block-Jacobi
 # driver needs ~170 launches per such bond).  TTR_EIGH_TOPK=0 switches it off.
 EIGH_TOPK_ENABLED = os.environ.get("TTR_EIGH_TOPK", "1") != "0"
+# batch-mode bonds with <= 64 rows and a rank cap <= 32: pass 1 by the top-r solver (ttr_eigh_top), the QL solver only for the
+# items that one declines
+EIGH_TOP_ENABLED = os.environ.get("TTR_EIGH_TOP", "1") != "0"
 _TOPK_MAX_RANK = 32
 
 
@@ -446,7 +449,15 @@ def truncate(
         V1 = None
         G = gram if gram is not None else _hip.rowgram(M)
         if algorithm == "svd":
-            V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+            if (batch and EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0 and rmax is not None and delta2_dev is None
+                    and _hip.eigh_top_ok(k, _rank_cap(rmax, k))):
+                # only the rmax largest eigenpairs matter when the kept spectrum is flat: multisection + twisted factorisations
+                # instead of the QL iteration over the whole spectrum, decided per item inside the launch (flat kept spectrum
+                # without close pairs; the others fall through to the QL phase).  Such items carry zeros beyond column / entry
+                # rmax, which nothing below looks at in batch mode.
+                V1, sig1, _, _ = _hip.eigh_top(G, _rank_cap(rmax, k), FLAT_SPECTRUM_THR)
+            else:
+                V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             flat = None
             if FLAT_SPECTRUM_THR > 0:
                 # items whose KEPT singular values lie within a factor 8 of each other do not need the second pass (the first

@@ -23,6 +23,8 @@
 // Epilogue = round.py:118-158 of the reference, fused: clamp, sqrt, sort by
 // decreasing sigma (counting sort, one thread per eigenvalue), permute V's columns,
 // tail-energy scan (accumulated in double like torch.cumsum on CPU), rank selection.
+#include <type_traits>
+
 #include "ttr_common.h"
 
 namespace ttr {
@@ -61,6 +63,11 @@ struct EighArgs {
   const int32_t* skip_items;
   const T* sigma_in;
   int64_t stride_sigma_in;
+  // eigh_tridiag_kernel<T, true>: top_r largest eigenpairs by the top-r path when the kept spectrum is flat within top_thr and has
+  // no close pair (top_flat[b] = 1, optional), the QL phase otherwise (top_flat[b] = 0)
+  int32_t* top_flat;
+  double top_thr;
+  int top_r;
   const int32_t* skip_flag;  // != 0 on the device: the driver has converged, the launch returns at once
   int32_t* rot_count;        // incremented once per problem that rotated anything (the driver's "a whole sweep found nothing")
 };
@@ -528,6 +535,31 @@ __device__ __forceinline__ double ql_shift(double dl, double dl1, double dm, dou
   return dm - dl + el / (t + copysign(r, t));
 }
 
+// a / b with the 1-ulp hardware reciprocal in fp32 (pivots of LDL^T factorisations: the Sturm counts and twisted
+// factorisations below only need them to a few ulp)
+__device__ __forceinline__ float fdiv_fast(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double fdiv_fast(double a, double b) { return a / b; }
+
+// The r LARGEST eigenpairs of a symmetric n x n matrix, n <= 64, r <= 32, for pass 1 of the batch-mode 'svd' truncation when the
+// kept spectrum is flat (ttr_spectrum_flat's criterion, decided HERE from the eigenvalues) -- what the QL kernel above spends
+// its time on, one serial rotation chain through ALL n eigenvectors (316 k of its 560 k cycles), is replaced by work that is
+// parallel over the eigenvalues.  Same two waves, same tridiagonalisation (wave 0) with the forward Q formation on the matrix
+// cores under it (wave 1: Q^T stays in its accumulators); then
+//   * the r largest eigenvalues by Sturm-count MULTISECTION: 128 / r shifts per eigenvalue and round, every lane runs the
+//     n-step count recurrence for its own shift; the groups of an eigenvalue never straddle the waves, so the waves do not
+//     talk (11 rounds for r = 32);
+//   * their eigenvectors from the TWISTED factorisation of T - lambda I (one lane per vector, D+ / D- of the stationary qd
+//     transforms in 64 registers, twist where |gamma| is smallest);
+//   * orthonormalisation and back-transformation on the matrix cores without a transposition: with Z (n x r) as the A and the
+//     B operand, S = Z^T Z, C = (Q Z)^T = Z^T Q^T (Q^T from the accumulators as the B operand), two (fp64: three) Newton-Schulz steps on
+//     the r x r matrices (P = 1.5 I - 0.5 S is symmetric, so its accumulator registers ARE its A operand) and V^T = P C.
+// An item qualifies when sigma_r >= thr sigma_1 > 0 and no two of the r eigenvalues are closer than 512 eps lambda_1 (the
+// twisted vectors of closer pairs are too parallel for two Newton-Schulz steps); V[:, r:] and sigma[r:] are then written as
+// zeros.  The others FALL THROUGH to the QL phase of the same launch (one more barrier; wave 1 stores Q^T from the same
+// accumulators) and get the full decomposition: eigh_tridiag_kernel<T, true> is the QL kernel with this path in front.
+template <int I>
+using IC2 = std::integral_constant<int, I>;
+
 // Two waves per matrix.  A single wave issues one VALU instruction per ~8 clocks whatever its dependencies (tools/microbench:
 // independent and dependent FMA chains both 8.0-8.5; four waves per SIMD: 2.4 per instruction), and at B <= 2048 there are at
 // most two matrices per SIMD -- the one-wave kernel of rounds 1-2 (everything below on one wave, Q formed backwards after the
@@ -542,7 +574,7 @@ __device__ __forceinline__ double ql_shift(double dl, double dl1, double dm, dou
 // Workgroup barriers are the only synchronisation: one per reflector block, then one per QL sweep (wave 0 arrives after
 // computing sweep s, wave 1 before replaying it, so wave 0 runs at most two sweeps ahead and never overwrites a buffer
 // that is still being replayed); the number of sweeps is data dependent, so every barrier's sweep carries a `done` word.
-template <typename T>
+template <typename T, bool TOP = false>
 __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -640,6 +672,154 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   long long nrot_dbg = 0, qlrec_dbg = 0;
 #endif
   if (n == 1 && tid == 0) { dv[0] = A[0]; ev[0] = T(0); tauv[0] = T(0); }
+  // ---- selection set-up of the top-r path (TOP; everything below is dead code otherwise)
+  const int rsel = TOP ? (p.top_r < n ? (p.top_r < 1 ? 1 : p.top_r) : n) : 1;  // eigenpairs wanted (host: <= 32)
+  int kp = 1;
+  while (kp < rsel) kp <<= 1;
+  const int GL = kp >= 2 ? (2 * kWave) / kp : kWave;            // lanes per eigenvalue; a group never straddles the two waves
+  const int gj = kp >= 2 ? tid / GL : (wv == 0 ? 0 : 1);        // eigenvalue of this lane's group
+  const int gs = kp >= 2 ? tid % GL : lane;
+  const int nvec = kp >= 2 ? kp / 2 : 1;                       // vectors per wave: wave w owns eigenvalues w * nvec + (0 .. nvec - 1)
+  const int jv = wv * nvec + lane;                             // this lane's vector (lane < nvec)
+  const bool vlive = lane < nvec && jv < rsel;
+  T* const lamv = vsh;                                         // [64] eigenvalues (the tridiagonalisation's broadcast arrays are free by then)
+  volatile int* const badf = meta + 3;                         // [1] some vector overflowed (a spare control word)
+  constexpr int ZLD = 36;                                      // Z[i][j] at A[i * ZLD + j] (A is free once Q sits in registers)
+  const T eps = Num<T>::eps();
+  if (TOP && tid == 0) badf[0] = 0;
+  // eigenvalues of this lane's group + the twisted factorisation of this lane's vector (everything a wave needs comes from
+  // d / e in LDS, which are final before the tridiagonalisation's last barrier)
+  T Dp[64];      // D+_i for i <= twist, D-_i above it
+  int twist = 0;
+  T lam_vec = T(0), pivmin = T(0);
+  auto select = [&]() __attribute__((always_inline)) {
+    T gl = Num<T>::big_theta(), gu = -Num<T>::big_theta(), emax2 = T(0);
+    if (lane < n) {
+      const T di = dv[lane], ei = lane + 1 < n ? ev[lane] : T(0), em = lane > 0 ? ev[lane - 1] : T(0);
+      const T rad = fabs(ei) + fabs(em);
+      gl = di - rad; gu = di + rad; emax2 = ei * ei;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      gl = fmin(gl, __shfl_xor(gl, off, 64)); gu = fmax(gu, __shfl_xor(gu, off, 64)); emax2 = fmax(emax2, __shfl_xor(emax2, off, 64));
+    }
+    const T tnorm = fmax(fabs(gl), fabs(gu));
+    pivmin = Num<T>::tiny() * fmax(T(1), emax2) / eps;
+    gl -= T(2.1) * tnorm * eps * n + T(2.1) * pivmin;
+    gu += T(2.1) * tnorm * eps * n + T(2.1) * pivmin;
+    auto count_below = [&](T sigma) __attribute__((always_inline)) {  // number of eigenvalues < sigma
+      T q = dv[0] - sigma;
+      if (fabs(q) < pivmin) q = -pivmin;
+      int cnt = q < T(0) ? 1 : 0;
+      for (int i = 1; i < n; ++i) {
+        const T e = ev[i - 1];
+        q = dv[i] - sigma - fdiv_fast(e * e, q);
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q < T(0) ? 1 : 0;
+      }
+      return cnt;
+    };
+    const bool live = gj < rsel;
+    const int idx = n - 1 - (live ? gj : 0);  // ascending index of the gj-th largest eigenvalue
+    const int jloc = gj - wv * nvec;          // group number inside this wave
+    T lo = gl, hi = gu;
+    const int max_rounds = sizeof(T) == 4 ? 40 : 90;
+    for (int it = 0; it < max_rounds; ++it) {
+      const T wdt = hi - lo;
+      const bool done = !(wdt > T(4) * eps * fmax(fabs(lo), fabs(hi)) + T(2) * pivmin);
+      if (__ballot(live && !done) == 0ull) break;
+      const T sigma = lo + wdt * (T)(gs + 1) / (T)(GL + 1);
+      const bool above = count_below(sigma) >= idx + 1;
+      const unsigned long long mask = __ballot(above);
+      const unsigned long long grp = (mask >> ((jloc < 0 ? 0 : jloc) * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
+      const int f = grp ? __ffsll((long long)grp) - 1 : GL;
+      const T nlo = f == 0 ? lo : lo + wdt * (T)f / (T)(GL + 1);
+      const T nhi = f == GL ? hi : lo + wdt * (T)(f + 1) / (T)(GL + 1);
+      if (!done) { lo = nlo; hi = nhi; }
+    }
+    const T lam_grp = T(0.5) * (lo + hi);
+    if (live && gs == 0) lamv[gj] = lam_grp;
+    lam_vec = __shfl(lam_grp, (lane < nvec ? lane : 0) * (kp >= 2 ? GL : 0), 64);
+    // twisted factorisation: D+ from the top, gamma from the bottom, then D- kept above the twist
+    const T lam = lam_vec;
+    T q = dv[0] - lam;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i < n) {
+        if (fabs(q) < pivmin) q = -pivmin;
+        Dp[i] = q;
+        if (i + 1 < n) { const T e = ev[i]; q = dv[i + 1] - lam - fdiv_fast(e * e, q); }
+      } else {
+        Dp[i] = T(1);
+      }
+    }
+    T best = fabs(Dp[0]);
+    twist = 0;
+    {
+      T qm = T(0);
+#pragma unroll
+      for (int i = 63; i >= 0; --i) {
+        if (i < n) {
+          if (i == n - 1) qm = dv[i] - lam;
+          else { const T e = ev[i]; if (fabs(qm) < pivmin) qm = -pivmin; qm = dv[i] - lam - fdiv_fast(e * e, qm); }
+          const T gam = Dp[i] + qm - (dv[i] - lam);
+          if (i == n - 1 || fabs(gam) < best) { best = fabs(gam); twist = i; }
+        }
+      }
+    }
+    {
+      T qm = T(0);
+#pragma unroll
+      for (int i = 63; i >= 1; --i) {
+        if (i < n) {
+          if (i == n - 1) qm = dv[i] - lam;
+          else { const T e = ev[i]; qm = dv[i] - lam - fdiv_fast(e * e, qm); }
+          if (fabs(qm) < pivmin) qm = -pivmin;
+          if (i > twist) Dp[i] = qm;
+        }
+      }
+    }
+  };
+  // x_twist = 1;  x_i = -(e_i / D+_i) x_{i+1} (i < twist);  x_{i+1} = -(e_i / D-_{i+1}) x_i (i >= twist).  WRITE = false: only ||x||^2.
+  auto vector_pass = [&](auto WRITE, T scale) __attribute__((always_inline)) -> T {
+    constexpr bool kWrite = decltype(WRITE)::value != 0;
+    T nrm2 = T(1), xc = T(0);
+    if (kWrite && twist < n) A[twist * ZLD + jv] = scale;
+#pragma unroll
+    for (int i = 62; i >= 0; --i) {  // upwards
+      if (i + 1 < n) {
+        if (i + 1 == twist) xc = T(1);
+        if (i < twist) {
+          xc = -fdiv_fast(ev[i], Dp[i]) * xc;
+          nrm2 += xc * xc;
+          if (kWrite) A[i * ZLD + jv] = xc * scale;
+        }
+      }
+    }
+    xc = T(0);
+#pragma unroll
+    for (int i = 0; i < 63; ++i) {  // downwards
+      if (i + 1 < n) {
+        if (i == twist) xc = T(1);
+        if (i >= twist) {
+          xc = -fdiv_fast(ev[i], Dp[i + 1]) * xc;
+          nrm2 += xc * xc;
+          if (kWrite) A[(i + 1) * ZLD + jv] = xc * scale;
+        }
+      }
+    }
+    return nrm2;
+  };
+  // after both waves have their eigenvalues in lamv: does the item qualify?  (same answer in every thread)
+  auto qualifies = [&]() __attribute__((always_inline)) -> bool {
+    T gmin = Num<T>::big_theta();
+    if (lane + 1 < rsel) gmin = lamv[lane] - lamv[lane + 1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off, 64));
+    const T l0 = lamv[0], lr = lamv[rsel - 1];
+    const T thr = (T)p.top_thr;
+    return l0 > T(0) && lr >= thr * thr * l0 && (rsel == 1 || gmin >= T(512) * eps * l0) && badf[0] == 0;
+  };
 
   if (wv == 0) {
     // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k]; a barrier after every block of 16
@@ -743,6 +923,42 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     }
     TTR_ESTAMP();
     TTR_ESTAMP();
+    if constexpr (TOP) {
+      // ---- 2t. this wave's eigenvalues and twisted factorisations
+      select();
+      T nrm2 = T(1);
+      if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
+      if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
+      __syncthreads();  // B1: all eigenvalues in lamv, wave 1 done with the reflectors in A
+      if (qualifies()) {
+        if (vlive) {
+          const T inv = T(1) / sqrt(nrm2);
+          (void)vector_pass(IC2<1>{}, inv);
+        }
+        __syncthreads();  // B2: Z complete
+        // epilogue of wave 0: sigma, rank, flag, zero columns
+        if (lane < n) {
+          T w = lane < rsel ? lamv[lane] * gmax : T(0);
+          if (!(w > T(0))) w = T(0);
+          p.sigma[bt * p.stride_sigma + lane] = sqrt(w);
+        }
+        if (lane == 0) {
+          T w0 = lamv[0] * gmax;
+          p.info[bt] = (sqrt(w0 > T(0) ? w0 : T(0)) < T(1e-13)) ? 0 : rsel;
+          if (p.top_flat) p.top_flat[bt] = 1;
+          if (p.sweeps) p.sweeps[bt] = 0;
+        }
+        T* __restrict__ Vo = p.V + bt * p.strideV;
+        const int zc = n - rsel;
+        for (int idx = lane; idx < n * zc; idx += kWave) {
+          const int row = idx / zc, c = rsel + idx - row * zc;
+          Vo[(int64_t)row * p.ldv + c] = T(0);
+        }
+        return;
+      }
+      if (lane == 0 && p.top_flat) p.top_flat[bt] = 0;
+      __syncthreads();  // B1': both waves have read lamv (= rotation buffer 0 of the QL phase below)
+    }
     // ---- 3. implicit-shift QL on (d, e); every sweep's rotations are published and replayed on Q's rows by wave 1.
     // The recurrence is one serial chain per matrix (the wave repeats it in all lanes): it runs at the issue rate of a
     // single wave.  d[k] / e[k] and the recorded rotation (c, s)[k-1] therefore live in REGISTERS, one index per lane:
@@ -925,6 +1141,116 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
             for (int tn = 0; tn < 4; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
           }
         }
+      }
+      if constexpr (TOP) {
+        // ---- 2t. this wave's eigenvalues and twisted factorisations (Q^T stays in the accumulators Z)
+        select();
+        T nrm2 = T(1);
+        if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
+        if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
+        __syncthreads();  // B1
+        if (qualifies()) {
+          if (vlive) {
+            const T inv = T(1) / sqrt(nrm2);
+            (void)vector_pass(IC2<1>{}, inv);
+          }
+          __syncthreads();  // B2: Z complete in LDS
+          // ---- 4. V^T = P (Q Z)^T on the matrix cores
+          T zr[4][4][2];  // Z[16 tm + row(lane, s)][16 tv + cl]
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int tv = 0; tv < 2; ++tv) {
+                const int row = 16 * tm + MF::row(lane, s), col = 16 * tv + cl;
+                zr[tm][s][tv] = (row < n && col < rsel) ? A[row * ZLD + col] : T(0);
+              }
+          Acc C[2][4];  // (Q Z)^T: rows = vector, columns = matrix row
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int tv = 0; tv < 2; ++tv) C[tv][ti] = MF::zero();
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int tv = 0; tv < 2; ++tv) C[tv][ti] = MF::mma(zr[tm][s][tv], Z[tm][ti][s], C[tv][ti]);
+          }
+          Acc S[2][2];
+#pragma unroll
+          for (int tv = 0; tv < 2; ++tv)
+#pragma unroll
+            for (int tw = 0; tw < 2; ++tw) {
+              S[tv][tw] = MF::zero();
+#pragma unroll
+              for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) S[tv][tw] = MF::mma(zr[tm][s][tv], zr[tm][s][tw], S[tv][tw]);
+            }
+          // Newton-Schulz: P = 1.5 I - 0.5 S (padding rows / columns: S = 0 there, P = 1.5 I -- harmless, C is zero there)
+          auto newton = [&](const Acc (&Sx)[2][2], Acc (&Px)[2][2]) {
+#pragma unroll
+            for (int tv = 0; tv < 2; ++tv)
+#pragma unroll
+              for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                  Px[tv][tw][rr] = T(-0.5) * Sx[tv][tw][rr] + ((16 * tv + MF::row(lane, rr) == 16 * tw + cl) ? T(1.5) : T(0));
+          };
+          // R = X Y for symmetric r x r matrices held in accumulators: X's registers are its A operand (X[m][k] = X[k][m]), Y's its B operand
+          auto symmul = [&](const Acc (&X)[2][2], const Acc (&Y)[2][2], Acc (&R)[2][2]) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn) {
+                R[tm][tn] = MF::zero();
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                  for (int s = 0; s < 4; ++s) R[tm][tn] = MF::mma(X[tk][tm][s], Y[tk][tn][s], R[tm][tn]);
+              }
+          };
+          // Two steps in fp32, three in fp64: the mutual contamination theta of the twisted vectors of a pair at the admitted
+          // distance (512 eps lambda_1) is ~ 1e-2 in EITHER precision, and a step squares it (theta -> 0.75 theta^2): 4e-9 after two
+          // steps is below eps of fp32 only (measured in fp64 with two steps: 1.4e-10 on triples 600 eps apart).
+          Acc P[2][2], T1[2][2], S1[2][2], P1[2][2], Pt[2][2];
+          newton(S, P);
+          symmul(S, P, T1);    // S P
+          symmul(P, T1, S1);   // S1 = P S P
+          newton(S1, P1);
+          symmul(P1, P, Pt);   // Pt = P1 P  (all polynomials in S: symmetric, commuting)
+          if constexpr (sizeof(T) == 8) {
+            Acc S2[2][2], P2[2][2], Pu[2][2];
+            symmul(S1, P1, T1);
+            symmul(P1, T1, S2);  // S2 = P1 S1 P1
+            newton(S2, P2);
+            symmul(P2, Pt, Pu);  // P2 P1 P
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b2 = 0; b2 < 2; ++b2) Pt[a][b2] = Pu[a][b2];
+          }
+          T* __restrict__ Vo = p.V + bt * p.strideV;
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tv = 0; tv < 2; ++tv) {
+              Acc X = MF::zero();
+#pragma unroll
+              for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) X = MF::mma(Pt[tk][tv][s], C[tk][ti][s], X);
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                const int v = 16 * tv + MF::row(lane, rr), i = 16 * ti + cl;
+                if (v < rsel && i < n) Vo[(int64_t)i * p.ldv + v] = X[rr];
+              }
+            }
+          return;
+        }
+        __syncthreads();  // B1'
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // Q[j][i] = X[i][j]: the transposed store (wave 0 no longer reads A: its last access is before the last block's barrier)
@@ -1157,6 +1483,31 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
   return eigh_typed<double>(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, eig_mode,
                             use_delta, delta2, rmax, abs_floor, sweeps, ws, ws_bytes, stream, delta2_dev, skip_items, sigma_in,
                             stride_sigma_in);
+}
+
+// pass 1 of a batch-mode bond, n <= 64: the r largest eigenpairs (flat[b] = 1) or the full QL decomposition (flat[b] = 0) per item
+template <typename T>
+static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
+                          void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int64_t r, double thr,
+                          int32_t* flat, hipStream_t stream) {
+  EighArgs<T> p{};
+  p.n = (int)n;
+  p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG; p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
+  p.V = (T*)V; p.ldv = ldv; p.strideV = strideV;
+  p.sigma = (T*)sigma; p.stride_sigma = stride_sigma;
+  p.info = info; p.rmax = n; p.top_r = (int)r; p.top_flat = flat; p.top_thr = thr;
+  p.eig_mode = TTR_EIG_RAW;
+  ProfScope prof(TTR_PROF_EIGH, stream);
+  hipLaunchKernelGGL((eigh_tridiag_kernel<T, true>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+int eigh_top_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
+                      int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info,
+                      int64_t r, double thr, int32_t* flat, hipStream_t stream) {
+  if (dtype == TTR_F32)
+    return eigh_top_typed<float>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream);
+  return eigh_top_typed<double>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream);
 }
 
 int g_bj_inner_sweeps = 1;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS); measured on C3's share: 1 -> 72 ms, 2 -> 82, 3 -> 90, until converged -> 97

@@ -37,13 +37,8 @@ def kind_of(name):
     return None
 
 
-def source_sha():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "tntorch_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from bench import kind_shas, source_sha  # noqa: E402  (one definition of the hashes for writer and reader)
 
 
 def read_pass(d):
@@ -86,7 +81,7 @@ def main():
             if ("mfma_kernel" in name or "mfma64_kernel" in name) and cs.get("GRBM_GUI_ACTIVE"):
                 calib = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(cs["GRBM_GUI_ACTIVE"]) * 1024.0)
     out = {"_source": f"tools/profile_round.sh ({steps} single-stream steps at B = {B}; separate --pmc passes)", "_batch": B,
-           "source_sha": source_sha(), "mfma_busy_ratio_of_pure_mfma_kernel": calib}
+           "source_sha": source_sha(), "kind_sha": kind_shas(), "mfma_busy_ratio_of_pure_mfma_kernel": calib}
     print(f"# PMC summary ({steps} steps, B = {B}); MFMA-busy ratio of a pure-MFMA kernel: {calib}")
     print(f"{'kind':10s} {'fetch_raw_GB/step':>18s} {'fetch_x2_GB/step':>18s} {'write_GB/step':>14s} {'hbm_GB/step':>12s} {'mfma_busy/(gui*1024)':>22s} {'mfma_util':>10s} {'mfma_TFLOP/step':>16s}")
     for k, c in sorted(per_kind.items()):
