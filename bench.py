@@ -125,10 +125,10 @@ def kind_shas():
     return {k: source_sha(v) for k, v in KIND_SOURCES.items()}
 
 
-def load_pmc():
+def load_pmc(path=None):
     """profiles/pmc_latest.json restricted to the kinds whose sources are unchanged since the counters were collected
     (``kind_sha``; files without it: all or nothing on ``source_sha``).  -> (dict or None, note or None)"""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    path = path or os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_latest.json"
     try:
