@@ -54,6 +54,57 @@ def make_input(B, device, seed):
     return cores
 
 
+def make_decaying_input(B, device, seed, decay):
+    """SURVEY 8d's second input variant of the metric: the same shapes (64^8, rank 64, fp32), i.i.d. normal cores of unit column
+    variance with rank index j of every bond scaled by 2^(-decay j) -- bond singular values ~ 2^(-decay j): the kept spectrum is
+    NOT flat, so neither the one-pass shortcut nor the top-r first pass applies (tests/test_gpu_parity.py: `_decaying_tt`)."""
+    import math
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    r = [1] + [R_IN] * (N_CORES - 1) + [1]
+    cores = []
+    for k in range(N_CORES):
+        c = torch.randn((B, r[k], MODE, r[k + 1]), generator=gen, device=device, dtype=torch.float32)
+        c.mul_(1.0 / math.sqrt(r[k] * MODE))
+        if k < N_CORES - 1:
+            c.mul_(2.0 ** (-decay * torch.arange(r[k + 1], device=device, dtype=torch.float32)))
+        cores.append(c)
+    return cores
+
+
+def decaying_parity(inp, out, item):
+    """One item of a decaying-spectrum batch against the oracle run in float64 on the same fp32 cores (the bounds of
+    tests/test_gpu_parity.py::test_decaying_spectrum_metric_shape): identical ranks, bond singular values to 4e-6 sigma_max,
+    right-orthonormal cores to 5e-5, approximation error within 4e-6 + 1e-2 relative of the oracle's."""
+    import math
+
+    import oracle
+
+    one = [c[item].cpu() for c in inp]
+    ref = oracle.round_tt([c.double() for c in one], rmax=R_OUT, algorithm="svd")
+    ours = [c[item].cpu() for c in out.cores]
+
+    def rel(a, b):
+        a = [c.double() for c in a]
+        b = [c.double() for c in b]
+        aa, bb, ab = oracle.tt_dot(a, a), oracle.tt_dot(b, b), oracle.tt_dot(a, b)
+        return math.sqrt(max((aa + bb - 2 * ab).item(), 0.0) / bb.item())
+
+    e_o, e_r = rel(ours, one), rel(ref, one)
+    sv = max(((a - b).abs().max() / b.max()).item()
+             for a, b in zip(oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)))
+    orth = 0.0
+    for c in ours[1:]:
+        Rm = c.double().reshape(c.shape[0], -1)
+        orth = max(orth, (Rm @ Rm.T - torch.eye(Rm.shape[0], dtype=torch.float64)).abs().max().item())
+    ranks_ok = oracle.tt_ranks(ours) == oracle.tt_ranks(ref)
+    ok = ranks_ok and sv <= 4e-6 and orth <= 5e-5 and abs(e_o - e_r) <= 4e-6 + 1e-2 * e_r
+    return {"item": item, "ranks_identical": ranks_ok, "bond_sv_max_abs_diff_rel_sigma_max": sv, "right_orthonormality_defect": orth,
+            "approx_err_ours": e_o, "approx_err_oracle_f64": e_r,
+            "bounds": {"bond_sv": 4e-6, "orth": 5e-5, "approx_err_abs_diff": "4e-6 + 1e-2 * oracle"}, "ok": bool(ok)}
+
+
 def kernel_model():
     """Algorithmic work of every kernel kind PER TENSOR of the metric workload (float32): `flops` = the arithmetic the
     kernel's algorithm performs, `bytes` = what it must move given its interface (operands read once, results written
@@ -227,7 +278,7 @@ def parity_check(inp, out, items):
             "ok": bool(ranks_ok and worst <= 2e-5)}
 
 
-def timed_steps(step, drain, fence, warmup, steps):
+def timed_steps(step, drain, fence, warmup, steps, on_timed_start=None):
     out = None
     for _ in range(warmup):
         # the result is held exactly as in the timed loop (the previous step's rounded train stays alive while the next step
@@ -238,6 +289,8 @@ def timed_steps(step, drain, fence, warmup, steps):
         out = step()
     drain()
     fence()
+    if on_timed_start is not None:
+        on_timed_start()
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -268,13 +321,16 @@ def main():
     ap.add_argument("--config", default="metric", choices=["metric", "c1", "c2", "c3", "c4"],
                     help="metric (default): the headline workload (its line also carries `configs`: one entry per BASELINE config); "
                          "c1 .. c4: one of BASELINE's other configs alone (tools/bench_configs.py)")
+    ap.add_argument("--variant", default="randn", choices=["randn", "lowrank"],
+                    help="--config c1 | c3: the input of SURVEY 8d (plain randn, or TT rank = the cap of unit RMS + 1e-3 randn)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch / single-tensor extra measurements")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 .. C4 entries of the default line (`configs`)")
-    ap.add_argument("--gather", default=os.environ.get("TTR_BENCH_GATHER", "step"), choices=["step", "end", "none"],
-                    help="N > 1: `step` (default) = every step's rounded cores are gathered on rank 0 (asynchronously, under the next "
-                         "step's compute); `end` = ONE gather after the last timed step (north_star: 'a single RCCL gather ... at the "
-                         "end'), inside the timed region; `none` = no gather (compute-only scaling)")
+    ap.add_argument("--gather", default=os.environ.get("TTR_BENCH_GATHER", "end"), choices=["end", "step", "none"],
+                    help="N > 1: `end` (default; north_star: 'a single RCCL gather over xGMI at the end') = ONE gather of the last "
+                         "step's rounded cores after the last timed step, inside the timed region; `step` = every step's result is "
+                         "gathered on rank 0 (asynchronously, under the next step's compute: link-bound at 8 GPUs, DESIGN section 6); "
+                         "`none` = no gather (compute-only scaling)")
     ap.add_argument("--single-stream", action="store_true",
                     help="issue the timed region on one stream too (for rocprofv3 kernel traces: with sub-batch "
                          "streams the traced kernel durations overlap)")
@@ -301,7 +357,7 @@ def main():
 
     import tntorch_amd as tn
     from tntorch_amd import _hip
-    from tntorch_amd.dist_batch import gather_batch
+    from tntorch_amd.dist_batch import GatherSchedule, gather_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -313,7 +369,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     nccl_ranks = 1
-    if world > 1:
+    # TTR_BENCH_FORCE_DIST=1 (tests, under torch.distributed.run with ONE rank): the N > 1 code path -- process group, gather
+    # schedule through the real collective, barriers, max-over-ranks -- on a single GPU
+    dist_on = world > 1 or (os.environ.get("TTR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         nccl_ranks = dist.get_world_size()
@@ -326,7 +385,7 @@ def main():
     inp = make_input(B, dev, seed=1234 + rank)
 
     sizes = [B] * world
-    pending = [None]
+    sched = GatherSchedule(args.gather if dist_on else "none", sizes=sizes, dst=0, local_shortcut=not dist_on)
     inflight = []  # completion events of the steps enqueued so far
     step_events = []  # all of them, for the per-step device times reported in the JSON line
     host_ms = []      # host time spent enqueuing each step
@@ -347,33 +406,22 @@ def main():
         ev.record()
         inflight.append(ev)
         step_events.append(ev)
-        last_step[0] = t
-        if world > 1 and args.gather == "step":
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = gather_batch(t, dst=0, sizes=sizes, async_op=True)
+        sched.after_step(t)   # `step`: start this step's gather (after the previous one completed); `end` / `none`: nothing moves
         return t
 
-    last_step = [None]
-
     def drain():
-        """Everything the root is owed has arrived when this returns (called inside the timed region)."""
-        if world > 1 and args.gather == "end" and last_step[0] is not None:
-            return gather_batch(last_step[0], dst=0, sizes=sizes, async_op=False).wait()
-        if pending[0] is not None:
-            res = pending[0].wait()
-            pending[0] = None
-            return res
-        return None
+        """Everything the root is owed has arrived when this returns (called inside the timed region): `end` = THE gather."""
+        return sched.drain()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
-    elapsed, out, gathered = timed_steps(step, drain, fence, args.warmup, args.steps)
-    if world > 1:
+    elapsed, out, gathered = timed_steps(step, drain, fence, args.warmup, args.steps, on_timed_start=lambda: setattr(sched, "g0", sched.gathers))
+    sched.gathers_timed = sched.gathers - getattr(sched, "g0", 0)
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -385,15 +433,33 @@ def main():
     # ---- N > 1: the gather of one step's result ALONE (nothing else running), so that a scaling line shows which side
     # binds: `gather.alone_ms` against `ms_per_step`.  Every peer sends its packed cores over its own xGMI link to rank 0.
     gather_info = None
-    if world > 1:
+    if dist_on:
         per_peer = sum(c.numel() * c.element_size() for c in out.cores)
         fence()
         g0 = time.perf_counter()
-        gather_batch(out, dst=0, sizes=sizes, async_op=False).wait()
+        gather_batch(out, dst=0, sizes=sizes, async_op=False, local_shortcut=False).wait()
         fence()
         g_ms = (time.perf_counter() - g0) * 1e3
-        gather_info = {"mode": args.gather, "bytes_per_peer_per_step": per_peer, "peers": world - 1, "alone_ms": g_ms,
-                       "root_inbound_GBs": per_peer * (world - 1) / g_ms / 1e6, "per_link_GBs": per_peer / g_ms / 1e6}
+        # ... and the steps ALONE (no gather at all), same fences: with `end` the timed region is steps * compute_only + one gather
+        mode_saved, sched.mode = sched.mode, "none"
+        n_ev, n_h = len(step_events), len(host_ms)
+        fence()
+        c0 = time.perf_counter()
+        for _ in range(min(args.steps, 3)):
+            step()
+        fence()
+        c_ms = (time.perf_counter() - c0) * 1e3 / min(args.steps, 3)
+        sched.mode = mode_saved
+        del step_events[n_ev:], host_ms[n_h:]   # (not part of the timed region's per-step records)
+        free_b, total_b = torch.cuda.mem_get_info()
+        gather_info = {"mode": args.gather, "collectives_in_timed_region": sched.gathers_timed, "bytes_per_peer_per_step": per_peer,
+                       "peers": world - 1, "alone_ms": g_ms, "compute_only_ms_per_step": c_ms,
+                       # `step`: the gather of step k has to hide under the compute of step k + 1 -- if it does not, the job is link-bound
+                       "hidden_under_compute": bool(g_ms < c_ms) if args.gather == "step" else None,
+                       "root_inbound_GBs": per_peer * max(world - 1, 1) / g_ms / 1e6, "per_link_GBs": per_peer / g_ms / 1e6,
+                       "root_receive_buffers_GB": per_peer * world / 1e9 * (2 if args.gather == "step" else 1),
+                       "hbm_GB": {"total": total_b / 1e9, "free_now": free_b / 1e9,
+                                  "reserved_by_torch": torch.cuda.memory_reserved() / 1e9}}
 
     # ---- per-kernel device time over an identical pass (HIP events on the launch stream).  The timed region
     # above runs sub-batches on several streams so that kernels overlap; here every kernel must run alone for
@@ -475,7 +541,7 @@ def main():
                 "parallelism": (f"batch-sharded x{world}, " + {
                     "step": "one async RCCL gather of packed cores per step (overlapped with the next step)",
                     "end": "ONE RCCL gather of the packed cores after the last step (inside the timed region)",
-                    "none": "no gather"}[args.gather]) if world > 1 else "single GPU",
+                    "none": "no gather"}[args.gather]) if dist_on else "single GPU",
             },
             "nccl_ranks": nccl_ranks,
             "gather": gather_info,
@@ -543,6 +609,34 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extras["batch_4096"] = {"error": repr(e)[:200]}
                 torch.cuda.empty_cache()
+            # SURVEY 8d's second variant of the metric input: bond singular values ~ 2^(-decay j).  Every shortcut that makes the
+            # flat `randn`-core input fast declines here (the second Gram pass runs, the first pass is the full QL solver);
+            # same shapes, same B, checked against the float64 oracle.
+            for decay in (1.0, 0.5):
+                try:
+                    dinp = make_decaying_input(B, dev, seed=777, decay=decay)
+
+                    def dstep(dinp=dinp):
+                        t = tn.Tensor(dinp, batch=True)
+                        t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+                        return t
+                    el, dout, _ = timed_steps(dstep, lambda: None, torch.cuda.synchronize, 2, 5)
+                    ent = {"tensors_per_step": B, "bond_sigma": f"~2^(-{decay} j)", "ms_per_step": el / 5 * 1e3,
+                           "cores_per_s": B * N_CORES * 5 / el, "ratio_to_headline": (el / 5 * 1e3) / ms_per_step}
+                    _hipops.STREAM_CHUNKS_ENABLED = False
+                    _hip.prof_enable(True)
+                    dstep()
+                    torch.cuda.synchronize()
+                    pk = _hip.prof_collect()
+                    _hip.prof_enable(False)
+                    _hipops.STREAM_CHUNKS_ENABLED = not args.single_stream
+                    ent["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in pk.items() if v["launches"] > 0}
+                    ent["oracle_check"] = decaying_parity(dinp, dout, 0)
+                    extras[f"decaying_spectrum_{decay}"] = ent
+                    del dinp, dout
+                except Exception as e:  # noqa: BLE001
+                    extras[f"decaying_spectrum_{decay}"] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
             res["extras"] = extras
         if world == 1 and not args.no_extras and not args.no_configs:
             # BASELINE's other configs (C1 .. C4), one entry each: time, SURVEY 8d flops / bytes, roofline fraction, CPU
@@ -559,7 +653,7 @@ def main():
             if "extras" in res and "single_tensor" in res["extras"]:
                 res["extras"]["single_tensor"]["speedup_vs_cpu_best"] = res["extras"]["single_tensor"]["cores_per_s"] / cb["value"]
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -102,3 +102,66 @@ def test_pack_cores_zero_copy_when_back_to_back():
     assert q.data_ptr() != off[10:].data_ptr() and torch.equal(q, off[10:70])
     gap = [off[10:34].view(2, 3, 2, 2), off[40:76].view(2, 2, 3, 3)]  # same storage, not adjacent: copy
     assert torch.equal(pack_cores(gap), torch.cat([off[10:34], off[40:76]]))
+
+
+def _sched_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tntorch_amd as tn
+    from tntorch_amd.dist_batch import GatherSchedule, shard_range
+
+    torch.manual_seed(0)
+    full = tn.randn([5, 6, 6, 6], ranks_tt=4, batch=True, dtype=torch.float64)
+    lo, hi = shard_range(5, world, rank)
+    sizes = [shard_range(5, world, r)[1] - shard_range(5, world, r)[0] for r in range(world)]
+    report = {}
+    for mode in GatherSchedule.MODES:
+        sched = GatherSchedule(mode, sizes=sizes, dst=0)
+        for k in range(3):  # three "steps": the same shard scaled by k + 1, rounded
+            t = tn.Tensor([c[lo:hi] * (k + 1.0) if i == 0 else c[lo:hi].clone() for i, c in enumerate(full.cores)], batch=True)
+            t.round_tt(rmax=2)
+            sched.after_step(t)
+        parts = sched.drain()
+        assert sched.drain() is None                     # nothing is owed twice
+        if rank == 0 and mode != "none":
+            merged = torch.cat([p.cores[0] for p in parts])
+            report[mode] = (sched.gathers, [p.cores[0].shape[0] for p in parts], merged.numpy())
+        else:
+            assert parts is None
+            report[mode] = (sched.gathers, None, None)
+        dist.barrier()
+    if rank == 0:
+        q.put(report)
+    dist.destroy_process_group()
+
+
+def test_gather_schedule_policies_gloo_world2():
+    """bench.py's `--gather end | step | none` control flow (GatherSchedule) on two gloo ranks: `end` issues ONE collective and
+    delivers the LAST step, `step` one per step (at most one in flight) and also ends with the last step, `none` none."""
+    import tntorch_amd as tn
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rep = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert rep["end"][0] == 1 and rep["step"][0] == 3 and rep["none"][0] == 0
+    assert rep["end"][1] == rep["step"][1] == [3, 2]
+    torch.manual_seed(0)
+    full = tn.randn([5, 6, 6, 6], ranks_tt=4, batch=True, dtype=torch.float64)
+    last = tn.Tensor([c * 3.0 if i == 0 else c.clone() for i, c in enumerate(full.cores)], batch=True)
+    last.round_tt(rmax=2)
+    for mode in ("end", "step"):
+        assert abs(torch.from_numpy(rep[mode][2]) - last.cores[0]).max() < 1e-12
+    with pytest.raises(ValueError):
+        from tntorch_amd.dist_batch import GatherSchedule
+        GatherSchedule("sometimes")

@@ -1342,6 +1342,7 @@ def test_big_bond_truncation_from_selected_eigenpairs(batch, dt, monkeypatch):
     calls = []
     orig = _hip.eigh_topk
     monkeypatch.setattr(_hip, "eigh_topk", lambda G, k: calls.append(tuple(G.shape)) or orig(G, k))
+    monkeypatch.setattr(_hipops, "SUBSPACE_ENABLED", False)   # (round 4: the range finder would take the low-rank input first)
 
     def run(X):
         if batch:
@@ -1363,3 +1364,100 @@ def test_big_bond_truncation_from_selected_eigenpairs(batch, dt, monkeypatch):
         e_o, e_b, e_r = rel_diff(dense(ours), X), rel_diff(dense(base), X), rel_diff(dense(ref), X)
         bound = 1e-5 if dt == torch.float32 else 1e-10
         assert abs(e_o - e_r) <= bound and abs(e_b - e_r) <= bound
+
+
+# ------------------------------------------------------------------ big bonds with concentrated spectra: the certified range finder
+def _lowrank_noise(m, n, r, noise, dt, seed, decay=0.0):
+    g = torch.Generator().manual_seed(seed)
+    U = torch.linalg.qr(torch.randn(m, r, generator=g, dtype=torch.float64))[0]
+    V = torch.linalg.qr(torch.randn(n, r, generator=g, dtype=torch.float64))[0]
+    s = 2.0 ** (-decay * torch.arange(r, dtype=torch.float64))
+    M = (U * s) @ V.T
+    M = M / M.norm() + noise * torch.randn(m, n, generator=g, dtype=torch.float64) / math.sqrt(m * n)
+    return M.to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(3000, 256), (200, 1100), (1024, 1024)])
+@pytest.mark.parametrize("batch", [False, True])
+def test_big_bond_range_finder_vs_lapack(dt, shape, batch):
+    """Both dimensions above 64, rank cap 8, energy concentrated in 8 directions (+ 1e-3 noise; second item: sigma_j ~ 2^(-j/2)):
+    `truncate` takes the subspace path (Gram matrix -> certified range finder -> fused small truncation) and returns what
+    LAPACK's SVD of the same matrix gives: kept singular values to 2e-5 sigma_1 (fp32) / 1e-11 (fp64), the same
+    approximation error, orthonormal rows of the right factor.  Tall (right Gram), wide (left Gram) and square."""
+    from tntorch_amd import _hipops
+    m, n = shape
+    r = 8
+    f32 = dt == torch.float32
+    Ms = [_lowrank_noise(m, n, r, 1e-3, dt, 1), _lowrank_noise(m, n, r, 1e-3, dt, 2, decay=0.5)]
+    _hipops.PATH_TRACE = []
+    try:
+        if batch:
+            left, right = tn.truncated_svd(torch.stack(Ms).cuda(), rmax=r, left_ortho=False, batch=True)
+            outs = [(left[i].cpu(), right[i].cpu()) for i in range(2)]
+        else:
+            outs = []
+            for M in Ms:
+                left, right = tn.truncated_svd(M.cuda(), rmax=r, left_ortho=False)
+                outs.append((left.cpu(), right.cpu()))
+        paths = [p[0] for p in _hipops.PATH_TRACE]
+    finally:
+        _hipops.PATH_TRACE = None
+    assert paths and all(p == "subspace" for p in paths), paths
+    for M, (left, right) in zip(Ms, outs):
+        assert left.shape == (m, r) and right.shape == (r, n)
+        Md = M.double()
+        sv = torch.linalg.svdvals(Md)
+        ours_sv = torch.linalg.svdvals(left.double())          # right has orthonormal rows: sigma(left) = kept sigma
+        assert ((ours_sv - sv[:r]).abs().max() / sv[0]).item() <= (2e-5 if f32 else 1e-11)
+        e_o = rel_diff(left.double() @ right.double(), Md)
+        e_r = (sv[r:].square().sum().sqrt() / sv.square().sum().sqrt()).item()
+        assert abs(e_o - e_r) <= (1e-5 if f32 else 1e-11), (e_o, e_r)
+        Rr = right.double()
+        assert (Rr @ Rr.T - torch.eye(r, dtype=torch.float64)).abs().max().item() <= (3e-5 if f32 else 1e-11)
+
+
+@pytest.mark.parametrize("left_ortho", [True, False])
+def test_big_bond_range_finder_declines_flat_and_heavy_tails(left_ortho):
+    """`randn` (flat: the participation ratio exceeds the basis) and a slowly decaying spectrum (sigma_j ~ 1/j: the energy
+    outside any 32-dimensional basis is not small against sigma_8^2) fail the certificate and take the full paths; results
+    against LAPACK either way."""
+    from tntorch_amd import _hipops
+    g = torch.Generator().manual_seed(5)
+    m, n, r = 2048, 256, 8
+    U = torch.linalg.qr(torch.randn(m, n, generator=g, dtype=torch.float64))[0]
+    V = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0]
+    heavy = ((U / torch.arange(1, n + 1, dtype=torch.float64)) @ V.T).float()
+    flat = torch.randn(m, n, generator=g, dtype=torch.float32)
+    for M in (flat, heavy):
+        _hipops.PATH_TRACE = []
+        try:
+            left, right = tn.truncated_svd(M.cuda(), rmax=r, left_ortho=left_ortho)
+            paths = [p[0] for p in _hipops.PATH_TRACE]
+        finally:
+            _hipops.PATH_TRACE = None
+        assert paths and "subspace" not in paths, paths
+        sv = torch.linalg.svdvals(M.double())
+        e_o = rel_diff(left.cpu().double() @ right.cpu().double(), M.double())
+        e_r = (sv[r:].square().sum().sqrt() / sv.square().sum().sqrt()).item()
+        assert abs(e_o - e_r) <= 1e-5, (e_o, e_r)
+
+
+def test_c1_proxy_lowrank_takes_range_finder():
+    """The C1 proxy of `test_c1_proxy_dense_64_4_vs_oracle` (dense 64^4, TT rank 16 + 1e-3 noise, eps mode with the cap): its
+    n = 1024 bond is decided by the certified range finder, not by the n x n eigen-decomposition."""
+    from tntorch_amd import _hipops
+    torch.manual_seed(11)
+    shape, r = [64] * 4, 16
+    low = oracle.tt_to_dense(oracle.tt_randn(shape, r, dtype=torch.float64))
+    X = (low / low.norm() * math.sqrt(low.numel()) + 1e-3 * torch.randn(shape, dtype=torch.float64)).float()
+    _hipops.PATH_TRACE = []
+    try:
+        t = tn.Tensor(X.cuda(), ranks_tt=r)
+        trace = list(_hipops.PATH_TRACE)
+    finally:
+        _hipops.PATH_TRACE = None
+    assert [p for p in trace if p[2] == 1024] == [("subspace", 4096, 1024, 16)], trace
+    assert list(t.ranks_tt) == [1, 16, 16, 16, 1]
+    e_o = rel_diff(t.torch().cpu().double(), X.double())
+    assert abs(e_o - 1e-3) <= 2e-5, e_o

@@ -346,6 +346,95 @@ def _topk_one_pass(G: torch.Tensor, r: int, use_delta: bool = False, delta2: flo
     return X, sig, info
 
 
+# Rank-capped truncation of a big bond (both dimensions above 64) whose energy is CONCENTRATED -- real data, low rank + noise,
+# decaying spectra: SURVEY 8d's primary inputs for C1 / C3 -- through a randomised range finder on the bond's n x n Gram matrix
+# (north_star: "randomised range-finder SVD"): subspace iteration Q <- orth(G Q) with l = max(32, 2 r) <= 64 columns (one small
+# MFMA GEMM + one TSQR per step; G is already there, the iteration never touches M), then ONE more pass over M for the
+# projection B = M Q and the fused <= 64-column / -row two-pass truncation of B (singular values of B to O(eps sigma_1), the
+# class of gesdd) -- instead of an n x n eigen-decomposition, a rotation M V1 (as many flops as the Gram matrix), a second Gram
+# matrix and a second n x n eigenproblem.  The basis is accepted on a CERTIFICATE, per item, decided from a handful of device
+# scalars and one flag readback per round (control flow, like the flat-spectrum decisions next to it):
+#   tau = trace(G) - trace(Q^T G Q) >= lambda_max of G on the complement of span(Q)  (G is PSD), so with theta_r > 2 tau the r kept
+#   Ritz values are separated from everything outside the basis by gap >= theta_r - tau, and lambda_j - theta_j <=
+#   ||G Q - Q (Q^T G Q)||_F^2 / gap  (the quadratic residual bound), which has to lie below 1e-5 sqrt(theta_r theta_1), i.e. the
+#   kept singular values of B = M Q equal those of M to ~5e-6 sigma_1 (they can only be smaller: interlacing).
+# A flat spectrum (randn: the participation ratio trace(G)^2 / ||G||_F^2 exceeds the basis size -- decided before any
+# iteration, from two reductions) or a heavy tail fails the certificate and takes the paths below unchanged (selected
+# eigenpairs when the kept spectrum is flat, the full decomposition otherwise).  eps mode: only when the rank rule, evaluated
+# on B's singular values alone (the invisible tail can only ADD energy), already returns the cap.  TTR_SUBSPACE=0 switches it off.
+SUBSPACE_ENABLED = os.environ.get("TTR_SUBSPACE", "1") != "0"
+_SUBSPACE_ROUNDS = (2, 4, 8)      # subspace-iteration steps before the 1st / 2nd / 3rd look at the certificate
+PATH_TRACE: Optional[list] = None  # bench / tests: set to a list and ``truncate`` appends (path, m, n, rank cap) for every big bond
+
+
+def _trace(path: str, m: int, n: int, r: int) -> None:
+    if PATH_TRACE is not None:
+        PATH_TRACE.append((path, int(m), int(n), int(r)))
+
+
+def _subspace_basis(G: torch.Tensor, r: int) -> Optional[torch.Tensor]:
+    """Orthonormal Q [B, n, l] whose span carries the r leading eigenpairs of the PSD matrices G [B, n, n] to the certificate
+    above for EVERY item, or None."""
+    Bt, n, _ = G.shape
+    l = min(64, max(32, 2 * r))
+    if not SUBSPACE_ENABLED or r > _TOPK_MAX_RANK or n < 2 * l or l > _hip.max_qr_cols(G.dtype):
+        return None
+    Gn, _ = _hip.pow2_normalize(G)                       # ||G[b]||_F in [0.5, 1)
+    tr = _gram_trace(Gn).double()                         # ([B]-sized device scalars from here on, in double)
+    fro = _hip.norm(Gn.reshape(Bt, -1)).double()
+    live = fro > 0
+    eff = torch.where(live, tr * tr / (fro * fro).clamp_min(1e-300), torch.zeros_like(tr))
+    if float(eff.amax().item()) > l + 1:                  # (readback: control flow only) energy spread over more directions than the basis holds
+        return None
+    gen = torch.Generator(device=G.device)
+    gen.manual_seed(0x5AB5 + n)
+    Q, _ = _hip.qr(_hip.gemm(Gn, torch.randn((Bt, n, l), dtype=G.dtype, device=G.device, generator=gen)))
+    eps = torch.finfo(G.dtype).eps
+    for steps in _SUBSPACE_ROUNDS:
+        for _ in range(steps):
+            Q, _ = _hip.qr(_hip.gemm(Gn, Q))
+        Y = _hip.gemm(Gn, Q)
+        H = _hip.gemm(Q, Y, transA=True)                  # l x l
+        _hip.gemm_axpby(Q, H, Y, -1.0, 1.0)               # Y <- G Q - Q H
+        res2 = _hip.norm(Y.reshape(Bt, -1)).double().square()
+        _, sg, _ = _hip.eigh_trunc(H, _hip.EIG_RAW, False, 0.0, l, abs_floor=_hip.SOLVER_TRIDIAG)
+        th = sg.double().square()                         # Ritz values, decreasing
+        tau = (tr - th.sum(dim=1)).clamp_min(0) + 4.0 * (l + math.sqrt(n)) * eps * tr   # (+ the rounding level of the subtraction)
+        th_r, th_1 = th[:, r - 1], th[:, 0]
+        ok = (th_r > 2.0 * tau) & (res2 <= (th_r - tau) * (th_r * th_1).sqrt() * 1e-5)
+        if bool((ok | ~live).all().item()):               # (readback: control flow only)
+            return Q
+        if bool(((th_r <= 2.0 * tau) & live).any().item()) and steps >= 4:
+            break                                          # the tail outside the basis is not small: more steps will not change that
+    return None
+
+
+def _subspace_truncate(M, G, r, delta, rmax, left_ortho, algorithm, batch, right_alloc, gtr):
+    """``truncate`` of a big bond through the range finder above; None when the basis is not certified (or, in eps mode, the
+    rank rule does not return the cap on the visible spectrum)."""
+    Bt, m, n = M.shape
+    left_side = m <= n
+    Q = _subspace_basis(G, r)
+    if Q is None:
+        return None
+    if left_side:
+        Bm = _hip.gemm(Q, M, transA=True)                 # l x n: the fused row kernels take it from here
+        t = truncate(Bm, delta, rmax, left_ortho, algorithm, batch, right_alloc)
+    else:
+        Bm = _hip.gemm(M, Q)                              # m x l: ... the fused column kernels
+        t = truncate(Bm, delta, rmax, left_ortho, algorithm, batch)
+    if t.zero:
+        zl, zr = _zero_factors(M)
+        return Truncation(zl, None, zr, 1, zero=True, gtrace=gtr)
+    if not batch and t.rank < r:
+        return None                                        # eps mode: the cap does not bind on the visible spectrum -- the full path decides
+    if left_side:
+        left = _hip.gemm(Q, t.left_scaled())
+        return Truncation(left, None, t.right, t.rank, info=t.info, gtrace=gtr)
+    right = _hip.gemm(t.right, Q, transB=True)
+    return Truncation(t.left, t.colscale, right, t.rank, info=t.info, gtrace=gtr)
+
+
 class Truncation:
     """Result of ``truncate``: ``left_core`` (m x r), optional column scale, ``right`` (r x n)."""
 
@@ -448,6 +537,7 @@ def truncate(
         # -> Jacobi -> projection with U = V1 V2 formed in the kernel's prologue, which also emits left = U sigma.
         V1 = None
         G = gram if gram is not None else _hip.rowgram(M)
+        gtr = _gram_trace(G) if want_trace else None
         if algorithm == "svd":
             if (batch and EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0 and rmax is not None and delta2_dev is None
                     and _hip.eigh_top_ok(k, _rank_cap(rmax, k))):
@@ -479,16 +569,16 @@ def truncate(
             if algorithm == "svd" and not left_ortho:
                 _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps, rank_dev=info)  # (not the rows that are cut away)
             _hip.mask_cols(left, info)
-            return Truncation(left, None, right, r, info=info)
+            return Truncation(left, None, right, r, info=info, gtrace=gtr)
         r = _select_rank(info, batch, rmax, k)
         if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
-                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True)
+                              torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True, gtrace=gtr)
         dst = right_alloc(r) if right_alloc is not None else None
         right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst)
         if algorithm == "svd" and not left_ortho:
             _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
-        return Truncation(left, None, right, r, info=info)
+        return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
     if not left_side and _hip.colsweep_fused_ok(M):
         # Tall matrix with up to 64 columns (the first, largest steps of a dense right-to-left TT-SVD): the same fused
@@ -527,11 +617,18 @@ def truncate(
         # on the host, hence one flag readback per such bond (dense batches: BASELINE config C3; the bonds of a TT-to-TT
         # rounding have <= 64 rows and decide per item on the device).  Otherwise pass 1 is a pre-rotation.
         try_flat = batch and FLAT_SPECTRUM_THR > 0
+        if (batch or rmax is not None) and min(m, n) > 64:
+            # concentrated spectra (low rank + noise, decaying): certified range finder + the fused small truncation
+            sub = _subspace_truncate(M, G, _rank_cap(rmax, k), delta, rmax, left_ortho, algorithm, batch, right_alloc, gtr)
+            if sub is not None:
+                _trace("subspace", m, n, _rank_cap(rmax, k))
+                return sub
         if FLAT_SPECTRUM_THR > 0 and (batch or rmax is not None):
             # (eps mode with a rank cap -- a single dense tensor to given ranks, BASELINE config C1: only when the cap provably binds)
             one_pass = _topk_one_pass(G, _rank_cap(rmax, k), use_delta, delta2)
         if one_pass is not None:
             V1, Mw = None, M
+            _trace("topk_one_pass", m, n, _rank_cap(rmax, k))
         else:
             V1, sig1, info1 = _eigh_any(G, _hip.EIG_RAW, False, 0.0, cap if try_flat else k, _hip.SOLVER_TRIDIAG,
                                         prerotation=not try_flat)
@@ -540,10 +637,13 @@ def truncate(
         elif try_flat and int(_hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR).amin().item()) == 1:
             one_pass = (V1, sig1, info1)
             V1, Mw = None, M
+            _trace("full_one_pass", m, n, _rank_cap(rmax, k))
         elif left_side:
+            _trace("full_two_pass", m, n, _rank_cap(rmax, k))
             Mw = _hip.gemm(V1, M, transA=True)           # V1^T M
             G = _hip.gemm(Mw, Mw, transB=True)
         else:
+            _trace("full_two_pass", m, n, _rank_cap(rmax, k))
             if scratch_ok and M.is_contiguous() and M.numel() * M.element_size() > _INPLACE_ROTATE_BYTES:
                 # config-scale carries (C1 class: tens of GiB): every row of M V1 depends on the same row of M only, so
                 # the rotation runs chunk by chunk into a bounded buffer that is copied back over its source rows
@@ -1238,8 +1338,8 @@ def dense_tt_svd(
             if bad:  # (readback: control flow only) redo with the norm pass and the scaled input
                 nr = _hip.norm(X.reshape(Bt, -1))
                 e2 = _range_guard_from_norms(nr)
-                if e2 is None:  # (the trace was unavailable or overflowed by accumulation only)
-                    e2 = torch.zeros(Bt, dtype=torch.int32, device=X.device)
+                if e2 is None:  # (the trace overflowed by accumulation only: the input itself is in range -- no scaled copy)
+                    return dense_tt_svd(X, eps, rmax, algorithm, batch, _guard_scaled=torch.zeros(Bt, dtype=torch.int32, device=X.device))
                 return dense_tt_svd(_scale_batch(X, e2, -1), eps, rmax, algorithm, batch, _guard_scaled=e2)
         cores[kdim] = t.right.reshape(Bt, t.rank, shape[kdim], rn)
         C = t.left_scaled()

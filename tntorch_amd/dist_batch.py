@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from .tensor import Tensor
 
-__all__ = ["shard_range", "pack_cores", "unpack_cores", "gather_batch", "round_tt_sharded", "GatherHandle"]
+__all__ = ["shard_range", "pack_cores", "unpack_cores", "gather_batch", "round_tt_sharded", "GatherHandle", "GatherSchedule"]
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -100,16 +100,19 @@ def gather_batch(
     group=None,
     sizes: Optional[Sequence[int]] = None,
     async_op: bool = False,
+    local_shortcut: bool = True,
 ) -> GatherHandle:
     """Collect the batch-sharded tensor ``t`` (``batch=True``) on rank ``dst`` with a single gather.
 
     Every rank must hold cores of identical trailing shape (rmax-mode rounding).  ``sizes``: local batch
     size of every rank when known up front (skips the 8-byte size exchange and its host sync); shorter
     shards are padded in the packed buffer.  ``async_op=True`` returns immediately; call ``wait()``.
+    ``local_shortcut=False``: a process group of ONE rank still goes through the collective (tests: the code an
+    N-rank job runs -- packed view, receive buffers, ``dist.gather``, the work handle -- on a single GPU).
     """
     assert t.batch, "gather_batch needs a batch=True tensor"
     Bl = t.cores[0].shape[0]
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and local_shortcut):
         flat = pack_cores(t.cores)
         return GatherHandle(None, [flat], [list(c.shape) for c in t.cores], [Bl], None)
     world = dist.get_world_size(group)
@@ -150,3 +153,47 @@ def round_tt_sharded(cores: Sequence[torch.Tensor], rmax, algorithm: str = "svd"
     t = Tensor(list(cores), batch=True)
     t.round_tt(rmax=rmax, algorithm=algorithm)
     return gather_batch(t, dst=dst, group=group, sizes=sizes).merged()
+
+
+class GatherSchedule:
+    """When the rounded cores of a stream of steps travel to the root (the policy `bench.py --gather` selects):
+
+    ``end``   north_star's reading -- "a single RCCL gather ... at the end": nothing moves while the steps run, ``drain()``
+              gathers the LAST step's result (blocking) -- one collective per job.
+    ``step``  every step's result is delivered: ``after_step`` starts an asynchronous gather (RCCL's own stream, under the next
+              step's compute) after waiting for the previous one -- at most one in flight; ``drain()`` completes the last.
+    ``none``  no gather (compute-only scaling).
+
+    ``drain()`` returns, on ``dst``, the list of per-rank ``Tensor`` parts of the last gathered step (``None`` elsewhere / for
+    ``none``).  ``gathers`` counts the collectives issued."""
+
+    MODES = ("end", "step", "none")
+
+    def __init__(self, mode: str, sizes: Optional[Sequence[int]] = None, dst: int = 0, group=None, local_shortcut: bool = True):
+        if mode not in self.MODES:
+            raise ValueError(f"gather mode must be one of {self.MODES}, got {mode!r}")
+        self.mode, self.sizes, self.dst, self.group, self.local_shortcut = mode, sizes, dst, group, local_shortcut
+        self._pending: Optional[GatherHandle] = None
+        self._last: Optional[Tensor] = None
+        self.gathers = 0
+
+    def _gather(self, t: Tensor, async_op: bool) -> GatherHandle:
+        self.gathers += 1
+        return gather_batch(t, dst=self.dst, group=self.group, sizes=self.sizes, async_op=async_op, local_shortcut=self.local_shortcut)
+
+    def after_step(self, t: Tensor) -> None:
+        self._last = t
+        if self.mode == "step":
+            if self._pending is not None:
+                self._pending.wait()
+            self._pending = self._gather(t, True)
+
+    def drain(self) -> Optional[List[Tensor]]:
+        if self.mode == "end" and self._last is not None:
+            t, self._last = self._last, None
+            return self._gather(t, False).wait()
+        if self._pending is not None:
+            res = self._pending.wait()
+            self._pending = None
+            return res
+        return None

@@ -97,6 +97,91 @@ def _roof(bound, flops, byts, sec):
             "hbm_frac": byts / sec / 1e9 / HBM_GBS}
 
 
+def _paths(fn):
+    """Which truncation path every big bond (both dimensions above 64) of ONE extra run took (`_hipops.PATH_TRACE`):
+    'subspace' = certified range finder + fused small truncation, 'topk_one_pass' = selected eigenpairs of the Gram matrix
+    (flat kept spectrum), 'full_one_pass' / 'full_two_pass' = the n x n eigen-decomposition(s)."""
+    from tntorch_amd import _hipops
+
+    _hipops.PATH_TRACE = []
+    try:
+        fn()
+        torch.cuda.synchronize()
+        tr = list(_hipops.PATH_TRACE)
+    finally:
+        _hipops.PATH_TRACE = None
+    return [{"path": p, "m": m, "n": n, "cap": r} for p, m, n, r in tr]
+
+
+def _lowrank_plus_noise(shape, r, dev, gen, batch=None, noise=1e-3, split=None):
+    """SURVEY 8d's primary dense input: a TT-rank-r tensor of unit RMS + noise * randn, built on the device without a second
+    tensor of its size: the product of the (modes < split) and (modes >= split) halves of a random rank-r train, written in
+    row chunks, the noise added chunk by chunk.  `batch`: leading batch dimension (independent items)."""
+    N = len(shape)
+    split = split if split is not None else (N + 1) // 2
+    lead = () if batch is None else (batch,)
+    rr = [1] + [r] * (N - 1) + [1]
+    cores = [torch.randn(lead + (rr[k], shape[k], rr[k + 1]), generator=gen, device=dev) for k in range(N)]
+
+    def chain(cs):
+        acc = cs[0].reshape(lead + (-1, cs[0].shape[-1]))
+        for c in cs[1:]:
+            acc = (acc @ c.reshape(lead + (c.shape[-3], -1))).reshape(lead + (-1, c.shape[-1]))
+        return acc
+
+    L = chain(cores[:split])                                   # [.., rows, r]  (rows = prod(shape[:split]))
+    Rt = cores[split].reshape(lead + (r, -1))
+    for c in cores[split + 1:]:
+        Rt = (Rt.reshape(lead + (-1, c.shape[-3])) @ c.reshape(lead + (c.shape[-3], -1))).reshape(lead + (r, -1))
+    # unit RMS: ||L Rt||^2 = trace((L^T L)(Rt Rt^T))
+    nrm2 = ((L.transpose(-1, -2) @ L) * (Rt @ Rt.transpose(-1, -2))).sum(dim=(-1, -2))
+    L = L * (math.sqrt(math.prod(shape)) / nrm2.sqrt()).reshape(lead + (1, 1))
+    rows, cols = L.shape[-2], Rt.shape[-1]
+    X = torch.empty(lead + (rows, cols), device=dev, dtype=torch.float32)
+    step = max(1, (1 << 28) // cols)
+    for r0 in range(0, rows, step):
+        blk = X[..., r0:r0 + step, :]
+        torch.matmul(L[..., r0:r0 + step, :], Rt, out=blk) if batch is None else blk.copy_(L[..., r0:r0 + step, :] @ Rt)
+        blk.add_(torch.randn(blk.shape, generator=gen, device=dev), alpha=noise)
+    return X.reshape(lead + tuple(shape))
+
+
+def _dense_tt_check(X, t, expect_err=None):
+    """Check of a TIMED dense -> TT result at config scale, on the device, slice by slice along the first mode (no second tensor
+    of the input's size): T = the projection of X onto the right-orthonormal cores 1.. iff <X, T> = ||T||^2 and the cores
+    are right-orthonormal; then ||X - T||^2 = ||X||^2 - ||T||^2.  Reports the relative approximation error, the projection
+    defect |<X,T> - ||T||^2| / ||T||^2, the energy identity and the orthonormality defect; `expect_err`: the error a
+    low-rank + noise input must come out at."""
+    from tntorch_amd import _hip, _hipops
+
+    cores = [c if c.dim() == 4 else c[None] for c in t.cores]          # [1, r, I, r']
+    xx = tt = xt = d2 = 0.0
+    for i in range(X.shape[0]):
+        Ti = _hipops.decompress([cores[0][:, :, i:i + 1, :].contiguous()] + cores[1:]).reshape(X[i].shape)
+        xi = X[i]
+        xx += float(_hip.norm(xi.reshape(1, -1))[0].item()) ** 2
+        tt += float(_hip.norm(Ti.reshape(1, -1))[0].item()) ** 2
+        # <x, t> as 4096 partial dot products (batched 1 x n x 1 GEMMs), summed in double
+        xt += float(_hip.gemm(xi.reshape(4096, 1, -1), Ti.reshape(4096, -1, 1)).double().sum().item())
+        d2 += float(_hipops.dense_dist(xi, Ti).item()) ** 2
+        del Ti
+    orth = 0.0
+    for c in cores[1:]:
+        Rm = c.reshape(1, c.shape[1], -1)
+        G = _hip.gemm(Rm, Rm, transB=True)[0]
+        orth = max(orth, float((G - torch.eye(G.shape[0], device=G.device, dtype=G.dtype)).abs().max().item()))
+    err = math.sqrt(d2 / xx)
+    out = {"approx_err": err, "kept_energy_fraction": tt / xx, "projection_defect": abs(xt - tt) / max(tt, 1e-300),
+           "energy_identity_defect": abs(d2 - (xx - tt)) / xx, "right_orthonormality_defect": orth,
+           "bounds": {"projection_defect": 1e-3, "energy_identity_defect": 1e-4, "right_orthonormality_defect": 5e-5}}
+    ok = out["projection_defect"] <= 1e-3 and out["energy_identity_defect"] <= 1e-4 and orth <= 5e-5
+    if expect_err is not None:
+        out["expected_err"] = expect_err
+        ok = ok and abs(err - expect_err) <= 2e-5
+    out["ok"] = bool(ok)
+    return out
+
+
 def _tt_rel_err(a, b):
     import oracle
     a = [c.double() for c in a]
@@ -164,14 +249,17 @@ def c2(tn, dev, algorithm="svd", cpu=True):
 
 
 # ---------------------------------------------------------------------------------------------------------------- C3
-def c3(tn, dev, algorithm="svd", cpu=True):
+def c3(tn, dev, algorithm="svd", cpu=True, variant="randn"):
     import oracle
 
     share, total = 64, 512
     shape = [32] * 5
     flop, byts = 7.71e9, 3.72e8  # SURVEY 8d, per tensor
     gen = torch.Generator(device=dev).manual_seed(99)
-    X = torch.randn([share] + shape, generator=gen, device=dev, dtype=torch.float32)
+    if variant == "randn":
+        X = torch.randn([share] + shape, generator=gen, device=dev, dtype=torch.float32)
+    else:  # "plus low-rank+noise variant" (TT rank 8 = the cap, unit RMS, + 1e-3 randn)
+        X = _lowrank_plus_noise(shape, 8, dev, gen, batch=share, split=3)
     sec, allt, out = _timeit(lambda: tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm), reps=3, warmup=1)
     assert out.ranks_tt.tolist() == [1, 8, 8, 8, 8, 1]
 
@@ -190,6 +278,8 @@ def c3(tn, dev, algorithm="svd", cpu=True):
     kinds = _kinds(lambda: tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm))
     res = {
         "kernel_ms": kinds,
+        "big_bond_paths": _paths(lambda: tn.Tensor(X, ranks_tt=8, batch=True, algorithm=algorithm)),
+        "input": variant if variant == "randn" else "TT rank 8 of unit RMS + 1e-3 randn",
         "workload": "TT-SVD of dense 32^5 fp32 tensors, rmax 8: the 64-tensor per-GPU share of the 8-GPU config (8.6 GB resident)",
         "dtype": "f32", "algorithm": algorithm,
         "ms": sec * 1e3, "ms_all": [round(x * 1e3, 2) for x in allt], "tensors": share, "tensors_per_s": share / sec,
@@ -204,7 +294,7 @@ def c3(tn, dev, algorithm="svd", cpu=True):
     e_r = ((oracle.tt_to_dense([c.double() for c in ref]) - x0.double()).norm() / x0.double().norm()).item()
     res["oracle_check"] = {"approx_err_ours": e_o, "approx_err_oracle": e_r, "bound_abs_diff": 1e-5,
                            "ok": bool(abs(e_o - e_r) <= 1e-5 and oracle.tt_ranks(ref) == [1, 8, 8, 8, 8, 1])}
-    if cpu:
+    if cpu and variant == "randn":
         secc, nt = _cpu_time(lambda: oracle.dense_to_tt(x0, 8, algorithm="eig"), threads=(8,), reps=1, budget_s=8.0)
         res["cpu_baseline"] = {"value": 1.0 / secc, "unit": "tensors/s", "cores": nt, "kind": "port",
                                "sample": "oracle.dense_to_tt(rmax=8, algorithm='eig') of ONE dense 32^5 tensor of the config "
@@ -230,21 +320,30 @@ def _c1_model(shape):
     return flop, byts, gram
 
 
-def c1(tn, dev, algorithm="svd", cpu=True):
+def c1(tn, dev, algorithm="svd", cpu=True, variant="randn", shape=None):
     import oracle
 
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     cands = [[64] * 6, [48] + [64] * 5, [32] + [64] * 5, [16] + [64] * 5, [64] * 5, [64] * 4]
-    shape = next(sh for sh in cands if math.prod(sh) * 4 * 1.35 <= free)
+    shape = shape or next(sh for sh in cands if math.prod(sh) * 4 * 1.35 <= free)
     gen = torch.Generator(device=dev).manual_seed(7)
-    X = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
+    if variant == "randn":
+        X = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
+    else:  # SURVEY 8d's primary C1 input: low-rank (TT rank 16, unit RMS) + 1e-3 randn
+        X = _lowrank_plus_noise(shape, 16, dev, gen)
     sec, allt, out = _timeit(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm), reps=2, warmup=1)
     ranks_out = out.ranks_tt.tolist()
     flop, byts, gram = _c1_model(shape)
     name = "x".join(map(str, shape))
+    check = _dense_tt_check(X, out, expect_err=None if variant == "randn" else 1e-3)
     del out
     res = {
+        "input": variant if variant == "randn" else "TT rank 16 of unit RMS + 1e-3 randn",
+        "oracle_check": dict(check, what="the TIMED result checked on the device: T is the orthogonal projection of X onto its "
+                                        "right-orthonormal cores (<X,T> = ||T||^2, ||X-T||^2 = ||X||^2 - ||T||^2); the choice of the "
+                                        "subspace against the oracle: tests/test_gpu_parity.py at 64^4"),
+        "big_bond_paths": _paths(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm)),
         "kernel_ms": _kinds(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm)),
         "workload": f"TT-SVD of a dense {name} fp32 tensor ({math.prod(shape) * 4 / 2 ** 30:.0f} GiB resident) to ranks_tt=16: the largest "
                     "member of the C1 family that fits (64^6 = 256 GiB does not fit 288 GB together with its carry)",
@@ -255,7 +354,7 @@ def c1(tn, dev, algorithm="svd", cpu=True):
     }
     del X
     torch.cuda.empty_cache()
-    if cpu:
+    if cpu and variant == "randn":
         torch.manual_seed(3)
         xp = torch.randn(64, 64, 64, 64)
         secc, nt = _cpu_time(lambda: oracle.dense_to_tt(xp, 16, algorithm="eig"), threads=(8,), reps=1, budget_s=8.0)
@@ -360,6 +459,20 @@ def config_extras(tn, dev, budget_s=170.0, algorithm="svd", cpu=True):
             out[name] = {"error": repr(e)[:400]}
         out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
         torch.cuda.empty_cache()
+        if name in ("c1", "c3") and "error" not in out[name]:
+            # SURVEY 8d's other input variant (low rank + 1e-3 noise: the kept spectrum is NOT flat), same shape, same checks
+            t0 = time.perf_counter()
+            try:
+                kw = {"cpu": False, "algorithm": algorithm, "variant": "lowrank"}
+                if name == "c1":
+                    kw["shape"] = out[name]["shape"]
+                v = fn(tn, dev, **kw)
+                v["ratio_to_randn"] = v["ms"] / out[name]["ms"]
+            except Exception as e:  # noqa: BLE001
+                v = {"error": repr(e)[:400]}
+            v["wall_s"] = round(time.perf_counter() - t0, 1)
+            out[name]["lowrank_variant"] = v
+            torch.cuda.empty_cache()
     return out
 
 
@@ -374,6 +487,8 @@ def main(args):
     _hip.lib()
     cpu = not getattr(args, "no_cpu_baseline", False)
     kw = {"cpu": cpu} if args.config == "c4" else {"cpu": cpu, "algorithm": args.algorithm}
+    if args.config in ("c1", "c3") and getattr(args, "variant", "randn") != "randn":
+        kw["variant"] = args.variant
     res = CONFIGS[args.config](tn, dev, **kw)
     line = {"metric": f"BASELINE config {args.config.upper()}: " + res["workload"], "value": res["ms"], "unit": "ms",
             "n_gpus": 1, "steps": None, "warmup": None, "ms_per_step": res["ms"], "higher_is_better": False, "scaling": "weak",
