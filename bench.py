@@ -76,7 +76,7 @@ def make_decaying_input(B, device, seed, decay):
 def decaying_parity(inp, out, item):
     """One item of a decaying-spectrum batch against the oracle run in float64 on the same fp32 cores (the bounds of
     tests/test_gpu_parity.py::test_decaying_spectrum_metric_shape): identical ranks, bond singular values to 4e-6 sigma_max,
-    right-orthonormal cores to 5e-5, approximation error within 4e-6 + 1e-2 relative of the oracle's."""
+    right-orthonormal cores to 5e-5, approximation error within 2e-5 + 1e-2 relative of the oracle's."""
     import math
 
     import oracle
@@ -99,10 +99,12 @@ def decaying_parity(inp, out, item):
         Rm = c.double().reshape(c.shape[0], -1)
         orth = max(orth, (Rm @ Rm.T - torch.eye(Rm.shape[0], dtype=torch.float64)).abs().max().item())
     ranks_ok = oracle.tt_ranks(ours) == oracle.tt_ranks(ref)
-    ok = ranks_ok and sv <= 4e-6 and orth <= 5e-5 and abs(e_o - e_r) <= 4e-6 + 1e-2 * e_r
+    # (approximation error: the fp32 bound of the headline's parity check -- 2e-5 through TT inner products at the metric size,
+    # seven truncations in fp32 -- on top of the oracle's own error)
+    ok = ranks_ok and sv <= 4e-6 and orth <= 5e-5 and abs(e_o - e_r) <= 2e-5 + 1e-2 * e_r
     return {"item": item, "ranks_identical": ranks_ok, "bond_sv_max_abs_diff_rel_sigma_max": sv, "right_orthonormality_defect": orth,
             "approx_err_ours": e_o, "approx_err_oracle_f64": e_r,
-            "bounds": {"bond_sv": 4e-6, "orth": 5e-5, "approx_err_abs_diff": "4e-6 + 1e-2 * oracle"}, "ok": bool(ok)}
+            "bounds": {"bond_sv": 4e-6, "orth": 5e-5, "approx_err_abs_diff": "2e-5 + 1e-2 * oracle"}, "ok": bool(ok)}
 
 
 def kernel_model():

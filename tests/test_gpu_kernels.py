@@ -650,6 +650,39 @@ def test_orth_fixup(dt, columns):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("r,n,first", [(32, 2048, 17), (64, 4096, 1), (30, 777, 29), (7, 50, 0), (70, 500, 40)])
+def test_orth_fixup_many_dead(dt, r, n, first):
+    """Most of the kept vectors below the resolution (a rank-64 bond with sigma_j ~ 2^-j: SURVEY 8d's decaying variant of the
+    metric): the block kernel (r <= 64; Gram matrix + Gram-Schmidt in coefficient space) and the sequential one (r = 70) leave
+    every vector orthonormal, the live ones bit-identical, and the dead ones inside span(their own old value, earlier vectors)
+    where that remainder was genuine."""
+    h = _hip()
+    g = torch.Generator().manual_seed(r * 1000 + n)
+    B = 3
+    Q = torch.linalg.qr(torch.randn(B, n, r, generator=g, dtype=torch.float64))[0].transpose(1, 2).contiguous()  # [B, r, n]
+    sig = torch.linspace(1.0, 0.25, r, dtype=torch.float64).repeat(B, 1)
+    sig[:, first:] = 1e-12 * torch.rand(B, r - first, generator=g, dtype=torch.float64) if first > 0 else 0.0   # (sigma_0 = 0: all dead)
+    X = Q.clone()
+    noise = torch.randn(B, r - first, n, generator=g, dtype=torch.float64)
+    X[:, first:] = 0.5 * X[:, first:] + 0.1 * noise + (0.3 * X[:, :1] if first > 0 else 0.0)   # noisy, not orthogonal, not unit
+    X[1, r - 1] = 0.0                                                                            # one exactly-zero dead vector
+    Xd = X.to(dt).cuda()
+    before = Xd.clone()
+    h.orth_fixup(Xd, sig.to(dt).cuda(), r, 1e-6)
+    out = Xd.cpu().double()
+    eye = torch.eye(r, dtype=torch.float64)
+    for b in range(B):
+        assert (out[b] @ out[b].T - eye).abs().max() < tol(dt, 2e-6, 1e-13), b
+    assert torch.equal(Xd[:, :first], before[:, :first])
+    # genuine remainders are kept: dead vector `first` of item 0 is its old value minus the projection on the earlier vectors
+    old = X[0, first].to(dt).double()
+    prev = out[0, :first]
+    rem = old - prev.T @ (prev @ old)
+    rem = rem / rem.norm()
+    assert (out[0, first] - rem).abs().max() < tol(dt, 5e-6, 1e-12)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("rows,n,B", [(4096, 64, 2), (100000, 32, 1), (1000, 37, 3), (33, 5, 2), (7, 1, 1), (300000, 64, 1), (64, 64, 40)])
 def test_colsweep_gram_project(dt, rows, n, B):
     """ttr_colgram / ttr_colproject (tall matrices, contraction over the rows) against float64 torch."""

@@ -283,6 +283,231 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_kernel(int r, int64_t n, 
   }
 }
 
+// Block variant of the kernel above for r <= 64 vectors (every bond of the rounding sweeps): the sequential modified
+// Gram-Schmidt of the kernel above walks the whole vector two times per (dead vector, earlier vector) pair with a block
+// reduction each -- 51 ms per metric step on a decaying-spectrum batch whose kept directions 17 .. 31 of every bond lie below
+// the resolution (SURVEY 8d's second input variant, measured).  Here one ROUND is: the Gram matrix S = X X^T of all r vectors
+// (one pass, column chunks through LDS, products and sums in double), Gram-Schmidt of the dead
+// rows IN COEFFICIENT SPACE against everything before them (r x r matrices in LDS, double; the live rows are orthonormal
+// already and stay untouched), then X_dead <- W X in a second pass.  A dead vector whose remainder collapses (below 1 % of its
+// norm, or a zero / non-finite vector) is replaced by a hashed pseudo-random one, which the next round orthogonalises.  Two
+// rounds ("twice is enough": the second sees a Gram matrix within rounding of the identity), a third / fourth only after a
+// replacement.  Same semantics as the kernel above: genuine remainders are kept, live vectors are not touched.
+constexpr int kOfMaxE = 32;        // tile elements per thread: r x CW <= 32 x 256 (CW = 256 up to 32 vectors, 128 above)
+
+inline size_t orth_fixup_lds_bytes(int r, int cw, size_t es) {
+  const int r4 = (r + 15) & ~15;   // whole 16 x 16 MFMA tiles
+  return (size_t)r4 * (cw + 4) * es + 2 * (size_t)r4 * (r4 + 1) * 8 + 2 * 64 * 8 + 64 * 4 + 16;
+}
+
+// kOfCW: columns per chunk (a chunk = one global round trip + two barriers: 64 columns left the kernel latency-bound on
+// them); kOfLd: tile row stride
+template <typename T, int kOfCW>
+__global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t es,
+                                                                    int64_t strideX, const T* __restrict__ sigma,
+                                                                    int64_t stride_sigma, double dead_rel,
+                                                                    const int32_t* __restrict__ rank_dev) {
+  constexpr int kOfLd = kOfCW + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char of_smem[];
+  const int r_launch = r;
+  const int64_t b = blockIdx.x;
+  if (rank_dev) r = rank_dev[b] < r ? rank_dev[b] : r;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const double s0 = (double)sg[0];
+  int first = r;
+  for (int i = 0; i < r; ++i)
+    if (!((double)sg[i] > dead_rel * s0)) { first = i; break; }  // (also catches NaN / zero sigma_0)
+  if (first >= r) return;
+  // carve the dynamic LDS (sized for the launch's r, rounded up to whole 16 x 16 MFMA tiles)
+  const int r4 = (r_launch + 15) & ~15;
+  const int ls = r4 + 1;                                   // row stride of S / W
+  double* S = reinterpret_cast<double*>(of_smem);          // [r4][ls]
+  double* W = S + (size_t)r4 * ls;
+  double* tv = W + (size_t)r4 * ls;                        // [64]
+  double* pj = tv + 64;
+  int* regen = reinterpret_cast<int*>(pj + 64);            // [64]
+  int* any_regen = regen + 64;
+  T* tile = reinterpret_cast<T*>(any_regen + 4);           // [r4][kOfLd]
+  T* __restrict__ Xb = X + b * strideX;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nt = (r + 15) >> 4;              // 16-row tiles that hold vectors
+  const bool vec_contig = es == 1;           // vectors are rows of a row-major matrix (else: columns, es = row stride)
+  const int ne = (r * kOfCW + kThreads - 1) / kThreads;    // tile elements per thread (<= kOfMaxE)
+  // rows of the tile beyond r are read by the 16 x 16 MFMA tiles: keep them zero
+  for (int idx = r * kOfLd + tid; idx < r4 * kOfLd; idx += kThreads) tile[idx] = T(0);
+
+  // chunk c0 .. c0 + 63 of all r vectors: global -> registers (issued one chunk ahead), registers -> LDS
+  auto fetch = [&](int64_t c0, T* reg) {
+    const int cw = (int)((n - c0) < kOfCW ? (n - c0) : kOfCW);
+#pragma unroll
+    for (int e = 0; e < kOfMaxE; ++e) {
+      if (e >= ne) break;
+      const int idx = tid + e * kThreads;
+      int i, c;
+      if (vec_contig) { i = idx / kOfCW; c = idx - i * kOfCW; } else { c = idx / r; i = idx - c * r; }
+      reg[e] = (i < r && c < cw) ? Xb[(int64_t)i * vs + (c0 + c) * es] : T(0);
+    }
+  };
+  auto stage = [&](const T* reg) {
+#pragma unroll
+    for (int e = 0; e < kOfMaxE; ++e) {
+      if (e >= ne) break;
+      const int idx = tid + e * kThreads;
+      int i, c;
+      if (vec_contig) { i = idx / kOfCW; c = idx - i * kOfCW; } else { c = idx / r; i = idx - c * r; }
+      if (i < r && c < kOfCW) {
+        const T v = reg[e];
+        tile[i * kOfLd + c] = (v - v == T(0)) ? v : T(0);   // (non-finite entries of a dead vector count as zero: 0 x NaN would poison the products)
+      }
+    }
+  };
+
+  for (int round = 0; round < 4; ++round) {
+    // ---- S = X X^T on the matrix cores: wave w owns the 16-row tile w of S (all column tiles); fp32 accumulators are
+    // flushed into double sums after every chunk (64 products per entry), fp64 accumulates in place
+    double sacc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sacc[u][v] = 0.0;
+    T reg[kOfMaxE];
+    fetch(0, reg);
+    for (int64_t c0 = 0; c0 < n; c0 += kOfCW) {
+      __syncthreads();
+      stage(reg);
+      __syncthreads();
+      if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);   // the next chunk's loads fly under this chunk's products
+      if (wv < nt) {
+        typename Mfma<T>::Acc acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = Mfma<T>::zero();
+        const T* __restrict__ arow = tile + (16 * wv + (lane & 15)) * kOfLd + (lane >> 4);
+#pragma unroll 4
+        for (int k0 = 0; k0 < kOfCW; k0 += 4) {
+          const T a = arow[k0];
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (v < nt) acc[v] = Mfma<T>::mma(a, tile[(16 * v + (lane & 15)) * kOfLd + k0 + (lane >> 4)], acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[v][u] += (double)acc[v][u];
+      }
+    }
+    __syncthreads();
+    if (wv < nt) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (v < nt) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) S[(16 * wv + Mfma<T>::row(lane, u)) * ls + 16 * v + (lane & 15)] = sacc[v][u];
+        }
+    }
+    if (tid < 64) regen[tid] = 0;
+    if (tid == 0) any_regen[0] = 0;
+    __syncthreads();
+    // ---- the dead rows against everything before them, in coefficient space (double).  The live rows are orthonormal
+    // (S_LL = I to rounding), so the remainders x_d - S_dL x_L have the Gram matrix C = S_DD - S_DL S_LD; with C = L L^T
+    // (Cholesky) the rows of  L^-1 [-S_DL, I]  are the coefficients of the orthonormalised dead vectors.  A pivot below 1e-4
+    // of the vector's own squared norm (or a zero vector) = the remainder collapsed: that row is replaced.
+    const int nd = r - first;
+    double* Cm = W;                                      // nd x nd, stride ls
+    for (int idx = tid; idx < nd * nd; idx += kThreads) {
+      const int ia = idx / nd, ib = idx - ia * nd;
+      const double* __restrict__ sa = S + (size_t)(first + ia) * ls;
+      const double* __restrict__ sb = S + (size_t)(first + ib) * ls;
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+      int k = 0;
+      for (; k + 3 < first; k += 4) { c0 += sa[k] * sb[k]; c1 += sa[k + 1] * sb[k + 1]; c2 += sa[k + 2] * sb[k + 2]; c3 += sa[k + 3] * sb[k + 3]; }
+      for (; k < first; ++k) c0 += sa[k] * sb[k];
+      Cm[ia * ls + ib] = sa[first + ib] - ((c0 + c1) + (c2 + c3));
+    }
+    __syncthreads();
+    for (int a = 0; a < nd; ++a) {                       // right-looking Cholesky, lower triangle in place
+      const double piv = Cm[a * ls + a], saa = S[(first + a) * ls + first + a];
+      const bool bad = !(saa > 0.0) || !(saa < 1e300) || !(piv > 1e-4 * saa);
+      const double dinv = bad ? 0.0 : 1.0 / sqrt(piv);
+      __syncthreads();                                   // (everybody has read the pivot)
+      if (tid > a && tid < nd) Cm[tid * ls + a] *= dinv; // (collapsed: the column is removed)
+      if (tid == a) Cm[a * ls + a] = bad ? 1.0 : piv * dinv;
+      if (tid == 0 && bad) { regen[first + a] = 1; any_regen[0] = 1; }
+      __syncthreads();
+      if (!bad) {
+        const int rem = nd - a - 1;
+        for (int idx = tid; idx < rem * rem; idx += kThreads) {
+          const int i = a + 1 + idx / rem, j = a + 1 + idx % rem;
+          if (j <= i) Cm[i * ls + j] -= Cm[i * ls + a] * Cm[j * ls + a];
+        }
+      }
+      __syncthreads();
+    }
+    // Z = [-S_DL, I] in place over the dead rows of S, then the forward substitution L W_D = Z row by row (S is not needed any more)
+    for (int idx = tid; idx < nd * r4; idx += kThreads) {
+      const int ia = idx / r4, k = idx - ia * r4;
+      double* __restrict__ zr = S + (size_t)(first + ia) * ls;
+      zr[k] = k < first ? -zr[k] : (k == first + ia ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int a = 0; a < nd; ++a) {
+      if (tid < r4) {
+        double* __restrict__ za = S + (size_t)(first + a) * ls;
+        double w = 0.0;
+        if (!regen[first + a]) {
+          double w0 = za[tid], w1 = 0.0, w2 = 0.0, w3 = 0.0;
+          const double* __restrict__ la = Cm + (size_t)a * ls;
+          int bq = 0;
+          for (; bq + 3 < a; bq += 4) {
+            w0 -= la[bq] * S[(size_t)(first + bq) * ls + tid];
+            w1 -= la[bq + 1] * S[(size_t)(first + bq + 1) * ls + tid];
+            w2 -= la[bq + 2] * S[(size_t)(first + bq + 2) * ls + tid];
+            w3 -= la[bq + 3] * S[(size_t)(first + bq + 3) * ls + tid];
+          }
+          for (; bq < a; ++bq) w0 -= la[bq] * S[(size_t)(first + bq) * ls + tid];
+          w = ((w0 + w1) + (w2 + w3)) / la[a];
+        }
+        za[tid] = w;
+      }
+      __syncthreads();
+    }
+    // ---- X_dead <- W X  (regenerated rows: hashed pseudo-random values, orthogonalised by the next round)
+    fetch(0, reg);
+    for (int64_t c0 = 0; c0 < n; c0 += kOfCW) {
+      const int cw = (int)((n - c0) < kOfCW ? (n - c0) : kOfCW);
+      __syncthreads();
+      stage(reg);
+      __syncthreads();
+      if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);
+      // wave w: the 16-column blocks w, w + 4, .. of the chunk, every 16-row tile that holds dead rows; W (double in LDS) is the A
+      // operand in the matrix precision -- the second round sees W = I + O(first round's error), which restores full accuracy
+      for (int cb = wv; cb < kOfCW / 16; cb += 4)
+      for (int it = first >> 4; it < nt; ++it) {
+        typename Mfma<T>::Acc acc = Mfma<T>::zero();
+        const double* __restrict__ wrow = S + (size_t)(16 * it + (lane & 15)) * ls + (lane >> 4);   // (the dead rows of S hold W_D now)
+        const T* __restrict__ bcol = tile + (lane >> 4) * kOfLd + 16 * cb + (lane & 15);
+        for (int k0 = 0; k0 < 16 * nt; k0 += 4) acc = Mfma<T>::mma((T)wrow[k0], bcol[k0 * kOfLd], acc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = 16 * it + Mfma<T>::row(lane, u), c = 16 * cb + (lane & 15);
+          if (d < first || d >= r || c >= cw) continue;
+          T out = acc[u];
+          if (regen[d]) {
+            const int64_t k = c0 + c;
+            uint32_t h = (uint32_t)(k * 2654435761u) ^ (uint32_t)((d + 1) * 40503u) ^ (uint32_t)((round + 1) * 97u);
+            h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+            out = (T)((double)(h >> 8) * (1.0 / 8388608.0) - 1.0);
+          }
+          Xb[(int64_t)d * vs + (c0 + c) * es] = out;
+        }
+      }
+    }
+    __syncthreads();
+    if (round >= 1 && !any_regen[0]) break;
+    __syncthreads();
+  }
+}
+
 // implemented in the other translation units
 int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
@@ -857,7 +1082,20 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
   TTR_REQUIRE(X && sigma, TTR_E_INVALID, "ttr_orth_fixup: null pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(TTR_PROF_MISC, s);
-  if (dtype == TTR_F32)
+  if (r <= 64) {  // the block variant (Gram matrix + coefficient-space Gram-Schmidt + one small product per round)
+    const int cw = r <= 32 ? 256 : 128;
+    const size_t lds = orth_fixup_lds_bytes((int)r, cw, dtype == TTR_F32 ? 4 : 8);
+#define TTR_OF_LAUNCH(T_, CW_)                                                                                                  \
+    do {                                                                                                                          \
+      auto kern = orth_fixup_block_kernel<T_, CW_>;                                                                               \
+      if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, n, (T_*)X, vec_stride, elem_stride, strideX, \
+                         (const T_*)sigma, stride_sigma, dead_rel, rank_dev);                                                      \
+    } while (0)
+    if (dtype == TTR_F32) { if (cw == 256) TTR_OF_LAUNCH(float, 256); else TTR_OF_LAUNCH(float, 128); }
+    else { if (cw == 256) TTR_OF_LAUNCH(double, 256); else TTR_OF_LAUNCH(double, 128); }
+#undef TTR_OF_LAUNCH
+  } else if (dtype == TTR_F32)
     hipLaunchKernelGGL(orth_fixup_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (float*)X,
                        vec_stride, elem_stride, strideX, (const float*)sigma, stride_sigma, dead_rel, rank_dev);
   else

@@ -194,12 +194,17 @@ struct Num<float> {
   static __device__ __forceinline__ float eps() { return 1.1920929e-07f; }
   static __device__ __forceinline__ float tiny() { return 1.17549435e-38f; }
   static __device__ __forceinline__ float big_theta() { return 1e18f; }
+  // Householder: a sub-column whose squared norm lies below 2^-100 of a block factored at the exponent of its largest entry is
+  // treated as zero (H = I): 2^-50 of the block, far below eps -- and the hardware sqrt / rcp flush denormal arguments
+  // (alpha^2 + ss ~ 1e-39 gave beta = 0, tau = inf: a rank-64 bond with sigma_j ~ 2^-j, SURVEY 8d's decaying variant)
+  static __device__ __forceinline__ float larfg_floor() { return 7.8886091e-31f; }
 };
 template <>
 struct Num<double> {
   static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
   static __device__ __forceinline__ double tiny() { return 2.2250738585072014e-308; }
   static __device__ __forceinline__ double big_theta() { return 1e150; }
+  static __device__ __forceinline__ double larfg_floor() { return 1e-290; }
 };
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             wave_sum2(s00, s01);
             const T alpha0 = lane_get(pcv[0][0].x, jj);
             T beta0, sc0;
-            if (s00 == T(0)) { beta0 = alpha0; t0 = T(0); sc0 = T(0); }  // LAPACK larfg: H = I
+            if (s00 < Num<T>::larfg_floor()) { beta0 = alpha0; t0 = T(0); sc0 = T(0); }  // LAPACK larfg: H = I (x = 0, or below 2^-50 of the block)
             else larfg_scalars(alpha0, s00, beta0, t0, sc0);
 #pragma unroll
             for (int h = 0; h < NH; ++h) v0[h] = x0[h] * sc0;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
               wave_sum2(s11, s0v);
               const T alpha1 = lane_get(pcv[1][0].x, jj1);
               T beta1, sc1;
-              if (s11 == T(0)) { beta1 = alpha1; t1 = T(0); sc1 = T(0); }
+              if (s11 < Num<T>::larfg_floor()) { beta1 = alpha1; t1 = T(0); sc1 = T(0); }
               else larfg_scalars(alpha1, s11, beta1, t1, sc1);
 #pragma unroll
               for (int h = 0; h < NH; ++h) v1[h] = x1[h] * sc1;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
               const T ss = d4[oc];
               const T alpha = lane_get(pc[oc][0], jj);
               T beta, tj, scale;
-              if (ss == T(0)) {  // LAPACK larfg: H = I
+              if (ss < Num<T>::larfg_floor()) {  // LAPACK larfg: H = I (x = 0, or below 2^-50 of the block)
                 beta = alpha; tj = T(0); scale = T(0);
               } else {
                 larfg_scalars(alpha, ss, beta, tj, scale);
