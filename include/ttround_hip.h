@@ -481,7 +481,8 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
 #define TTR_KNOB_QR_STAMP_BY 4
 /*   TTR_KNOB_QR_F64_NW4  1 = fp64 TSQR trees consist of 256-row (4-wave) blocks only -- two blocks per CU; 0 (default) = the
  *                      512-row (8-wave) blocks of the fp32 path (132 KB of LDS in fp64: one block per CU; measured 17 %
- *                      faster on config C2 all the same).  Set it BEFORE any workspace is sized (an A/B switch). */
+ *                      faster on config C2 all the same).  Bit 1 (value 2 / 3): the same for fp32 (round 4's A/B on the metric
+ *                      workload).  Set it BEFORE any workspace is sized (an A/B switch). */
 #define TTR_KNOB_QR_F64_NW4 5
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);

@@ -266,7 +266,7 @@ def test_host_cp_als_golden():
         assert abs(tn.relative_error(g["inp"], t).item() - runs[name]["relerr"]) < 1e-10
     # CP factors behave as TT cores with diagonal slices everywhere else (tensor.py:1717-1769)
     ref = oracle.cp_to_dense(g["r5_it4"])
-    assert (t.torch() - ref).norm() / ref.norm() < 1e-10   # (0 on most runs; 2.2e-13 seen once in ~30: see above)
+    assert (t.torch() - ref).norm() / ref.norm() < 2e-12   # (0 on most runs; 2.2e-13 seen once in ~30: a bound ~10x the observed noise)
     assert t.ranks_tt.tolist() == [5, 5, 5, 5, 5]
     u = t.clone()
     u.round_tt(eps=1e-10)

@@ -660,7 +660,12 @@ def bj_sweeps(G: torch.Tensor, V: torch.Tensor, b: int, relative: bool, tol: flo
     scratch = torch.empty(max(int(L.ttr_bj_scratch_bytes(dt, b, npairs, Bt)), 16), dtype=torch.uint8, device=G.device)
     st = _stream()
     rounds = nbk - 1
-    for _ in range(max_sweeps):
+    tranche = 8   # sweeps enqueued before the convergence word is looked at (one readback: control flow only).  Convergence
+                  # typically comes after 6 .. 10 sweeps; the launches of the remaining sweeps of max_sweeps would return at their
+                  # first instruction, but each still costs a launch (n = 1024, b = 32: 63 launches per sweep)
+    for sweep in range(max_sweeps):
+        if sweep > 0 and sweep % tranche == 0 and int(ctrl[0].item()) != 0:
+            break
         for r in range(rounds):
             tab = tabs[r].data_ptr()
             _check(L.ttr_bj_solve(dt, b, npairs, Bt, G.data_ptr(), n, n * n, tab, W.data_ptr(), scratch.data_ptr(),

@@ -107,7 +107,9 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
                 eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(), scale=perturb)
                 _hip.gemm_axpby(noise, eye, W, delta, 1.0)         # W += delta * noise (zero items: += 0; rank-keeping items: untouched)
             else:
-                cn = torch.diagonal(_hip.gemm(W0, W0, transA=True), dim1=1, dim2=2).clamp_min(0).sqrt()  # column norms [Bt, w]
+                # column norms [Bt, w]: ttr_norm over the columns of the panel (a transposed layout copy of m x w elements; round 3
+                # formed the whole w x w Gram matrix on the matrix cores for its diagonal)
+                cn = _hip.norm(W0.transpose(1, 2).reshape(Bt * w, m)).reshape(Bt, w)
             if j0 == 0:
                 Qj, Rjj = _hip.qr(W)
                 d = torch.diagonal(Rjj, dim1=1, dim2=2)
@@ -130,8 +132,17 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         return Q, R, collapsed
 
     Q, R, collapsed = factor(None)
-    if bool(collapsed.any().item()):  # (readback: control flow only)
-        Q, R, _ = factor(live * collapsed.to(A.dtype))
+    bad = torch.nonzero(collapsed).flatten()           # (readback of the item list: control flow only)
+    if bad.numel() == Bt:
+        Q, R, _ = factor(live)
+    elif bad.numel() > 0:
+        # only the collapsing items are factored again (gather / scatter of those items: layout copies)
+        A_all, live_all = A, live
+        A, live, Bt = A_all.index_select(0, bad).contiguous(), live_all.index_select(0, bad), int(bad.numel())
+        Qb, Rb, _ = factor(live)
+        A, live, Bt = A_all, live_all, A_all.shape[0]
+        Q.index_copy_(0, bad, Qb)
+        R.index_copy_(0, bad, Rb)
     return Q, _hip.scale_batch(R, expo=a_exp, expo_sign=+1)
 
 
@@ -545,9 +556,10 @@ def truncate(
                 # instead of the QL iteration over the whole spectrum, decided per item inside the launch (flat kept spectrum
                 # without close pairs; the others fall through to the QL phase).  Such items carry zeros beyond column / entry
                 # rmax, which nothing below looks at in batch mode.
-                V1, sig1, _, _ = _hip.eigh_top(G, _rank_cap(rmax, k), FLAT_SPECTRUM_THR)
+                V1, sig1, _, top_flat = _hip.eigh_top(G, _rank_cap(rmax, k), FLAT_SPECTRUM_THR)
             else:
                 V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
+                top_flat = None
             flat = None
             if FLAT_SPECTRUM_THR > 0:
                 # items whose KEPT singular values lie within a factor 8 of each other do not need the second pass (the first
@@ -557,6 +569,10 @@ def truncate(
                 # evaluated on pass 1's sigma and the item only qualifies when pass 2 provably selects the same rank (fp64
                 # trains: config C2; in fp32 the error margin of pass 1's tail energies exceeds a delta of 1e-4 ||T||).
                 flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, use_delta, delta2, delta2_dev)
+                if top_flat is not None:
+                    # an item the top-r kernel decided on eigenvalues carries ONLY its r leading eigenpairs: it must pass through,
+                    # also when the same test on sigma = sqrt(lambda) rounds to the other side of the threshold ([B] int32 flags)
+                    flat = torch.maximum(flat, top_flat)
             V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev,
                                            skip_items=flat, sigma_in=sig1 if flat is not None else None)
@@ -1427,8 +1443,18 @@ def cp_hosvd_init(X: torch.Tensor, R: int) -> List[torch.Tensor]:
         else:
             A = (X if n == 0 else X.movedim(n, 0).contiguous()).reshape(1, I, -1)
             G = _hip.gemm(A, A, transB=True)
-        V, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, I, _hip.SOLVER_TRIDIAG)  # columns by decreasing eigenvalue
-        c = V[0][:, :R].contiguous()
+        c = None
+        if EIGH_TOPK_ENABLED and 64 < I <= _hip.lib().ttr_eigsel_max_n() and R <= 64 and 4 * R <= I:
+            # only the R leading eigenvectors are looked at (tensor.py:262): selected eigenpairs (tridiagonalisation, multisection,
+            # twisted factorisations) instead of the full block-Jacobi decomposition -- C4: four 256 x 256 problems, 114 -> ~35 ms of
+            # init.  Vectors of a cluster the solver cannot separate (min |R_jj| of its orthonormalisation <= 0.5): the full solver.
+            Gn, _ = _hip.pow2_normalize(G)
+            Xk, _, rmin = _hip.eigh_topk(Gn, R)
+            if float(rmin[0].item()) > 0.5:   # (readback: control flow only)
+                c = Xk[0].contiguous()
+        if c is None:
+            V, _, _ = _eigh_any(G, _hip.EIG_RAW, False, 0.0, I, _hip.SOLVER_TRIDIAG)  # columns by decreasing eigenvalue
+            c = V[0][:, :R].contiguous()
         if c.shape[1] < R:  # complete with random entries (tensor.py:262-277)
             c = torch.cat((c, torch.randn(I, R - c.shape[1], dtype=c.dtype, device=c.device)), dim=1)
         cores.append(c)

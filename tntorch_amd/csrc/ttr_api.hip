@@ -1145,7 +1145,7 @@ int ttr_debug_set_knob(int knob, int value) {
       g_qr_dbg_by = value;
       return TTR_OK;
     case TTR_KNOB_QR_F64_NW4:
-      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: fp64 block switch %d outside [0, 1]", value);
+      TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: 4-wave block switch %d outside [0, 3]", value);
       g_qr_f64_nw4 = value;
       return TTR_OK;
     case TTR_KNOB_GEMM_BIG:

@@ -1096,7 +1096,9 @@ int g_qr_f64_nw4 = 0;  // ttr_debug_set_knob(TTR_KNOB_QR_F64_NW4): fp64 trees ou
 // blocks would fit (75 KB, 2 waves per SIMD).  Measured on config C2's resident batch (tools/c2_ab.py): 256 trains in
 // 40.9 ms with the 4-wave blocks against 34.0 ms with the 8-wave blocks (qr_factor 37.1 vs 25.5 ms) -- the pair phases of
 // the 8-wave block and the shallower tree outweigh the second chain per CU.  Kept as a switch, off.
-static int nw_for(int64_t rows, bool f64) { return (rows > BR4 && !(f64 && g_qr_f64_nw4)) ? 8 : 4; }
+// (bit 1 of the switch: the same for fp32 -- round 4's A/B of "256-row leaves x 4 waves, four blocks per CU" on the metric)
+static bool nw4_forced(bool f64) { return f64 ? (g_qr_f64_nw4 & 1) != 0 : (g_qr_f64_nw4 & 2) != 0; }
+static int nw_for(int64_t rows, bool f64) { return (rows > BR4 && !nw4_forced(f64)) ? 8 : 4; }
 
 static QrPlan make_plan(int64_t m, int64_t n, int64_t batch, bool f64) {
   QrPlan pl{};
@@ -1320,7 +1322,7 @@ int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, 
 // zero-padded blocks of 64*NW rows (one mode index per wave), so the plan is that of a (64*NW*ceil(I/NW)) x n
 // matrix -- NW = 8 as soon as there are more than four mode indices (consistent with nw_for; fp64: 4-wave blocks, see there).
 static int64_t pushed_rows(int64_t I, int dtype) {
-  if (dtype == TTR_F64 && g_qr_f64_nw4) return 256 * ceil_div(I, 4);
+  if (nw4_forced(dtype == TTR_F64)) return 256 * ceil_div(I, 4);
   return I > 4 ? 512 * ceil_div(I, 8) : 256;
 }
 
