@@ -1474,7 +1474,7 @@ def test_cp_hosvd_init_selected_eigenpairs():
     from tntorch_amd import _hip, _hipops
     torch.manual_seed(23)
     shape, R = [160, 24, 160], 8
-    fac = [torch.randn(i, R, dtype=torch.float64) * (2.0 ** -torch.arange(R, dtype=torch.float64)) for i in shape]
+    fac = [torch.randn(i, R, dtype=torch.float64) * (2.0 ** (-torch.arange(R, dtype=torch.float64) / 3)) for i in shape]   # component weights 2^-j
     X = oracle.cp_to_dense(fac)
     X = (X / X.norm() + 1e-3 * torch.randn(shape, dtype=torch.float64) / math.sqrt(X.numel())).float()
     calls = []
@@ -1492,3 +1492,28 @@ def test_cp_hosvd_init_selected_eigenpairs():
         d = (a.T @ b).abs()                               # |cosines|: the identity up to sign for a separated spectrum
         assert (d - torch.eye(R, dtype=torch.float64)).abs().max() < 1e-2, d.diagonal()   # (fp32: eps lambda_1 / gap ~ 2e-3 for the smallest pair)
         assert (a.T @ a - torch.eye(R, dtype=torch.float64)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["randn", "lowrank"])
+def test_from_dense_consuming_matches_constructor(kind, monkeypatch):
+    """`Tensor.from_dense_consuming` (the first carry written in place over the consumed front of the input: BASELINE C1 at
+    64^6 has no room for a carry next to it) returns exactly what the constructor returns; the row ranges of the in-place
+    projection are forced small so that five launches chain (each writes into rows the previous ones consumed)."""
+    from tntorch_amd import _hipops
+    monkeypatch.setattr(_hipops, "_INPLACE_FIRST_ROWS", 1024)
+    torch.manual_seed(31)
+    shape, r = [64, 64, 32, 64], 16
+    if kind == "randn":
+        X = torch.randn(shape, dtype=torch.float32)
+    else:
+        low = oracle.tt_to_dense(oracle.tt_randn(shape, r, dtype=torch.float64))
+        X = (low / low.norm() * math.sqrt(low.numel()) + 1e-3 * torch.randn(shape, dtype=torch.float64)).float()
+    ref = tn.Tensor(X.cuda(), ranks_tt=r)
+    Xd = X.cuda()
+    t = tn.Tensor.from_dense_consuming(Xd, r)
+    assert list(t.ranks_tt) == list(ref.ranks_tt) == [1, 16, 16, 16, 1]
+    for a, b in zip(t.cores, ref.cores):
+        assert torch.equal(a, b)
+    assert not torch.equal(Xd.cpu(), X)      # (the input really was consumed)
+    with pytest.raises(ValueError):
+        tn.Tensor.from_dense_consuming(X, r)  # CPU tensors: the constructor is the way

@@ -835,8 +835,10 @@ def colgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[t
 
 @_on_device
 def colproject(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma: Optional[torch.Tensor], ro: int,
-               left_ortho: bool):
-    """left [batch, rows, ro] = M U [/ sigma], right [batch, ro, n] = [sigma] U^T with U = V1 V2[:, :ro] (ttr_colproject)."""
+               left_ortho: bool, left_out: Optional[torch.Tensor] = None):
+    """left [batch, rows, ro] = M U [/ sigma], right [batch, ro, n] = [sigma] U^T with U = V1 V2[:, :ro] (ttr_colproject).
+    ``left_out``: optional contiguous [batch, rows, ro] destination of ``left`` (may lie in M's own storage BELOW the rows this
+    call reads: the in-place first step of a config-scale dense TT-SVD, ``_hipops._colproject_inplace``)."""
     L = lib()
     dt = dtype_code(M.dtype)
     M, ldm, sM = _mat(M)
@@ -851,7 +853,11 @@ def colproject(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, si
     if V1 is not None:
         V1, ldv1, sV1 = _mat(V1)
         v1p = V1.data_ptr()
-    left = torch.empty((batch, rows, ro), dtype=M.dtype, device=M.device)
+    if left_out is not None:
+        assert tuple(left_out.shape) == (batch, rows, ro) and left_out.is_contiguous() and left_out.dtype == M.dtype
+        left = left_out
+    else:
+        left = torch.empty((batch, rows, ro), dtype=M.dtype, device=M.device)
     right = torch.empty((batch, ro, n), dtype=M.dtype, device=M.device)
     if batch == 0:
         return left, right

@@ -514,6 +514,7 @@ def truncate(
     gram: Optional[torch.Tensor] = None,
     delta2_dev: Optional[torch.Tensor] = None,
     want_trace: bool = False,
+    consume: bool = False,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
@@ -525,6 +526,9 @@ def truncate(
     from device memory, the factors are computed at the rank cap ``min(rmax, k)``, the selected rank stays on the device
     (``Truncation.info``) and the columns of ``left`` beyond it are zeroed there (``ttr_mask_cols``): the caller slices the
     cores once, at the end of its sweep, after ONE readback of all ranks.
+
+    ``consume`` (tall fused path, one contiguous matrix): M's storage may be overwritten -- ``left`` is produced in place over
+    its front (``_colproject_inplace``).
 
     ``want_trace``: also return ``Truncation.gtrace`` = trace of the first Gram matrix (the tall column sweep and the GEMM
     path: the shapes of a dense TT-SVD's first steps).
@@ -617,7 +621,10 @@ def truncate(
         if r == 0:
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
                               torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True, gtrace=gtr)
-        left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
+        if consume and Bt == 1 and M.is_contiguous() and 2 * r <= n:
+            left, right = _colproject_inplace(M, V1, V, sig, r, left_ortho)
+        else:
+            left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
         if algorithm == "svd" and left_ortho:
             _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
         return Truncation(left, None, right, r, info=info, gtrace=gtr)
@@ -723,6 +730,30 @@ def truncate(
         else:
             right = Vr.transpose(1, 2).contiguous()
     return Truncation(left, None, right, r, info=info, gtrace=gtr)
+
+
+_INPLACE_FIRST_ROWS = 1 << 22   # rows of the in-place projection that go through a bounded temporary (256 MB at 16 kept columns)
+
+
+def _colproject_inplace(M: torch.Tensor, V1, V, sig, r: int, left_ortho: bool):
+    """``_hip.colproject`` for ONE tall contiguous matrix [1, rows, n] whose storage may be consumed: ``left`` (rows x r, r <= n / 2)
+    is written over the FRONT of M's own storage -- output row i (r values at element offset i r) lies inside input row i r / n --
+    so a dense tensor that fills the GPU (BASELINE config C1 at its stated 64^6 = 256 GiB, whose 64 GiB carry does not fit next
+    to it) is decomposed without a second buffer.  Order: the rows are processed in ranges [a, b) with b <= a n / r (one launch
+    each; the range's output lands in input rows < a, which earlier launches have consumed -- the kernel boundary is the
+    ordering), the first range through a bounded temporary that is copied to the front last.  Returns (left view, right)."""
+    Bt, rows, n = M.shape
+    assert Bt == 1 and M.is_contiguous() and 2 * r <= n
+    flat = M.reshape(-1)
+    U = _hip.gemm(V1, V[:, :, :r]) if V1 is not None else V[:, :, :r].contiguous()
+    a = min(rows, _INPLACE_FIRST_ROWS)
+    first, right = _hip.colproject(M[:, :a], None, U, sig, r, left_ortho)
+    while a < rows:
+        b = min(rows, (a * n) // r)
+        _hip.colproject(M[:, a:b], None, U, sig, r, left_ortho, left_out=flat[a * r:b * r].view(1, b - a, r))
+        a = b
+    flat[:first.numel()].view(first.shape).copy_(first)
+    return flat[:rows * r].view(1, rows, r), right
 
 
 def _scale_batch(X: torch.Tensor, e: torch.Tensor, sign: int) -> torch.Tensor:
@@ -1301,8 +1332,11 @@ def dense_tt_svd(
     algorithm: str,
     batch: bool,
     _guard_scaled: Optional[torch.Tensor] = None,
+    consume_input: bool = False,
 ) -> List[torch.Tensor]:
     """Dense [B, I_1..I_N] -> TT cores [B, r, I, r'] by a right-to-left TT-SVD on the unfoldings.
+    ``consume_input`` (one tensor, fp32 in range / fp64): X's storage is overwritten by the first carry (see
+    ``_colproject_inplace``) -- for inputs that leave no room for a carry next to them.
 
     Equivalent to ``_full_rank_tt`` + ``round_tt(eps, rmax)`` of the reference
     (tensor.py:10-104, 401-408): after the full left orthogonalisation the right unfolding
@@ -1347,7 +1381,8 @@ def dense_tt_svd(
         Mk = C.reshape(Bt, -1, shape[kdim] * rn)
         first = lazy_guard and kdim == N - 1
         t = truncate(Mk, delta, rmax[kdim - 1], False, algorithm, batch, scratch_ok=kdim < N - 1, want_trace=first,
-                     gram=gram0 if kdim == N - 1 else None)  # C is our own carry
+                     gram=gram0 if kdim == N - 1 else None,  # C is our own carry
+                     consume=consume_input and kdim == N - 1 and e is None)
         if first:
             tr = t.gtrace
             bad = tr is None or bool(((~torch.isfinite(tr)) | (tr >= 2.0 ** 80) | ((tr > 0) & (tr <= 2.0 ** -80))).any().item())
@@ -1440,6 +1475,14 @@ def cp_hosvd_init(X: torch.Tensor, R: int) -> List[torch.Tensor]:
         if n == N - 1 and N > 1:
             A = X.reshape(1, -1, I)
             G = _hip.gemm(A, A, transA=True)
+        elif n == 1 and N > 2 and X.shape[0] * I * I * X.element_size() <= (1 << 28):
+            # second mode without the permuted copy: X = [P, I, Q] is P contiguous I x Q slabs, X_(1) X_(1)^T = sum_p X_p X_p^T --
+            # one batched symmetric product (P partial Gram matrices, <= 256 MB) and their sum as a GEMM with a ones vector
+            P = X.shape[0]
+            A = X.reshape(P, I, -1)
+            part = _hip.gemm(A, A, transB=True)                                   # [P, I, I]
+            ones = torch.ones((1, 1, P), dtype=X.dtype, device=X.device)
+            G = _hip.gemm(ones, part.reshape(1, P, I * I)).reshape(1, I, I)
         else:
             A = (X if n == 0 else X.movedim(n, 0).contiguous()).reshape(1, I, -1)
             G = _hip.gemm(A, A, transB=True)

@@ -162,6 +162,22 @@ class Tensor(object):
         ops = ops_for(X)
         return self._denorm(ops.dense_tt_svd(X, e, rmax, algorithm, self.batch))
 
+    @classmethod
+    def from_dense_consuming(cls, data: torch.Tensor, ranks_tt, algorithm: str = "svd") -> "Tensor":
+        """EXTENSION (not in the reference): ``Tensor(data, ranks_tt=..., algorithm=...)`` for ONE dense device tensor whose
+        storage may be OVERWRITTEN -- the first carry of the right-to-left TT-SVD (ranks_tt[-1] / I_N of the input) is written
+        over the front of ``data`` instead of next to it, so a tensor that fills the device (BASELINE config C1: 64^6 fp32 =
+        256 GiB of 288 GB) can be decomposed at all.  ``data`` holds garbage afterwards.  Same result as the constructor."""
+        from . import _hipops
+
+        if data.device.type != "cuda" or not data.is_contiguous() or data.dim() < 2:
+            raise ValueError("from_dense_consuming needs a contiguous dense device tensor with >= 2 modes")
+        N = data.dim()
+        rmax = list(ranks_tt) if hasattr(ranks_tt, "__len__") else [ranks_tt] * (N - 1)
+        assert len(rmax) == N - 1
+        cores = _hipops.dense_tt_svd(data[None], 1e-14, rmax, algorithm, False, consume_input=True)
+        return cls([c[0] for c in cores])
+
     def _from_dense_tucker(self, data: torch.Tensor, ranks_tucker, ranks_tt, algorithm):
         """tensor.py:401-408 with ``ranks_tucker`` (and optionally ``ranks_tt``)."""
         X = data if self.batch else data[None]

@@ -113,7 +113,7 @@ def _paths(fn):
     return [{"path": p, "m": m, "n": n, "cap": r} for p, m, n, r in tr]
 
 
-def _lowrank_plus_noise(shape, r, dev, gen, batch=None, noise=1e-3, split=None):
+def _lowrank_plus_noise(shape, r, dev, gen, batch=None, noise=1e-3, split=None, out=None):
     """SURVEY 8d's primary dense input: a TT-rank-r tensor of unit RMS + noise * randn, built on the device without a second
     tensor of its size: the product of the (modes < split) and (modes >= split) halves of a random rank-r train, written in
     row chunks, the noise added chunk by chunk.  `batch`: leading batch dimension (independent items)."""
@@ -137,7 +137,7 @@ def _lowrank_plus_noise(shape, r, dev, gen, batch=None, noise=1e-3, split=None):
     nrm2 = ((L.transpose(-1, -2) @ L) * (Rt @ Rt.transpose(-1, -2))).sum(dim=(-1, -2))
     L = L * (math.sqrt(math.prod(shape)) / nrm2.sqrt()).reshape(lead + (1, 1))
     rows, cols = L.shape[-2], Rt.shape[-1]
-    X = torch.empty(lead + (rows, cols), device=dev, dtype=torch.float32)
+    X = torch.empty(lead + (rows, cols), device=dev, dtype=torch.float32) if out is None else out.view(lead + (rows, cols))
     step = max(1, (1 << 28) // cols)
     for r0 in range(0, rows, step):
         blk = X[..., r0:r0 + step, :]
@@ -156,13 +156,19 @@ def _dense_tt_check(X, t, expect_err=None):
 
     cores = [c if c.dim() == 4 else c[None] for c in t.cores]          # [1, r, I, r']
     xx = tt = xt = d2 = 0.0
+    # pieces of <= 1 GiB: one index of the first mode x a group of indices of the second (the check has to fit next to an
+    # input that fills the device)
+    per = X[0].numel()
+    grp = X.shape[1] if per <= (1 << 28) else max(1, X.shape[1] // (per >> 28))
     for i in range(X.shape[0]):
-        Ti = _hipops.decompress([cores[0][:, :, i:i + 1, :].contiguous()] + cores[1:]).reshape(X[i].shape)
-        xi = X[i]
+      for j0 in range(0, X.shape[1], grp):
+        xi = X[i, j0:j0 + grp]
+        Ti = _hipops.decompress([cores[0][:, :, i:i + 1, :].contiguous(), cores[1][:, :, j0:j0 + grp, :].contiguous()]
+                                + cores[2:]).reshape(xi.shape)
         xx += float(_hip.norm(xi.reshape(1, -1))[0].item()) ** 2
         tt += float(_hip.norm(Ti.reshape(1, -1))[0].item()) ** 2
-        # <x, t> as 4096 partial dot products (batched 1 x n x 1 GEMMs), summed in double
-        xt += float(_hip.gemm(xi.reshape(4096, 1, -1), Ti.reshape(4096, -1, 1)).double().sum().item())
+        # <x, t> as 1024 partial dot products (batched 1 x n x 1 GEMMs), summed in double
+        xt += float(_hip.gemm(xi.reshape(1024, 1, -1), Ti.reshape(1024, -1, 1)).double().sum().item())
         d2 += float(_hipops.dense_dist(xi, Ti).item()) ** 2
         del Ti
     orth = 0.0
@@ -326,27 +332,68 @@ def c1(tn, dev, algorithm="svd", cpu=True, variant="randn", shape=None):
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     cands = [[64] * 6, [48] + [64] * 5, [32] + [64] * 5, [16] + [64] * 5, [64] * 5, [64] * 4]
-    shape = shape or next(sh for sh in cands if math.prod(sh) * 4 * 1.35 <= free)
-    gen = torch.Generator(device=dev).manual_seed(7)
-    if variant == "randn":
-        X = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
-    else:  # SURVEY 8d's primary C1 input: low-rank (TT rank 16, unit RMS) + 1e-3 randn
-        X = _lowrank_plus_noise(shape, 16, dev, gen)
-    sec, allt, out = _timeit(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm), reps=2, warmup=1)
+    nbytes = lambda sh: math.prod(sh) * 4
+    # a shape fits next to its carry (1.35 x), or -- round 4 -- alone, with the first carry written IN PLACE over the consumed
+    # front of the input (`Tensor.from_dense_consuming`: the input is destroyed, so every repetition regenerates it, untimed)
+    fits = lambda sh: nbytes(sh) * 1.35 <= free or nbytes(sh) + (9 << 30) <= free
+    shape = shape or next(sh for sh in cands if fits(sh))
+    consume = not nbytes(shape) * 1.35 <= free
+
+    def make(out=None):
+        gen = torch.Generator(device=dev).manual_seed(7)
+        if variant == "randn":
+            if out is None:
+                return torch.randn(shape, generator=gen, device=dev, dtype=torch.float32)
+            flat = out.view(-1)
+            for c0 in range(0, flat.numel(), 1 << 30):    # (chunks: identical values for a fresh and a refilled buffer)
+                flat[c0:c0 + (1 << 30)].normal_(generator=gen)
+            return out
+        # SURVEY 8d's primary C1 input: low-rank (TT rank 16, unit RMS) + 1e-3 randn
+        return _lowrank_plus_noise(shape, 16, dev, gen, out=out).view(shape)
+
+    X = make(torch.empty(shape, device=dev, dtype=torch.float32))
+
+    def run():
+        if consume:
+            return tn.Tensor.from_dense_consuming(X, 16, algorithm=algorithm)
+        return tn.Tensor(X, ranks_tt=16, algorithm=algorithm)
+
+    ts, out = [], None
+    for rep in range(3):                                   # one warm-up + two timed repetitions
+        if consume and rep > 0:
+            out = None
+            make(X)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    allt = sorted(ts[1:])
+    sec = allt[len(allt) // 2]
     ranks_out = out.ranks_tt.tolist()
     flop, byts, gram = _c1_model(shape)
     name = "x".join(map(str, shape))
+    if consume:
+        make(X)                                            # the same values again: the check needs the input the result came from
     check = _dense_tt_check(X, out, expect_err=None if variant == "randn" else 1e-3)
     del out
+
+    def again():
+        if consume:
+            make(X)
+        return run()
+
     res = {
         "input": variant if variant == "randn" else "TT rank 16 of unit RMS + 1e-3 randn",
         "oracle_check": dict(check, what="the TIMED result checked on the device: T is the orthogonal projection of X onto its "
                                         "right-orthonormal cores (<X,T> = ||T||^2, ||X-T||^2 = ||X||^2 - ||T||^2); the choice of the "
                                         "subspace against the oracle: tests/test_gpu_parity.py at 64^4"),
-        "big_bond_paths": _paths(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm)),
-        "kernel_ms": _kinds(lambda: tn.Tensor(X, ranks_tt=16, algorithm=algorithm)),
+        "in_place_first_carry": bool(consume),
+        "big_bond_paths": _paths(again),
+        "kernel_ms": _kinds(again),
         "workload": f"TT-SVD of a dense {name} fp32 tensor ({math.prod(shape) * 4 / 2 ** 30:.0f} GiB resident) to ranks_tt=16: the largest "
-                    "member of the C1 family that fits (64^6 = 256 GiB does not fit 288 GB together with its carry)",
+                    "member of the C1 family that fits" + (" -- with the first carry written in place over the consumed input "
+                                                            "(Tensor.from_dense_consuming)" if consume else ""),
         "dtype": "f32", "algorithm": algorithm, "shape": shape, "ranks": ranks_out,
         "ms": sec * 1e3, "ms_all": [round(x * 1e3, 1) for x in allt],
         # AI = flop / bytes ~ 60 > ridge 19.7: the n = 1024 Gram matrix of the second step binds (MFMA >= 301 ms, HBM >= 121 ms at 64^6)
