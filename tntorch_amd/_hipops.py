@@ -1475,22 +1475,14 @@ def cp_hosvd_init(X: torch.Tensor, R: int) -> List[torch.Tensor]:
         if n == N - 1 and N > 1:
             A = X.reshape(1, -1, I)
             G = _hip.gemm(A, A, transA=True)
-        elif n == 1 and N > 2 and X.shape[0] * I * I * X.element_size() <= (1 << 28):
-            # second mode without the permuted copy: X = [P, I, Q] is P contiguous I x Q slabs, X_(1) X_(1)^T = sum_p X_p X_p^T --
-            # one batched symmetric product (P partial Gram matrices, <= 256 MB) and their sum as a GEMM with a ones vector
-            P = X.shape[0]
-            A = X.reshape(P, I, -1)
-            part = _hip.gemm(A, A, transB=True)                                   # [P, I, I]
-            ones = torch.ones((1, 1, P), dtype=X.dtype, device=X.device)
-            G = _hip.gemm(ones, part.reshape(1, P, I * I)).reshape(1, I, I)
         else:
             A = (X if n == 0 else X.movedim(n, 0).contiguous()).reshape(1, I, -1)
             G = _hip.gemm(A, A, transB=True)
         c = None
         if EIGH_TOPK_ENABLED and 64 < I <= _hip.lib().ttr_eigsel_max_n() and R <= 64 and 4 * R <= I:
             # only the R leading eigenvectors are looked at (tensor.py:262): selected eigenpairs (tridiagonalisation, multisection,
-            # twisted factorisations) instead of the full block-Jacobi decomposition -- C4: four 256 x 256 problems, 114 -> ~35 ms of
-            # init.  Vectors of a cluster the solver cannot separate (min |R_jj| of its orthonormalisation <= 0.5): the full solver.
+            # twisted factorisations) instead of the full block-Jacobi decomposition -- C4: four 256 x 256 problems, 113 -> 79 ms of
+            # init, of which 58 ms are the four 2.2e12-flop Gram matrices at ~150 TF (fp32 MFMA peak 157.3) and 14 the two permuted copies.  Vectors of a cluster the solver cannot separate (min |R_jj| of its orthonormalisation <= 0.5): the full solver.
             Gn, _ = _hip.pow2_normalize(G)
             Xk, _, rmin = _hip.eigh_topk(Gn, R)
             if float(rmin[0].item()) > 0.5:   # (readback: control flow only)
