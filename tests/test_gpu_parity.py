@@ -1517,3 +1517,14 @@ def test_from_dense_consuming_matches_constructor(kind, monkeypatch):
     assert not torch.equal(Xd.cpu(), X)      # (the input really was consumed)
     with pytest.raises(ValueError):
         tn.Tensor.from_dense_consuming(X, r)  # CPU tensors: the constructor is the way
+
+
+def test_verbose_prints_the_reference_stage_lines_on_device(capsys):
+    t = gpu_tensor(oracle.tt_randn([16, 16, 16, 16], 8, dtype=torch.float32))
+    t.round_tt(rmax=3, verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert [ln.split(":")[0] for ln in out] == ["Orthogonalization time"] + ["Time (SVD)", "Time (product)"] * 3
+    t = gpu_tensor(oracle.tt_randn([16, 16, 16], 8, dtype=torch.float64))
+    t.round_tt(eps=1e-3, algorithm="eig", verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert [ln.split(":")[0] for ln in out] == ["Orthogonalization time"] + ["Time (gram)", "Time (symmetric EIG)", "Time (product)"] * 2

@@ -394,3 +394,20 @@ def test_ttmatrix_trace_sums_a_leading_rank():
     m.cores, m.batch = cores, False
     want = torch.einsum("iaaj,jbbk->ik", cores[0], cores[1]).sum(dim=0)[0]
     assert abs(float(m.trace()) - float(want)) <= 1e-12
+
+
+def test_verbose_prints_the_reference_stage_lines(capsys):
+    """`verbose=True` prints the reference's per-stage timing lines (tensor.py:2032-2035; round.py:95-117, 163-185)."""
+    t = tn.randn([6, 6, 6, 6], ranks_tt=5)
+    t.round_tt(rmax=3, verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("Orthogonalization time:")
+    assert [ln.split(":")[0] for ln in out[1:]] == ["Time (SVD)", "Time (product)"] * 3
+    t = tn.randn([6, 6, 6], ranks_tt=5)
+    t.round_tt(eps=1e-3, algorithm="eig", verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert [ln.split(":")[0] for ln in out] == ["Orthogonalization time"] + ["Time (gram)", "Time (symmetric EIG)", "Time (product)"] * 2
+    tn.truncated_svd(torch.randn(9, 12), rmax=2, verbose=True)
+    assert [ln.split(":")[0] for ln in capsys.readouterr().out.splitlines()] == ["Time (SVD)", "Time (product)"]
+    t.round_tt(rmax=2)
+    assert capsys.readouterr().out == ""

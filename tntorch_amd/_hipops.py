@@ -34,6 +34,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -41,6 +42,27 @@ import torch
 from . import _hip
 
 INT32_MAX = 2**31 - 1
+# set by the API layer around a call with verbose=True: the reference's per-stage timing lines (round.py:95-117, 163-185;
+# tensor.py:2032-2035).  Every stage boundary then synchronises the device (a diagnostic mode), and a batch runs on one stream.
+VERBOSE = False
+
+
+class _Stage:
+    """Stage timer of the verbose mode (no-op otherwise)."""
+
+    def __init__(self):
+        self.t = None
+        if VERBOSE:
+            torch.cuda.synchronize()
+            self.t = time.time()
+
+    def lap(self, label: str) -> None:
+        if self.t is not None:
+            torch.cuda.synchronize()
+            now = time.time()
+            print(label, now - self.t)
+            self.t = now
+
 
 
 def _rank_cap(rmax: Optional[int], k: int) -> int:
@@ -551,8 +573,11 @@ def truncate(
         # -> Gram of the ROTATED rows (ttr_rotgram: the rotated matrix only exists 16 columns at a time in registers)
         # -> Jacobi -> projection with U = V1 V2 formed in the kernel's prologue, which also emits left = U sigma.
         V1 = None
+        st = _Stage()
         G = gram if gram is not None else _hip.rowgram(M)
         gtr = _gram_trace(G) if want_trace else None
+        if algorithm == "eig":
+            st.lap("Time (gram):")
         if algorithm == "svd":
             if (batch and EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0 and rmax is not None and delta2_dev is None
                     and _hip.eigh_top_ok(k, _rank_cap(rmax, k))):
@@ -583,6 +608,7 @@ def truncate(
         else:
             V, sig, info = _hip.eigh_trunc(G, _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG, delta2_dev=delta2_dev)
+        st.lap("Time (SVD):" if algorithm == "svd" else "Time (symmetric EIG):")   # ('svd' here: both Gram passes + both solvers)
         if delta2_dev is not None:  # rank on the device: factors at the cap, the columns beyond info[b] zeroed in place
             r = _rank_cap(rmax, k)
             right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho)
@@ -598,6 +624,7 @@ def truncate(
         right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst)
         if algorithm == "svd" and not left_ortho:
             _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
+        st.lap("Time (product):")
         return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
     if not left_side and _hip.colsweep_fused_ok(M):
@@ -605,8 +632,11 @@ def truncate(
         # kernels with the contraction over the rows.  The unfolding is read three times ('eig': twice) and only the
         # carry (r / n of its size) is written -- no rotated copy of the input.
         V1 = None
+        st = _Stage()
         G0 = gram if gram is not None else _hip.colgram(M)
         gtr = _gram_trace(G0) if want_trace else None
+        if algorithm == "eig":
+            st.lap("Time (gram):")
         if algorithm == "svd":
             V1, sig1, _ = _hip.eigh_trunc(G0, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
             # (batch mode, or eps mode with the rank decision certified on pass 1's sigma: see the row sweep above)
@@ -617,6 +647,7 @@ def truncate(
         else:
             V, sig, info = _hip.eigh_trunc(G0, _hip.EIG_REF, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_TRIDIAG)
+        st.lap("Time (SVD):" if algorithm == "svd" else "Time (symmetric EIG):")
         r = _select_rank(info, batch, rmax, k)
         if r == 0:
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
@@ -627,9 +658,11 @@ def truncate(
             left, right = _hip.colproject(M, V1, V, sig, r, left_ortho)
         if algorithm == "svd" and left_ortho:
             _hip.orth_fixup(left, sig, r, k * torch.finfo(M.dtype).eps, columns=True)
+        st.lap("Time (product):")
         return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
     one_pass = None
+    st = _Stage()
     if algorithm == "svd":
         # ---- pass 1: rotate into (nearly) orthogonal rows / columns
         G = gram if gram is not None else (_hip.gemm(M, M, transB=True) if left_side else _hip.gemm(M, M, transA=True))
@@ -696,6 +729,7 @@ def truncate(
     # noise only; LAPACK's V is orthonormal there too (round.py:96), so they get an orthonormal completion
     # (ttr_orth_fixup; a per-item early exit when there are none -- the normal case)
     dead_rel = k * torch.finfo(M.dtype).eps if algorithm == "svd" else None
+    st.lap("Time (SVD):" if algorithm == "svd" else "Time (gram + symmetric EIG):")
     r = _select_rank(info, batch, rmax, k)
     if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)
         z_l = torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device)
@@ -713,6 +747,7 @@ def truncate(
             if dead_rel is not None:
                 _hip.orth_fixup(right, sig, r, dead_rel)
         U = _hip.gemm(V1, Vr) if V1 is not None else Vr
+        st.lap("Time (product):")
         return Truncation(U, None if left_ortho else sig, right, r, info=info, gtrace=gtr)
     # right side: left = Mw Vr (= U sigma); right = (V1 Vr)^T
     if left_ortho:
@@ -729,6 +764,7 @@ def truncate(
             right = _hip.gemm(Vr, V1, transA=True, transB=True)
         else:
             right = Vr.transpose(1, 2).contiguous()
+    st.lap("Time (product):")
     return Truncation(left, None, right, r, info=info, gtrace=gtr)
 
 
@@ -988,7 +1024,7 @@ _SIDE_STREAMS: dict = {}
 
 
 def _stream_chunks(Bt: int, batch: bool) -> int:
-    if not (batch and STREAM_CHUNKS_ENABLED):
+    if not (batch and STREAM_CHUNKS_ENABLED) or VERBOSE:
         return 1
     forced = os.environ.get("TTR_STREAM_CHUNKS")  # (experiments)
     if forced:
@@ -1119,6 +1155,7 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
     item of this sub-batch hit the zero guard); see ``round_tt``."""
     N = len(c)
     facs = []
+    st = _Stage()
     Rprev = None  # R factor still to be pushed into the current core
     expo = None   # fp32: accumulated binary exponent taken out of the R factors (per batch item)
     for mu in range(N - 1):  # L2R: tensor.py:1905-1906 (Q implicit, push fused into the next QR)
@@ -1164,6 +1201,7 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
     if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
         c[N - 1], _ = _hip.pow2_normalize(c[N - 1], expo_acc=expo)
+    st.lap("Orthogonalization time:")   # tensor.py:2032-2035 (here: the factorisations; Q stays implicit)
     d2dev, infos = None, []
     if batch:  # tensor.py:2036-2037
         delta = None

@@ -10,11 +10,13 @@ round-off.  It is selected ONLY for CPU tensors; device tensors never come here
 from __future__ import annotations
 
 import math
+import time
 from typing import List, Sequence, Tuple
 
 import torch
 
 INT32_MAX = 2**31 - 1
+VERBOSE = False   # set by the API layer around a call with verbose=True: the reference's per-stage timing lines (round.py:95-117, 163-185; tensor.py:2032-2035)
 
 
 def _t(M):
@@ -58,15 +60,23 @@ def _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch, squeeze):
         rmax = INT32_MAX
     m, n = M3.shape[-2], M3.shape[-1]
 
+    start = time.time()
     if algorithm == "svd":  # round.py:94-100
         U, sig = torch.linalg.svd(M3)[:2]
         side = "left"
+        if VERBOSE:
+            print("Time (SVD):", time.time() - start)
     else:  # round.py:101-135
         if m <= n:
             gram, side = M3 @ _t(M3), "left"
         else:
             gram, side = _t(M3) @ M3, "right"
+        if VERBOSE:
+            print("Time (gram):", time.time() - start)
+        start = time.time()
         w, U = torch.linalg.eigh(gram)
+        if VERBOSE:
+            print("Time (symmetric EIG):", time.time() - start)
         w = torch.where(w < 0, torch.zeros_like(w) + 1e-8, w)
         sig = torch.sqrt(w)
         sig, idx = torch.sort(sig, dim=-1, descending=True)
@@ -89,6 +99,7 @@ def _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch, squeeze):
 
     left = U[..., :rank]
     sr = sig[..., :rank].to(M3.dtype)
+    start = time.time()
     if side == "left":  # round.py:164-172
         if left_ortho:
             M2 = _t(left) @ M3
@@ -104,6 +115,8 @@ def _truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch, squeeze):
             newleft = M3 @ left
             M2 = _t(left)
             left = newleft
+    if VERBOSE:
+        print("Time (product):", time.time() - start)
     if squeeze:
         return left[None], M2[None]
     return left, M2
@@ -166,8 +179,11 @@ def round_tt(cores4: Sequence[torch.Tensor], eps, rmax, algorithm, batch, Us=Non
     """tensor.py:2008-2083 (``Us``: Tucker factors, orthogonalised in place by the L2R sweep)."""
     c = list(cores4)
     N = len(c)
+    start = time.time()
     for mu in range(N - 1):
         left_orthogonalize(c, mu, Us)
+    if VERBOSE:
+        print("Orthogonalization time:", time.time() - start)
     if batch:
         delta = None
     else:

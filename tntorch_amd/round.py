@@ -60,13 +60,12 @@ def truncated_svd(
     assert rmax >= 1
     assert algorithm in ("svd", "eig")
     ops = ops_for(M)
-    start = time.time()
     M3 = M if batch else M[None]
-    left, M2 = ops.truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch)
-    if verbose:
-        if M.is_cuda:
-            torch.cuda.synchronize()
-        print("Time (truncated SVD, {}):".format(algorithm), time.time() - start)
+    ops.VERBOSE = bool(verbose)   # the reference's per-stage lines: "Time (SVD):" | "Time (gram):", "Time (symmetric EIG):"; "Time (product):"
+    try:
+        left, M2 = ops.truncated_svd(M3, delta, eps, rmax, left_ortho, algorithm, batch)
+    finally:
+        ops.VERBOSE = False
     if batch:
         return left, M2
     return left[0], M2[0]

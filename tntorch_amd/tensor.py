@@ -473,13 +473,12 @@ class Tensor(object):
             return
         c, Us = self._norm4(), self._norm_us()
         ops = ops_for(c[0])
-        start = time.time()
-        out = ops.round_tt(c, eps, list(rmax), algorithm, self.batch, Us if self._has_factors() else None)
+        ops.VERBOSE = bool(verbose)   # the reference's lines: "Orthogonalization time:", then per bond those of truncated_svd
+        try:
+            out = ops.round_tt(c, eps, list(rmax), algorithm, self.batch, Us if self._has_factors() else None)
+        finally:
+            ops.VERBOSE = False
         self.Us = self._denorm_us(Us)
-        if verbose:
-            if c[0].is_cuda:
-                torch.cuda.synchronize()
-            print("round_tt time (orthogonalization + truncation sweeps):", time.time() - start)
         self.cores = self._denorm(out)
 
     @staticmethod
