@@ -1,6 +1,6 @@
 """Cost of the fused row-Gram epilogue of qr_apply at the metric's shape: apply alone, apply + Gram, rowgram alone (us per launch)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

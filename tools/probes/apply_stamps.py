@@ -1,6 +1,6 @@
 """Cycle stamps inside the level-0 qr_apply kernel (library built with -DTTR_QR_WSTAMPS, TTR_LIB_PATH)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 L = _hip.lib()

@@ -1,7 +1,7 @@
 """Block-Jacobi driver in isolation: sweeps performed (device control block) and time per eigenproblem for C3's (n = 256,
 64 items) and C1's (n = 1024, one item) bond sizes, absolute (pass 1) and relative (pass 2) mode, per inner-sweep setting."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, math
 from tntorch_amd import _hip as h, _hipops
 

@@ -1,6 +1,6 @@
 """fp64 TSQR block size A/B on config C2's resident batch: 256-row (4-wave) blocks vs 512-row (8-wave) blocks."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tntorch_amd as tn
 from tntorch_amd import _hip as h

@@ -1,7 +1,7 @@
 """Config C2, ONE fp64 train (round_tt eps=1e-4; 10 cores x mode 128, rank 64 -> 32): wall time per call and the library's
-per-kind kernel time / launch counts of one call.   python tools/c2_single_probe.py"""
+per-kind kernel time / launch counts of one call.   python tools/probes/c2_single_probe.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import tntorch_amd as tn

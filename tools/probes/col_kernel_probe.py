@@ -1,7 +1,7 @@
 """Launch times of the tall-matrix kernels of a dense TT-SVD's first steps (ttr_colgram, ttr_colproject) at C3's and C1's
-shapes, with the HBM rates their algorithmic bytes give.   python tools/col_kernel_probe.py"""
+shapes, with the HBM rates their algorithmic bytes give.   python tools/probes/col_kernel_probe.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the non-headline BASELINE configs (C2, C3 unit, C1 proxy) through the public API on one GPU."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tntorch_amd as tn
 

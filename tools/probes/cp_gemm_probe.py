@@ -1,7 +1,7 @@
 """The two X-sized products of one CP-ALS sweep at config C4's shape (X = 256^4 fp32, R = 32): X (I^3 x I) times a factor, and
-X^T ((I x I^3)^T) times a factor -- launch time and HBM rate.   python tools/cp_gemm_probe.py [I]"""
+X^T ((I x I^3)^T) times a factor -- launch time and HBM rate.   python tools/probes/cp_gemm_probe.py [I]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

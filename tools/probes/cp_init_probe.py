@@ -1,7 +1,7 @@
 """Where the time of the CP HOSVD init (tensor.py:228-277) of BASELINE C4 goes: per mode, Gram / eigensolver, cold and warm."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tntorch_amd import _hip, _hipops  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Where the dense configs spend their time (GPU): per-kind kernel time of one C3 share / one C1-class step for a few
 settings of the block-Jacobi inner sweep count and with / without the 128 x 128-tile GEMM; raw GEMM rates of the C1 shapes."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tntorch_amd as tn
 from tntorch_amd import _hip as h

@@ -1,7 +1,7 @@
 """Where does a config-scale dense TT-SVD spend its time?  Wall time of every right-to-left step (one truncate() call each)
-and the library's per-kernel-kind device time.  python tools/dense_steps_probe.py 16 64 64 64 64 64 [--alg eig] [--batch B] [--rank r]"""
+and the library's per-kernel-kind device time.  python tools/probes/dense_steps_probe.py 16 64 64 64 64 64 [--alg eig] [--batch B] [--rank r]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tntorch_amd as tn
 from tntorch_amd import _hip, _hipops

@@ -1,6 +1,6 @@
 """Orthogonality / residual of the tridiagonal eigensolver's V on metric-like and full-rank Gram matrices (fp32)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 torch.manual_seed(0)

@@ -1,7 +1,7 @@
 """Timing of the eigensolver launches of the metric sweep in isolation: tridiagonal QL (pass 1) and Jacobi LIVE (pass 2) on
-Gram matrices like the metric's (rank 32 of 64) and on full-rank ones; batch 2048 and 1.   python tools/eigh_probe.py"""
+Gram matrices like the metric's (rank 32 of 64) and on full-rank ones; batch 2048 and 1.   python tools/probes/eigh_probe.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

@@ -1,7 +1,7 @@
 """Cycle stamps inside the tridiagonal eigensolver (library built with -DTTR_EIGH_STAMPS, TTR_LIB_PATH): phases of matrix 0
-and the split of the QL phase into recurrence / rotation application.   python tools/eigh_stamps.py"""
+and the split of the QL phase into recurrence / rotation application.   python tools/probes/eigh_stamps.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 L = _hip.lib()

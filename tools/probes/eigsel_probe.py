@@ -1,7 +1,7 @@
 """Selected-eigenpair solver (ttr_tridiag -> ttr_tri_eigsel -> ttr_qr -> ttr_tridiag_back) against the full block-Jacobi
-decomposition on Gram matrices of C3's shape: per-stage kernel time.   python tools/eigsel_probe.py [B] [n] [k]"""
+decomposition on Gram matrices of C3's shape: per-stage kernel time.   python tools/probes/eigsel_probe.py [B] [n] [k]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip, _hipops
 

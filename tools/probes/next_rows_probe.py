@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device timings of the SURVEY 8f rows other than CP-ALS (tools/cp_probe.py): Tucker rounding, consumers, producers."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tntorch_amd as tn
 

@@ -3,7 +3,7 @@ starts together with every other first-wave block (all of them stream their core
 the grid show the steady state.  Prints per block: total cycles and the deltas [push | per panel: transpose, phases,
 T / W, update]."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip as h
 

@@ -2,7 +2,7 @@
 built with -DTTR_QR_WSTAMPS, pointed to by TTR_LIB_PATH).  Prints, for every phase, what each wave did between the
 phase entry, the pre-barrier point, the barrier release and the end of its apply section."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

@@ -1,7 +1,7 @@
 """Per-step wall times of the metric workload in a fresh process (are the first steps slower: clock ramp, first-touch of the
-workspaces?).  python tools/step_times.py [steps]"""
+workspaces?).  python tools/probes/step_times.py [steps]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 import tntorch_amd as tn

@@ -1,8 +1,8 @@
 """Launch times of the R2L sweep's streaming kernels at the metric's shapes (B items of a 64 x 2048 right unfolding, fp32):
 ttr_rowgram (reads M), ttr_rotgram (reads M, MFMA-bound), ttr_project to rank 32 (reads M, writes half of it), with the
-HBM rates their algorithmic bytes give.   python tools/sweep_kernel_probe.py [B]"""
+HBM rates their algorithmic bytes give.   python tools/probes/sweep_kernel_probe.py [B]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tntorch_amd import _hip
 

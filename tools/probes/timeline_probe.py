@@ -1,7 +1,7 @@
 """Timeline of the kernels of a few metric steps from a rocprofv3 --kernel-trace CSV: busy time per queue, their union,
 overlap, and the largest idle gaps -- to see what the sub-batch streams really overlap.
     rocprofv3 --kernel-trace --output-format csv -d out -o kt -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras
-    python tools/timeline_probe.py out/.../kt_kernel_trace.csv"""
+    python tools/probes/timeline_probe.py out/.../kt_kernel_trace.csv"""
 import csv, sys
 from collections import defaultdict
 
