@@ -484,6 +484,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      faster on config C2 all the same).  Bit 1 (value 2 / 3): the same for fp32 (round 4's A/B on the metric
  *                      workload).  Set it BEFORE any workspace is sized (an A/B switch). */
 #define TTR_KNOB_QR_F64_NW4 5
+/*   TTR_KNOB_QR_RANK_SKIP  c (default 8): the 8-wave QR blocks do not factor a panel whose remaining part is below c eps of the
+ *                      block's Frobenius norm (rank-inflated trains: H = I, tau = 0; ttr_qr_apply skips trailing identity
+ *                      panels); 0 = every panel is factored (A/B). */
+#define TTR_KNOB_QR_RANK_SKIP 6
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */

@@ -985,6 +985,7 @@ KNOB_BJ_INNER_SWEEPS = 1
 KNOB_GEMM_BIG = 2
 KNOB_QR_STAMP_BX, KNOB_QR_STAMP_BY = 3, 4
 KNOB_QR_F64_NW4 = 5
+KNOB_QR_RANK_SKIP = 6
 
 
 def set_knob(knob: int, value: int):

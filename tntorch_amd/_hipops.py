@@ -615,6 +615,7 @@ def truncate(
             if algorithm == "svd" and not left_ortho:
                 _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps, rank_dev=info)  # (not the rows that are cut away)
             _hip.mask_cols(left, info)
+            st.lap("Time (product):")
             return Truncation(left, None, right, r, info=info, gtrace=gtr)
         r = _select_rank(info, batch, rmax, k)
         if r == 0:  # zero guard, round.py:137-145 (kept on M's device/dtype)

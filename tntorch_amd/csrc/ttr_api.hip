@@ -592,6 +592,7 @@ extern int g_bj_inner_sweeps;
 extern int g_gemm_big;
 extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
+extern int g_rank_skip_c;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -1143,6 +1144,10 @@ int ttr_debug_set_knob(int knob, int value) {
       return TTR_OK;
     case TTR_KNOB_QR_STAMP_BY:
       g_qr_dbg_by = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_RANK_SKIP:
+      TTR_REQUIRE(value >= 0 && value <= 4096, TTR_E_INVALID, "ttr_debug_set_knob: rank-skip factor %d outside [0, 4096]", value);
+      g_rank_skip_c = value;
       return TTR_OK;
     case TTR_KNOB_QR_F64_NW4:
       TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: 4-wave block switch %d outside [0, 3]", value);

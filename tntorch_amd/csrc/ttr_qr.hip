@@ -56,6 +56,7 @@ struct QrLevel {
   T* Rout;             // the block's R: next level's X (row block b*n) or the user's R
   int64_t ldr, strideR;
   int top;             // 1: single block, writes k x n to the user's R
+  int rank_skip_c;     // rank-revealing early exit of PAIR blocks: a panel below (c eps)^2 of the block's squared norm is H = I; 0 = off
   // PUSHED level 0: the factored matrix is the left unfolding of  P[kk,i,c] = sum_r0 Rm[kk,r0] C[r0,i,c]
   // (tensor.py:1826-1832 fused into the next QR): block b owns rows {(kk, i): i = 4b + wave}
   const T* Rm;         // [pk x pRin], leading dimension ldrm
@@ -324,6 +325,32 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           for (int r = 0; r < 4; ++r) acc[tm][tn][r] = ldexpf((float)acc[tm][tn][r], -bexp);
     }
   }
+  // Rank-revealing early exit (PAIR blocks, round 4): rounding works on rank-INFLATED trains (sums, products: the metric's
+  // t = g + g has unfoldings of rank 32 in 64 columns), so after the first panels the remaining columns of a block are
+  // rounding noise.  A panel whose remaining part (rows >= j0 of its 16 columns, after the earlier panels' updates) has a
+  // squared Frobenius norm below (8 eps)^2 of the block's is not factored: its reflectors are H = I (tau = 0), what is dropped
+  // below the diagonal is a backward error of 8 eps ||block||_F -- the size of the factorisation's own -- and the apply kernel
+  // skips trailing identity panels altogether.  bf2: the block's squared Frobenius norm (at the factorisation's exponent).
+  T rank_thr = T(0);
+  if constexpr (PAIR) {
+    T sq = T(0);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq += acc[tm][tn][r] * acc[tm][tn][r];
+    sq = wave_sum_dpp(sq);
+    if (lane == 0) Ss[wave] = sq;
+    lds_barrier();
+    T bf2 = Ss[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bf2 += Ss[w];
+    lds_barrier();  // Ss is reused by the panels
+    const T ce = T(p.rank_skip_c) * Num<T>::eps();
+    rank_thr = lane_get(ce * ce * bf2, 0);   // (wave-uniform: lives in SGPRs)
+    if (p.rank_skip_c <= 0) rank_thr = T(-1);
+  }
   stamp();
 #ifdef TTR_QR_WSTAMPS
   // diagnostics build only: per-wave cycle stamps of the first panel's phases, dbg[64 + 40 * wave + 4 * phase + k]
@@ -367,11 +394,34 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       if (tid < PW * PW) { Ts[(tid >> 4) * VLD + (tid & 15)] = T(0); Ss[(tid >> 4) * VLD + (tid & 15)] = T(0); }
     }
     lds_barrier();
+    bool rank_skip = false;
     if constexpr (PAIR) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int q = 0; q < NW; ++q) pcv[cc][q >> 1][q & 1] = Vs[(lane + 64 * q) * VLD + wave * 2 + cc];
+      // what is left of this panel: rows >= j0 of its columns (rows < 64 only exist in the first half of pair 0)
+      {
+        T e = T(0);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          V2 x0 = pcv[cc][0];
+          if (lane < j0) x0.x = T(0);
+          V2 a2 = x0 * x0;
+#pragma unroll
+          for (int h = 1; h < NW / 2; ++h) a2 = pcv[cc][h] * pcv[cc][h] + a2;
+          e += a2.x + a2.y;
+        }
+        e = wave_sum_dpp(e);
+        if (lane == 0) pairt[wave] = e;   // (pairt: free until the first owner publishes)
+        lds_barrier();
+        T pr2 = pairt[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) pr2 += pairt[w];
+        rank_skip = lane_get(pr2, 0) <= rank_thr;   // block-uniform, scalar
+        lds_barrier();                     // pairt is rewritten by the owners
+        if (rank_skip) nsteps = 0;
+      }
     } else {
 #pragma unroll
       for (int cc = 0; cc < CPW; ++cc)
@@ -697,7 +747,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     }
     if constexpr (PAIR) {
       // the owners stored their pairs themselves; columns no phase covered are identity reflectors
-      for (int j = (nsteps + 1) & ~1; j < PW; ++j) Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
+      // (a rank-skipped panel is recognised by its zero taus: the apply kernel never reads its reflectors or its T)
+      if (!rank_skip)
+        for (int j = (nsteps + 1) & ~1; j < PW; ++j) Vt[(int64_t)(j0 + j) * BR + tid] = T(0);
       if (tid < PW && tid >= ((nsteps + 1) & ~1)) tau[j0 + tid] = T(0);
     } else {
       for (int j = nsteps; j < PW; ++j) {  // identity reflectors: keep the stored factors well defined
@@ -714,7 +766,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         const int nph = (nsteps + 1) >> 1;
         if (nph >= 2) t_columns(nph - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int e = lane; e < PW * PW; e += 64) Tg[pnl * PW * PW + e] = Ts[(e >> 4) * VLD + (e & 15)];
+        if (!rank_skip)
+          for (int e = lane; e < PW * PW; e += 64) Tg[pnl * PW * PW + e] = Ts[(e >> 4) * VLD + (e & 15)];
       }
     } else {
     // S = V^T V over the block (MFMA, K = BR split over the waves), then T
@@ -774,7 +827,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // (6) W = V^T A2, per-wave partial over its 64 rows; the accumulator registers are the B operand.  W does not
     // depend on T: it is formed in the same barrier interval as the (serial, 16-lane) larft recurrence above, so
     // the other waves' MFMAs run under wave 0's recurrence instead of waiting for it.
-    const bool trailing = pnl < NT - 1 && (pnl + 1) * PW < n;
+    const bool trailing = pnl < NT - 1 && (pnl + 1) * PW < n && !rank_skip;   // (H = I: nothing to update)
     if (trailing) {
 #pragma unroll
       for (int tn = pnl + 1; tn < NT; ++tn) {
@@ -893,7 +946,16 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #endif
   astamp();
   // the first panel's reflectors are requested before C is initialised: their HBM latency hides the Top loads
-  const int npanels = (kb + PW - 1) / PW;
+  int npanels = (kb + PW - 1) / PW;
+  {
+    // trailing panels whose taus are all zero are H = I (rank-skipped by the factor kernel, or never factored): they are not
+    // loaded at all.  Every wave looks at the block's taus itself (lane = reflector index): wave-uniform without LDS.
+    const T* __restrict__ tq = p.tau + blk * (int64_t)NP;
+    const T tv = lane < NP ? tq[lane] : T(0);
+    const unsigned long long livem = __ballot(tv != T(0));
+    const int nlive = livem ? (63 - __builtin_clzll(livem)) / PW + 1 : 0;
+    npanels = npanels < nlive ? npanels : nlive;
+  }
   const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
   T vreg[PW], treg = T(0);
   if (npanels > 0) {
@@ -1146,6 +1208,7 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
 int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_set_knob: a block in the middle of the grid shows the
                                         // steady state -- block (0, 0) starts together with every other first-wave block)
+int g_rank_skip_c = 8;   // ttr_debug_set_knob(TTR_KNOB_QR_RANK_SKIP, c): threshold factor of the rank-revealing early exit (0 = off)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
 struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factorisation)
@@ -1167,6 +1230,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     QrLevel<T> p;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     p.dbg_bx = g_qr_dbg_bx; p.dbg_by = g_qr_dbg_by;
+    p.rank_skip_c = g_rank_skip_c;
     p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
     p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
     p.Cn2 = (const T*)pu.Cn2; p.strideCn2 = pu.strideCn2; p.sumRa = pu.sumRa; p.sumCa = pu.sumCa;
