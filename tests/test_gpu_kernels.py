@@ -173,6 +173,44 @@ def test_qr_pushed(dt, k, Rin, I, n, qr_variant):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("pack", [0, 1, 2])
+@pytest.mark.parametrize("I,mixed", [(64, False), (128, False), (64, True), (24, False)])
+def test_qr_pushed_rank_deficient_R_packs_rows(dt, I, mixed, pack):
+    """Fused push with an R factor of numerical rank 32 of 64 (rows 32 .. 63 at the rounding level: the L2R sweep of a
+    rank-inflated train, t = g + g): the level-0 blocks pack two mode indices per wave and drop the pushed rows (kk >= 32, i)
+    as zeros (TTR_KNOB_QR_PACK), the trailing panels are H = I (TTR_KNOB_QR_RANK_SKIP).  Q R still reproduces the product to
+    the rounding level, Q stays orthonormal on its range, and a batch that mixes a rank-deficient and a full-rank item (decided
+    per item on the device) handles both; I = 24 (3 blocks: odd) never packs."""
+    h = _hip()
+    h.set_knob(h.KNOB_QR_PACK, pack)   # (off by default: measured without gain at scale; 1 / 2 = the two block pairings)
+    g = torch.Generator().manual_seed(I + 7 * int(mixed))
+    B, k, Rin, n = 3, 64, 64, 64
+    top = torch.triu(torch.randn(B, 32, 64, generator=g, dtype=torch.float64))
+    Rm = torch.cat([top, 1e-9 * torch.triu(torch.randn(B, 32, 64, generator=g, dtype=torch.float64), diagonal=32)], dim=1)
+    if mixed:
+        Rm[1] = torch.triu(torch.randn(64, 64, generator=g, dtype=torch.float64))
+    Rm = Rm.to(dt)
+    # a core with the block structure of g + g: rows 32.. only reach columns 32.. (rank-32 unfolding for the deficient items)
+    gcore = torch.randn(B, 32, I, 32, generator=g, dtype=torch.float64)
+    z = torch.zeros_like(gcore)
+    core = torch.cat([torch.cat([gcore, z], dim=-1), torch.cat([z, gcore], dim=-1)], dim=1).to(dt)
+    P = (Rm.double() @ core.double().reshape(B, Rin, I * n)).reshape(B, k * I, n)
+    f = h.qr_factor_pushed(Rm.cuda(), core.cuda())
+    R = f.R.cpu().double()
+    C = torch.eye(64, dtype=torch.float64)[None, :, :32].repeat(B, 1, 1).to(dt)
+    C2 = torch.eye(64, dtype=torch.float64)[None, :, 32:].repeat(B, 1, 1).to(dt)
+    Q = torch.cat([h.qr_apply(f, C.cuda()).cpu().double(), h.qr_apply(f, C2.cuda()).cpu().double()], dim=2)   # Q [I; 0], 32 columns at a time
+    assert torch.isfinite(Q).all() and torch.isfinite(R).all()
+    assert (Q @ R - P).abs().max() / P.abs().max() < tol(dt, 2e-5, 1e-8)        # (fp64: the 1e-9 rows are dropped by design)
+    for bi in range(B):
+        r = 64 if (mixed and bi == 1) else 32
+        Qr = Q[bi][:, :r]
+        assert (Qr.T @ Qr - torch.eye(r, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
+    assert torch.equal(torch.tril(f.R, diagonal=-1), torch.zeros_like(f.R))
+    h.set_knob(h.KNOB_QR_PACK, 0)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_qr_rank_deficient(dt, qr_variant):
     """Left unfolding of g+g: exactly rank-deficient; Q must still be orthonormal."""
     h = _hip()

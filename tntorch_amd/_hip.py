@@ -986,6 +986,7 @@ KNOB_GEMM_BIG = 2
 KNOB_QR_STAMP_BX, KNOB_QR_STAMP_BY = 3, 4
 KNOB_QR_F64_NW4 = 5
 KNOB_QR_RANK_SKIP = 6
+KNOB_QR_PACK = 7
 
 
 def set_knob(knob: int, value: int):

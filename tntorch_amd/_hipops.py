@@ -1007,6 +1007,10 @@ class _ExplicitQ:
 _FUSE_APPLY_GRAM = os.environ.get("TTR_FUSE_APPLY_GRAM", "0") == "1"
 
 
+if _FUSE_APPLY_GRAM:   # (its epilogue assumes the unpacked row map of the level-0 blocks)
+    _hip.set_knob(_hip.KNOB_QR_PACK, 0)
+
+
 def _apply_q(f, C: torch.Tensor, out: Optional[torch.Tensor] = None, want_gram: bool = False):
     if isinstance(f, _ExplicitQ):
         Q = _hip.gemm(f.Q, C, out=out)

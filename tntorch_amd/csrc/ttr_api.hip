@@ -593,6 +593,7 @@ extern int g_gemm_big;
 extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
+extern int g_qr_pack;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -1144,6 +1145,10 @@ int ttr_debug_set_knob(int knob, int value) {
       return TTR_OK;
     case TTR_KNOB_QR_STAMP_BY:
       g_qr_dbg_by = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_PACK:
+      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: packing switch %d outside [0, 2]", value);
+      g_qr_pack = value;
       return TTR_OK;
     case TTR_KNOB_QR_RANK_SKIP:
       TTR_REQUIRE(value >= 0 && value <= 4096, TTR_E_INVALID, "ttr_debug_set_knob: rank-skip factor %d outside [0, 4096]", value);

@@ -57,6 +57,13 @@ struct QrLevel {
   int64_t ldr, strideR;
   int top;             // 1: single block, writes k x n to the user's R
   int rank_skip_c;     // rank-revealing early exit of PAIR blocks: a panel below (c eps)^2 of the block's squared norm is H = I; 0 = off
+  // PUSHED level 0, row packing (round 4): when rows 32 .. 63 of Rm are below rank_skip_c eps of ||Rm||_F (the R factor of a
+  // rank-inflated train: numerical rank <= 32 of 64) the pushed rows (kk >= 32, i) are dropped as zeros and every wave holds TWO
+  // mode indices -- rows 0..31 = (kk, i = NW b + w), rows 32..63 = (kk, i = NW partner + w), partner = b +- nb / 2: one half of the blocks
+  // (which half alternates with the item: XCD balance) absorbs the other, whose blocks write a zero R and exit.  Decided per item by every block from Rm itself; block 0 records it for the
+  // apply kernel in pack_flag[item] (always written when non-null).  pack_ok = 0: never pack.
+  int32_t* pack_flag;
+  int pack_ok;
   // PUSHED level 0: the factored matrix is the left unfolding of  P[kk,i,c] = sum_r0 Rm[kk,r0] C[r0,i,c]
   // (tensor.py:1826-1832 fused into the next QR): block b owns rows {(kk, i): i = 4b + wave}
   const T* Rm;         // [pk x pRin], leading dimension ldrm
@@ -154,16 +161,30 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // then only needs the K steps r0 >= 16 tm (10 of the 16 tile x K-group combinations).  Detected here, not assumed: the
     // entry point takes any matrix.
     bool lower_nz = false;
+    T sq_all = T(0), sq_low = T(0);
     for (int idx = tid; idx < 64 * 64; idx += NTH) {
       const int kk = idx >> 6, r0 = idx & 63;
       const T rv = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
       lower_nz = lower_nz || (kk > r0 && rv != T(0));
+      sq_all += rv * rv;
+      if (kk >= 32) sq_low += rv * rv;
       Rs[kk * RLD + r0] = rv;
     }
-    if (lane == 0) pairt[wave] = __ballot(lower_nz) != 0ull ? T(1) : T(0);  // (pairt is free until the first panel)
+    wave_sum2(sq_all, sq_low);
+    if (lane == 0) {
+      pairt[wave] = __ballot(lower_nz) != 0ull ? T(1) : T(0);  // (pairt is free until the first panel)
+      Ss[wave] = sq_all; Ss[NW + wave] = sq_low;               // (so is Ss)
+    }
     const int imode = b * NW + wave;
     const bool ivalid = imode < p.pI;
     const int ksteps = (p.pRin + 3) >> 2;
+    bool packed = false;
+    // which half of an item's blocks does the work when it packs alternates with the item: consecutive workgroups go to
+    // consecutive XCDs, i.e. XCD = b for nb = 8 -- with a fixed half, four of the eight XCDs got all the heavy blocks (measured:
+    // 11.7 instead of 10.6 ms/step for the kind, slower than not packing at all)
+    const int half_nb = p.nb >> 1;
+    const bool absorbed_blk = p.pack_ok == 2 ? ((b & 1) != 0) != ((bt & 1) != 0) : (b >= half_nb) != ((bt & 1) != 0);
+    const int partner_blk = p.pack_ok == 2 ? (b ^ 1) : (b < half_nb ? b + half_nb : b - half_nb);
     if (p.Cn2 == nullptr) {
       // The wave's core slice C[:, i, :] (pRin rows of n values, 16 KiB for a 64 x 64 x 64 core) is streamed in groups
       // of four K steps with the NEXT group's loads in flight under the current group's MFMAs: with one K step per
@@ -182,9 +203,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       auto stream = [&](auto FULL) {
         constexpr bool kFull = decltype(FULL)::value != 0;
         T bvA[KG][NT], bvB[KG][NT];
+        int im_cur = imode_u;           // the mode index the loads address (packed: a second pass with the absorbed block's)
+        int tm_lo = 0, tm_hi = 4, tm_sub = 0;   // row tiles of this pass; A rows of tile tm = Rm rows 16 (tm - tm_sub) ..
         auto load_group = [&](int grp, T (&bv)[KG][NT]) {
           if constexpr (kFull) {
-            const T* __restrict__ rowp = Cb + (size_t)imode_u * n + (size_t)(grp * KG * 4) * cs;
+            const T* __restrict__ rowp = Cb + (size_t)im_cur * n + (size_t)(grp * KG * 4) * cs;
 #pragma unroll
             for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
@@ -214,36 +237,62 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
-              // upper-triangular Rm: rows 16 tm .. 16 tm + 15 are zero in the columns of K groups < tm (a K group = 16 columns)
-              if (upper && grp < tm) continue;  // wave-uniform
+              if (tm < tm_lo || tm >= tm_hi) continue;  // wave-uniform (packed: two row tiles per pass)
+              // upper-triangular Rm: rows 16 tm' .. 16 tm' + 15 are zero in the columns of K groups < tm' (a K group = 16 columns)
+              if (upper && grp < tm - tm_sub) continue;  // wave-uniform
 #pragma unroll
-              for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(av[tm], bv[kk][tn], acc[tm][tn]);
+              for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(tm_sub == 0 ? av[tm] : av[tm & 1], bv[kk][tn], acc[tm][tn]);
             }
           }
         };
-        load_group(0, bvA);  // in flight while Rs is being staged
+        auto run_pass = [&]() {   // group 0 of the pass is already in bvA
+          for (int grp = 0; grp < ngroups; grp += 2) {
+            if (grp + 1 < ngroups) load_group(grp + 1, bvB);
+            mma_group(grp, bvA);
+            if (grp + 1 < ngroups) {
+              if (grp + 2 < ngroups) load_group(grp + 2, bvA);
+              mma_group(grp + 1, bvB);
+            }
+          }
+        };
+        load_group(0, bvA);  // in flight while Rs is being staged (the same mode index whether the block packs or not)
         lds_barrier();
         {
-          T any = pairt[0];
+          T any = pairt[0], sa = Ss[0], sl = Ss[NW];
 #pragma unroll
-          for (int w = 1; w < NW; ++w) any += pairt[w];
+          for (int w = 1; w < NW; ++w) { any += pairt[w]; sa += Ss[w]; sl += Ss[NW + w]; }
           upper = any == T(0);
+          if constexpr (kFull && NW == 8 && PAIR) {
+            const T ce = T(p.rank_skip_c) * Num<T>::eps();
+            packed = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb &&
+                     lane_get(sl, 0) <= ce * ce * lane_get(sa, 0);
+          }
         }
+        if (packed && absorbed_blk) return;   // absorbed by its partner block (block-uniform; handled by the caller)
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
-        for (int grp = 0; grp < ngroups; grp += 2) {
-          if (grp + 1 < ngroups) load_group(grp + 1, bvB);
-          mma_group(grp, bvA);
-          if (grp + 1 < ngroups) {
-            if (grp + 2 < ngroups) load_group(grp + 2, bvA);
-            mma_group(grp + 1, bvB);
-          }
+        if (packed) tm_hi = 2;
+        run_pass();
+        if (packed) {   // second pass: the absorbed block's mode index into row tiles 2, 3 (Rm rows 0 .. 31 again)
+          im_cur = NW * partner_blk + wave_id;
+          tm_lo = 2; tm_hi = 4; tm_sub = 2;
+          load_group(0, bvA);
+          run_pass();
         }
       };
       if (full) stream(IC<1>{});
       else stream(IC<0>{});
+      if (packed && absorbed_blk) {
+        // an absorbed block: its rows live in its partner block.  The level above reads this block's R: zeros; its reflectors are
+        // H = I (zero taus: the apply kernel returns at once for it)
+        T* __restrict__ Ro = p.Rout + bt * p.strideR + (int64_t)b * n * p.ldr;
+        for (int idx = tid; idx < n * n; idx += NTH) Ro[(int64_t)(idx / n) * p.ldr + idx % n] = T(0);
+        if (tid < NP) p.tau[(bt * p.nb + b) * (int64_t)NP + tid] = T(0);
+        if (p.pack_flag && b == 0 && tid == 0) p.pack_flag[bt] = p.pack_ok;   // (block 0 records the decision whichever half it is in)
+        return;
+      }
     } else {
       lds_barrier();
 #pragma unroll
@@ -277,6 +326,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         }
       }
     }
+    if (p.pack_flag && b == 0 && tid == 0) p.pack_flag[bt] = packed ? p.pack_ok : 0;
     lds_barrier();  // Rs aliases Vs
   } else {
     const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
@@ -903,6 +953,7 @@ struct QrApply {
   T* Gp;           // optional (level 0 of a pushed factorisation, fp32, pk = 64, kcols = 32, whole blocks): the block's share of the
                    // ROW GRAM matrix of Out as a pk x pk unfolding, Gp[(bt * nb + b)][pk][pk] = sum_i Out_i Out_i^T over the block's mode indices
   long long* dbg;  // optional: cycle stamps of block (0, 0) (diagnostics)
+  const int32_t* pack_flag;  // level 0 of a PUSHED factorisation: != 0 for items the factor kernel packed (see QrLevel)
 };
 
 template <typename T, int NT, int NTC, int NW>
@@ -946,6 +997,10 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #endif
   astamp();
   // the first panel's reflectors are requested before C is initialised: their HBM latency hides the Top loads
+  const bool packed = p.pack_flag && p.pack_flag[bt] != 0;   // block-uniform
+  const int half_nb = p.nb >> 1;
+  const bool pmode2 = p.pack_flag && p.pack_flag[bt] == 2;
+  if (packed && (pmode2 ? ((b & 1) != 0) != ((bt & 1) != 0) : ((b >= half_nb) != ((bt & 1) != 0)))) return; // absorbed block: its rows are written by its partner block
   int npanels = (kb + PW - 1) / PW;
   {
     // trailing panels whose taus are all zero are H = I (rank-skipped by the factor kernel, or never factored): they are not
@@ -1045,6 +1100,30 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     astamp();
   }
 
+  if (p.pI > 0 && packed) {
+    // packed item (factor kernel: QrLevel::pack_flag): local rows 0..31 of wave w are (kk, i0 = NW b + w), rows 32..63 are
+    // (kk, i1 = NW partner + w), kk = 0..31; the rows kk >= 32 of both mode indices were dropped as zeros -- written here
+    T* __restrict__ Out = p.Out + bt * p.strideOut;
+    const int64_t kstride = (int64_t)p.pI * p.ldout;
+    const int i0 = b * NW + wave, i1 = (pmode2 ? (b ^ 1) : (b < half_nb ? b + half_nb : b - half_nb)) * NW + wave;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      T* __restrict__ o = Out + (int64_t)(tm < 2 ? i0 : i1) * p.ldout + cl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t kk = (tm & 1) * 16 + M::row(lane, r);
+#pragma unroll
+        for (int tc = 0; tc < NTC; ++tc) {
+          if (tc * PW + cl < kc) {
+            o[kk * kstride + tc * PW] = C[tm][tc][r];
+            o[(kk + 32) * kstride + tc * PW] = T(0);
+          }
+        }
+      }
+    }
+    astamp();
+    return;
+  }
   if (p.pI > 0) {
     T* __restrict__ Out = p.Out + bt * p.strideOut;
     const int imode = b * NW + wave;
@@ -1149,6 +1228,7 @@ struct QrPlan {
   int nw[16];  // waves per block on this level (block rows = 64 * nw)
   // workspace offsets in elements
   int64_t off_vt[16], off_tau[16], off_tg[16], off_x[16], off_out[16];
+  int64_t off_flag;  // one int32 per item (stored in an element slot): level-0 row packing of a pushed factorisation
   int64_t total;  // elements
 };
 
@@ -1187,6 +1267,7 @@ static QrPlan make_plan(int64_t m, int64_t n, int64_t batch, bool f64) {
       pl.off_out[l] = off; off += batch * pl.m[l] * n;  // Q slab of level l (m_l x kcols, kcols <= n)
     }
   }
+  pl.off_flag = off; off += align_up(batch, 64);
   pl.total = off;
   return pl;
 }
@@ -1208,6 +1289,12 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
 int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_set_knob: a block in the middle of the grid shows the
                                         // steady state -- block (0, 0) starts together with every other first-wave block)
+// ttr_debug_set_knob(TTR_KNOB_QR_PACK): 1 / 2 = pushed level-0 blocks pack two mode indices per wave when Rm has numerical rank
+// <= 32 (1: one half of an item's blocks absorbs the other, 2: even / odd blocks).  OFF by default -- measured (round 4,
+// tools/probes/qr_pack_stamps.py, profiles/r04_qr_pack_ab.txt): the packed blocks cost what an unpacked block costs (155 k vs 149 k
+// cycles) and there are half as many, yet the level-0 launch does not get shorter at scale (B = 1024: 1.26 ms either way; the
+// metric step 22.4 vs 20.8 ms with the apply's packed epilogue); only B = 256 gains (0.36 vs 0.45 ms).
+int g_qr_pack = 0;
 int g_rank_skip_c = 8;   // ttr_debug_set_knob(TTR_KNOB_QR_RANK_SKIP, c): threshold factor of the rank-revealing early exit (0 = off)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
@@ -1231,6 +1318,8 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     p.dbg_bx = g_qr_dbg_bx; p.dbg_by = g_qr_dbg_by;
     p.rank_skip_c = g_rank_skip_c;
+    p.pack_flag = (l == 0 && pu.Rm) ? reinterpret_cast<int32_t*>(ws + pl.off_flag) : nullptr;
+    p.pack_ok = (g_qr_pack && pu.Cn2 == nullptr) ? g_qr_pack : 0;
     p.Rm = (const T*)pu.Rm; p.ldrm = pu.ldrm; p.strideRm = pu.strideRm;
     p.Cn = (const T*)pu.Cn; p.strideCn = pu.strideCn; p.pk = pu.k; p.pRin = pu.Rin; p.pI = pu.I;
     p.Cn2 = (const T*)pu.Cn2; p.strideCn2 = pu.strideCn2; p.sumRa = pu.sumRa; p.sumCa = pu.sumCa;
@@ -1281,6 +1370,7 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     else { p.Out = wsw + pl.off_out[l]; p.ldout = kc; p.strideOut = pl.m[l] * n; }
     p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
     p.Gp = (l == 0) ? Gp : nullptr;
+    p.pack_flag = (l == 0 && pk > 0) ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
     const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
