@@ -488,12 +488,13 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      block's Frobenius norm (rank-inflated trains: H = I, tau = 0; ttr_qr_apply skips trailing identity
  *                      panels); 0 = every panel is factored (A/B). */
 #define TTR_KNOB_QR_RANK_SKIP 6
-/*   TTR_KNOB_QR_PACK  0 (default): off.  1 / 2 = level 0 of a fused push (ttr_qr_factor_pushed) whose R factor has rows 32 .. 63 below
+/*   TTR_KNOB_QR_PACK  3 (default) = level 0 of a fused push (ttr_qr_factor_pushed) whose R factor has rows 32 .. 63 below
  *                      c eps of its norm (c: TTR_KNOB_QR_RANK_SKIP) drops the pushed rows (kk >= 32, i) as zeros and packs two
- *                      mode indices per wave: half the level-0 blocks do all the work, the others write a zero R and exit;
- *                      ttr_qr_apply_pushed follows the per-item flag the factor kernel leaves in the workspace (1: one half of the
- *                      blocks absorbs the other, 2: even / odd).  Measured without gain at scale (round 4), hence off; must stay off
- *                      for ttr_qr_apply_pushed_gram, whose epilogue assumes the unpacked row map. */
+ *                      mode indices per wave: blocks b < nb / 2 do all the work, the others write a zero R and return, and the
+ *                      launch is block-major (all working blocks first); decided per item on the device,
+ *                      ttr_qr_apply_pushed follows the per-item flag the factor kernel leaves in the workspace.  1 / 2 = the
+ *                      item-major variants (measured without gain: the dispatcher stalls on alternating long / short
+ *                      workgroups); 0 = never (required for ttr_qr_apply_pushed_gram, whose epilogue assumes the unpacked map). */
 #define TTR_KNOB_QR_PACK 7
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);

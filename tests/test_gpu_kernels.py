@@ -173,7 +173,7 @@ def test_qr_pushed(dt, k, Rin, I, n, qr_variant):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("pack", [0, 1, 2])
+@pytest.mark.parametrize("pack", [0, 1, 2, 3])
 @pytest.mark.parametrize("I,mixed", [(64, False), (128, False), (64, True), (24, False)])
 def test_qr_pushed_rank_deficient_R_packs_rows(dt, I, mixed, pack):
     """Fused push with an R factor of numerical rank 32 of 64 (rows 32 .. 63 at the rounding level: the L2R sweep of a

@@ -1147,7 +1147,7 @@ int ttr_debug_set_knob(int knob, int value) {
       g_qr_dbg_by = value;
       return TTR_OK;
     case TTR_KNOB_QR_PACK:
-      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: packing switch %d outside [0, 2]", value);
+      TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: packing switch %d outside [0, 3]", value);
       g_qr_pack = value;
       return TTR_OK;
     case TTR_KNOB_QR_RANK_SKIP:

@@ -64,6 +64,7 @@ struct QrLevel {
   // apply kernel in pack_flag[item] (always written when non-null).  pack_ok = 0: never pack.
   int32_t* pack_flag;
   int pack_ok;
+  int grid_swap;
   // PUSHED level 0: the factored matrix is the left unfolding of  P[kk,i,c] = sum_r0 Rm[kk,r0] C[r0,i,c]
   // (tensor.py:1826-1832 fused into the next QR): block b owns rows {(kk, i): i = 4b + wave}
   const T* Rm;         // [pk x pRin], leading dimension ldrm
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = lane & 15, g = lane >> 4;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
-  const int b = blockIdx.x;
-  const int64_t bt = blockIdx.y;
+  // grid (nb, batch), or -- grid_swap, experiment -- (batch, nb): block-major launch order
+  const int b = p.grid_swap ? blockIdx.y : blockIdx.x;
+  const int64_t bt = p.grid_swap ? blockIdx.x : blockIdx.y;
   int64_t row0;
   int rows;
   block_rows(p.m, p.nb, b, row0, rows);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   auto rowl = [&](int tm, int reg) { return wave * 64 + tm * 16 + M::row(lane, reg); };
 
   int dbgi = 0;
-  auto stamp = [&]() { if (p.dbg && blockIdx.x == p.dbg_bx && blockIdx.y == p.dbg_by && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  auto stamp = [&]() { if (p.dbg && b == p.dbg_bx && bt == p.dbg_by && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
   stamp();
   Acc acc[4][NT];
   if constexpr (PUSHED) {
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // consecutive XCDs, i.e. XCD = b for nb = 8 -- with a fixed half, four of the eight XCDs got all the heavy blocks (measured:
     // 11.7 instead of 10.6 ms/step for the kind, slower than not packing at all)
     const int half_nb = p.nb >> 1;
-    const bool absorbed_blk = p.pack_ok == 2 ? ((b & 1) != 0) != ((bt & 1) != 0) : (b >= half_nb) != ((bt & 1) != 0);
+    const bool absorbed_blk = p.pack_ok == 3 ? (b >= half_nb)
+                            : p.pack_ok == 2 ? ((b & 1) != 0) != ((bt & 1) != 0) : (b >= half_nb) != ((bt & 1) != 0);
     const int partner_blk = p.pack_ok == 2 ? (b ^ 1) : (b < half_nb ? b + half_nb : b - half_nb);
     if (p.Cn2 == nullptr) {
       // The wave's core slice C[:, i, :] (pRin rows of n values, 16 KiB for a 64 x 64 x 64 core) is streamed in groups
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         for (int idx = tid; idx < n * n; idx += NTH) Ro[(int64_t)(idx / n) * p.ldr + idx % n] = T(0);
         if (tid < NP) p.tau[(bt * p.nb + b) * (int64_t)NP + tid] = T(0);
         if (p.pack_flag && b == 0 && tid == 0) p.pack_flag[bt] = p.pack_ok;   // (block 0 records the decision whichever half it is in)
+        stamp();
         return;
       }
     } else {
@@ -954,6 +958,7 @@ struct QrApply {
                    // ROW GRAM matrix of Out as a pk x pk unfolding, Gp[(bt * nb + b)][pk][pk] = sum_i Out_i Out_i^T over the block's mode indices
   long long* dbg;  // optional: cycle stamps of block (0, 0) (diagnostics)
   const int32_t* pack_flag;  // level 0 of a PUSHED factorisation: != 0 for items the factor kernel packed (see QrLevel)
+  int grid_swap;             // grid (batch, nb) instead of (nb, batch): block-major launch order (see QrLevel)
 };
 
 template <typename T, int NT, int NTC, int NW>
@@ -975,8 +980,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
-  const int64_t bt = blockIdx.y;
+  const int b = p.grid_swap ? blockIdx.y : blockIdx.x;
+  const int64_t bt = p.grid_swap ? blockIdx.x : blockIdx.y;
   int64_t row0;
   int rows;
   block_rows(p.m, p.nb, b, row0, rows);
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 
 #ifdef TTR_QR_WSTAMPS
   int dbgi = 0;
-  auto astamp = [&]() { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  auto astamp = [&]() { if (p.dbg && b == 0 && bt == 0 && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
 #else
   auto astamp = [&]() {};
 #endif
@@ -999,8 +1004,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   // the first panel's reflectors are requested before C is initialised: their HBM latency hides the Top loads
   const bool packed = p.pack_flag && p.pack_flag[bt] != 0;   // block-uniform
   const int half_nb = p.nb >> 1;
-  const bool pmode2 = p.pack_flag && p.pack_flag[bt] == 2;
-  if (packed && (pmode2 ? ((b & 1) != 0) != ((bt & 1) != 0) : ((b >= half_nb) != ((bt & 1) != 0)))) return; // absorbed block: its rows are written by its partner block
+  const int pmode = p.pack_flag ? p.pack_flag[bt] : 0;
+  const bool pmode2 = pmode == 2;
+  if (packed && (pmode == 3 ? (b >= half_nb) : pmode2 ? ((b & 1) != 0) != ((bt & 1) != 0) : ((b >= half_nb) != ((bt & 1) != 0)))) return; // absorbed block: its rows are written by its partner block
   int npanels = (kb + PW - 1) / PW;
   {
     // trailing panels whose taus are all zero are H = I (rank-skipped by the factor kernel, or never factored): they are not
@@ -1106,17 +1112,33 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     T* __restrict__ Out = p.Out + bt * p.strideOut;
     const int64_t kstride = (int64_t)p.pI * p.ldout;
     const int i0 = b * NW + wave, i1 = (pmode2 ? (b ^ 1) : (b < half_nb ? b + half_nb : b - half_nb)) * NW + wave;
+    if (kc == NC) {  // every store valid: one lane pointer per mode index, wave-uniform row offsets (as the unpacked fast path)
+      T* __restrict__ o0 = Out + (int64_t)i0 * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
+      T* __restrict__ o1 = Out + (int64_t)i1 * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      T* __restrict__ o = Out + (int64_t)(tm < 2 ? i0 : i1) * p.ldout + cl;
+      for (int tm = 0; tm < 4; ++tm) {
+        T* __restrict__ o = tm < 2 ? o0 : o1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t kk = (tm & 1) * 16 + M::row(lane, r);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int tc = 0; tc < NTC; ++tc) {
-          if (tc * PW + cl < kc) {
-            o[kk * kstride + tc * PW] = C[tm][tc][r];
-            o[(kk + 32) * kstride + tc * PW] = T(0);
+          for (int tc = 0; tc < NTC; ++tc) {
+            o[(int64_t)((tm & 1) * 16 + M::row(0, r)) * kstride + tc * PW] = C[tm][tc][r];
+            o[(int64_t)((tm & 1) * 16 + M::row(0, r) + 32) * kstride + tc * PW] = T(0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        T* __restrict__ o = Out + (int64_t)(tm < 2 ? i0 : i1) * p.ldout + cl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t kk = (tm & 1) * 16 + M::row(lane, r);
+#pragma unroll
+          for (int tc = 0; tc < NTC; ++tc) {
+            if (tc * PW + cl < kc) {
+              o[kk * kstride + tc * PW] = C[tm][tc][r];
+              o[(kk + 32) * kstride + tc * PW] = T(0);
+            }
           }
         }
       }
@@ -1289,12 +1311,14 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch) {
 long long* g_qr_dbg = nullptr;  // set through ttr_debug_set_qr_stamps (diagnostics only)
 int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_set_knob: a block in the middle of the grid shows the
                                         // steady state -- block (0, 0) starts together with every other first-wave block)
-// ttr_debug_set_knob(TTR_KNOB_QR_PACK): 1 / 2 = pushed level-0 blocks pack two mode indices per wave when Rm has numerical rank
-// <= 32 (1: one half of an item's blocks absorbs the other, 2: even / odd blocks).  OFF by default -- measured (round 4,
-// tools/probes/qr_pack_stamps.py, profiles/r04_qr_pack_ab.txt): the packed blocks cost what an unpacked block costs (155 k vs 149 k
-// cycles) and there are half as many, yet the level-0 launch does not get shorter at scale (B = 1024: 1.26 ms either way; the
-// metric step 22.4 vs 20.8 ms with the apply's packed epilogue); only B = 256 gains (0.36 vs 0.45 ms).
-int g_qr_pack = 0;
+// ttr_debug_set_knob(TTR_KNOB_QR_PACK): pushed level-0 blocks pack two mode indices per wave when Rm has numerical rank <= 32.
+// 3 (default): blocks b >= nb / 2 are absorbed by b - nb / 2 and the launch is BLOCK-MAJOR (grid (batch, nb)): all working
+// blocks are dispatched first, the absorbed ones (which return after ~12 k cycles) last.  1 / 2 (item-major grid, the working
+// half alternating with the item / even-odd blocks): measured WITHOUT gain -- the dispatcher stalls when long and short
+// workgroups alternate in launch order (level-0 launch 1.78 ms against 1.60 ms unpacked, although the working blocks cost
+// what an unpacked block costs and there are half as many); block-major: 1.1 ms, the metric step 20.9 -> 17.5 ms
+// (tools/probes/qr_pack_stamps.py, profiles/r04_qr_pack_ab.txt).  0 = never pack.
+int g_qr_pack = 3;
 int g_rank_skip_c = 8;   // ttr_debug_set_knob(TTR_KNOB_QR_RANK_SKIP, c): threshold factor of the rank-revealing early exit (0 = off)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
@@ -1335,7 +1359,8 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-    const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
+    p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? 1 : 0;
+    const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
     const bool pushed = (l == 0 && pu.Rm);
     if (pl.nw[l] == 8 && g_qr_variant != 0) {
       if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, true>), grid, dim3(512), 0, stream, p);
@@ -1373,7 +1398,8 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     p.pack_flag = (l == 0 && pk > 0) ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
-    const dim3 grid((unsigned)pl.nb[l], (unsigned)batch);
+    p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? 1 : 0;
+    const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
     if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 4>), grid, dim3(256), 0, stream, p);
   }

@@ -15,7 +15,7 @@ g = torch.randn(B, 32, 64, 32, device="cuda")
 z = torch.zeros_like(g)
 core = torch.cat([torch.cat([g, z], dim=-1), torch.cat([z, g], dim=-1)], dim=1).contiguous()
 buf = torch.zeros(64, dtype=torch.int64, device="cuda")
-for pack in (0, 1, 2):
+for pack in (0, 1, 3):
     h.set_knob(h.KNOB_QR_PACK, pack)
     h.qr_factor_pushed(Rm, core); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,7 +24,7 @@ for pack in (0, 1, 2):
     for Bs in (256, 512, 1024):
         e0.record(); h.qr_factor_pushed(Rm[:Bs], core[:Bs]); e1.record(); torch.cuda.synchronize()
         print(f"    B={Bs}: {e0.elapsed_time(e1):.3f} ms")
-    for bx, by in ((1, B // 4), (2, B // 2)):
+    for bx, by in ((1, B // 4), (2, B // 2), (5, B // 2), (6, B // 4), (3, B // 2 + 1)):
         h.set_knob(h.KNOB_QR_STAMP_BX, bx); h.set_knob(h.KNOB_QR_STAMP_BY, by)
         L.ttr_debug_set_qr_stamps(buf.data_ptr()); buf.zero_()
         h.qr_factor_pushed(Rm, core); torch.cuda.synchronize()
