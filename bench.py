@@ -141,8 +141,14 @@ def kernel_model():
     # flops the kernels actually EXECUTE (structure they exploit): the pushed R is upper triangular -- 10 of the 16
     # (row tile, K group) products of R @ core; before its first panel the apply's C is [Top; 0] -- 7 of the 8 waves of
     # a 512-row block skip that panel's W = V^T C
-    f_exec = f_flops - mid * 2.0 * Rr * Rr * I * n * (6.0 / 16.0)
-    a_exec = a_flops - mid * (leaf_blocks + 1) * (7.0 / 8.0) * 2.0 * 16 * leaf_rows * ro
+    # Round 4: on THIS input (t = g + g: R factors and unfoldings of numerical rank 32 of 64) the factor kernel packs the 2048
+    # significant rows of a pushed unfolding into four leaf blocks (two mode indices per wave; R rows 32.. dropped: half the push,
+    # of which the triangular R skips 1/8) and factors only the first two panels of every block (the other two are below 8 eps of
+    # the block: H = I); the apply walks the two live panels of the four working leaves.  `frac` stays on the ALGORITHMIC flops.
+    rk = 32
+    leaf_exec = hh(leaf_rows, rk) + 4.0 * leaf_rows * rk * (n - rk)                 # 32 reflectors + their update of the other 32 columns
+    f_exec = mid * (4 * leaf_exec + leaf_exec + 2.0 * rk * Rr * I * n * (7.0 / 8.0)) + hh(I, n)
+    a_exec = mid * (4 + 1) * 4.0 * leaf_rows * rk * ro + 4.0 * I * n * ro
     return {
         "qr_factor": {"flops": f_flops, "bytes": f_bytes, "executed_flops": f_exec},
         "qr_apply": {"flops": a_flops, "bytes": a_bytes, "executed_flops": a_exec},
@@ -644,6 +650,12 @@ def main():
             # BASELINE's other configs (C1 .. C4), one entry each: time, SURVEY 8d flops / bytes, roofline fraction, CPU
             # baseline on the config or its largest feasible proxy, oracle check (tools/bench_configs.py)
             del inp, out, t
+            sched._last = None          # (everything that still holds a step's result: C1 needs the whole device)
+            inflight.clear()
+            step_events.clear()
+            gathered = None
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs

@@ -54,7 +54,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
    ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 7
+#define TTR_ABI_VERSION 8
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -365,7 +365,12 @@ int ttr_mask_cols(int dtype, int64_t rows, int64_t cols, int64_t batch, void* x,
  */
 int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch);
 int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
-                void* G, int64_t nparts, void* stream);
+                void* G, int64_t nparts, const int32_t* rows32, void* stream);
+/* `rows32` (ttr_rowgram, ttr_project; optional device int32 [batch]): != 0 -> rows 32.. of this item's M are exactly zero and are
+ * not loaded (half the reads of an HBM-bound kernel).  Source: the flags a packed ttr_qr_factor_pushed leaves in its workspace at
+ * byte offset ttr_qr_pushed_flag_offset (TTR_KNOB_QR_PACK: the carry ttr_qr_apply_pushed produces from such a factorisation has
+ * zero rows kk >= 32). */
+int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch);
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip, void* stream);
 /*
@@ -392,7 +397,7 @@ int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
                 const void* V2, int64_t ldv2, int64_t strideV2,
                 const void* sigma, int64_t stride_sigma, int scale_right,
                 void* right, int64_t ldr, int64_t strideR,
-                void* left, int64_t ldl, int64_t strideL, void* stream);
+                void* left, int64_t ldl, int64_t strideL, const int32_t* rows32, void* stream);
 
 /*
  * The same fused kernels for TALL matrices (rows x n, n <= 64, row-major): the unfoldings a dense right-to-left TT-SVD

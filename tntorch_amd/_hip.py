@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 7  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 8  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -124,7 +124,8 @@ _SIGNATURES = {
     ),
     "ttr_bj_control": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "ttr_sweep_gram_parts": (c_int64, [c_int64, c_int64]),
-    "ttr_rowgram": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "ttr_rowgram": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ttr_qr_pushed_flag_offset": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_rotgram": (
         c_int,
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
@@ -132,7 +133,7 @@ _SIGNATURES = {
     "ttr_project": (
         c_int,
         [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p],
     ),
     "ttr_colgram_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_colgram": (
@@ -399,11 +400,14 @@ def qr_t(At: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 class QrFactors:
     """Handle on a factored batch (reflectors + T factors live in ``ws``) for later ``qr_apply`` calls."""
 
-    __slots__ = ("ws", "wsb", "m", "n", "batch", "dtype", "R", "pushed")
+    __slots__ = ("ws", "wsb", "m", "n", "batch", "dtype", "R", "pushed", "rows32")
 
-    def __init__(self, ws, wsb, m, n, batch, dtype, R, pushed=None):
+    def __init__(self, ws, wsb, m, n, batch, dtype, R, pushed=None, rows32=None):
         self.ws, self.wsb, self.m, self.n, self.batch, self.dtype, self.R = ws, wsb, m, n, batch, dtype, R
         self.pushed = pushed  # (k, I) when the factorisation came from qr_factor_pushed
+        # int32 [batch] view into ``ws`` (pushed factorisations): != 0 for items whose level-0 blocks packed their rows -- rows
+        # kk >= 32 of what qr_apply produces from this handle are exactly zero (ttr_rowgram / ttr_project: ``rows32``)
+        self.rows32 = rows32
 
     @property
     def k(self):
@@ -449,7 +453,12 @@ def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
         code = L.ttr_qr_factor_pushed(dt, k, Rin, I, n, batch, Rm.data_ptr(), ldrm, sRm, core4.data_ptr(), Rin * I * n,
                                       R.data_ptr(), n, kq * n, ws.data_ptr(), wsb, _stream())
         _check(code, "ttr_qr_factor_pushed")
-    return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I))
+    flags = None
+    if batch > 0 and k == 64:
+        off = int(L.ttr_qr_pushed_flag_offset(dt, I, n, batch))
+        if off >= 0:
+            flags = ws[off:off + 4 * batch].view(torch.int32)
+    return QrFactors(ws, wsb, k * I, n, batch, core4.dtype, R, pushed=(k, I), rows32=flags)
 
 
 @_on_device
@@ -751,7 +760,8 @@ def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float, use_delta: bool = 
 
 
 @_on_device
-def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None,
+            rows32: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Split-K partials [batch, parts, R, R] of M M^T (V1 None) or of (V1^T M)(V1^T M)^T for M [batch, R, n], R <= 64
     (ttr_rowgram / ttr_rotgram); ``eigh_trunc`` sums the parts on load."""
     L = lib()
@@ -763,7 +773,8 @@ def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[t
     if batch == 0:
         return G
     if V1 is None:
-        _check(L.ttr_rowgram(dt, R, n, batch, M.data_ptr(), ldm, sM, G.data_ptr(), parts, _stream()), "ttr_rowgram")
+        _check(L.ttr_rowgram(dt, R, n, batch, M.data_ptr(), ldm, sM, G.data_ptr(), parts,
+                             rows32.data_ptr() if rows32 is not None else None, _stream()), "ttr_rowgram")
     else:
         V1, ldv, sV = _mat(V1)
         assert V1.shape == (batch, R, R)
@@ -775,7 +786,8 @@ def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[t
 
 @_on_device
 def project(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma: Optional[torch.Tensor], ro: int,
-            scale_right: bool, out: Optional[torch.Tensor] = None, want_left: bool = True):
+            scale_right: bool, out: Optional[torch.Tensor] = None, want_left: bool = True,
+            rows32: Optional[torch.Tensor] = None):
     """right [batch, ro, n] = diag(1/sigma) U^T M and left [batch, R, ro] = U diag(sigma) with U = V1 V2[:, :ro]
     (ttr_project; ``scale_right=False``: right = U^T M, left = U).  ``out``: optional contiguous destination of right."""
     L = lib()
@@ -801,7 +813,8 @@ def project(M: torch.Tensor, V1: Optional[torch.Tensor], V2: torch.Tensor, sigma
         sp, ss = sigma.data_ptr(), sigma.shape[-1]
     _check(L.ttr_project(dt, R, n, ro, batch, M.data_ptr(), ldm, sM, v1p, ldv1, sV1, V2.data_ptr(), ldv2, sV2, sp, ss,
                          int(bool(scale_right)), right.data_ptr(), n, ro * n,
-                         left.data_ptr() if left is not None else None, ro, R * ro, _stream()), "ttr_project")
+                         left.data_ptr() if left is not None else None, ro, R * ro,
+                         rows32.data_ptr() if rows32 is not None else None, _stream()), "ttr_project")
     return right, left
 
 

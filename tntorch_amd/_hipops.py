@@ -537,6 +537,7 @@ def truncate(
     delta2_dev: Optional[torch.Tensor] = None,
     want_trace: bool = False,
     consume: bool = False,
+    rows32: Optional[torch.Tensor] = None,
 ) -> Truncation:
     """Truncated SVD of ``M`` [B, m, n]; semantics of round.py:52-187.
     ``right_alloc(r)``: optional callable returning the contiguous [B, r, n] tensor ``right`` is written into.
@@ -548,6 +549,9 @@ def truncate(
     from device memory, the factors are computed at the rank cap ``min(rmax, k)``, the selected rank stays on the device
     (``Truncation.info``) and the columns of ``left`` beyond it are zeroed there (``ttr_mask_cols``): the caller slices the
     cores once, at the end of its sweep, after ONE readback of all ranks.
+
+    ``rows32`` (fused <= 64-row path; int32 [B] on the device): items flagged != 0 have exactly zero rows 32.. in M (the carry of
+    a bond whose QR packed its rows, ``_hip.QrFactors.rows32``): the Gram and projection kernels do not load them.
 
     ``consume`` (tall fused path, one contiguous matrix): M's storage may be overwritten -- ``left`` is produced in place over
     its front (``_colproject_inplace``).
@@ -574,7 +578,7 @@ def truncate(
         # -> Jacobi -> projection with U = V1 V2 formed in the kernel's prologue, which also emits left = U sigma.
         V1 = None
         st = _Stage()
-        G = gram if gram is not None else _hip.rowgram(M)
+        G = gram if gram is not None else _hip.rowgram(M, rows32=rows32)
         gtr = _gram_trace(G) if want_trace else None
         if algorithm == "eig":
             st.lap("Time (gram):")
@@ -611,7 +615,7 @@ def truncate(
         st.lap("Time (SVD):" if algorithm == "svd" else "Time (symmetric EIG):")   # ('svd' here: both Gram passes + both solvers)
         if delta2_dev is not None:  # rank on the device: factors at the cap, the columns beyond info[b] zeroed in place
             r = _rank_cap(rmax, k)
-            right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho)
+            right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, rows32=rows32)
             if algorithm == "svd" and not left_ortho:
                 _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps, rank_dev=info)  # (not the rows that are cut away)
             _hip.mask_cols(left, info)
@@ -622,7 +626,7 @@ def truncate(
             return Truncation(torch.zeros((Bt, m, 1), dtype=M.dtype, device=M.device), None,
                               torch.zeros((Bt, 1, n), dtype=M.dtype, device=M.device), 1, zero=True, gtrace=gtr)
         dst = right_alloc(r) if right_alloc is not None else None
-        right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst)
+        right, left = _hip.project(M, V1, V, sig, r, scale_right=not left_ortho, out=dst, rows32=rows32)
         if algorithm == "svd" and not left_ortho:
             _hip.orth_fixup(right, sig, r, k * torch.finfo(M.dtype).eps)  # see below
         st.lap("Time (product):")
@@ -1231,11 +1235,14 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
                 M4 = _apply_q(f, left)
             M4 = M4.reshape(f.batch, r0, I, left.shape[2])
         Bt, R, I, rn = M4.shape
+        # rows kk >= 32 of the carry are exactly zero for the items whose QR of this bond packed its rows
+        r32 = getattr(facs[mu][0], "rows32", None) if (mu < N - 1 and R == 64) else None
         alloc = None
         if arena is not None:
             def alloc(r, mu=mu, n=I * rn):
                 return arena.slice(mu, chunk, (r, n))
-        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram, delta2_dev=d2dev)
+        t = truncate(M4.reshape(Bt, R, I * rn), delta, rmax[mu - 1], False, algorithm, batch, alloc, gram=gram, delta2_dev=d2dev,
+                     rows32=r32)
         if d2dev is not None:
             infos.append(t.info)
         if zflags is not None and mu == N - 1 and t.info is not None:

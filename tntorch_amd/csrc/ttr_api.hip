@@ -571,11 +571,13 @@ int eigh_max_n_lds(int dtype);
 int sweep_gram_parts(int64_t n, int64_t batch);
 int sweep_gram_dispatch(int dtype, int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
                         const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream,
-                        const int32_t* skip = nullptr);
+                        const int32_t* skip = nullptr, const int32_t* rows32 = nullptr);
 int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
                            int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
                            int64_t strideV2, const void* sigma, int64_t stride_sigma, int scale_right, void* right,
-                           int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream);
+                           int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream,
+                           const int32_t* rows32 = nullptr);
+int64_t qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch);
 
 int64_t colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch);
 int colgram_dispatch(int dtype, int64_t rows, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
@@ -899,12 +901,17 @@ int64_t ttr_sweep_gram_parts(int64_t n, int64_t batch) {
 }
 
 int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM, void* G,
-                int64_t nparts, void* stream) {
+                int64_t nparts, const int32_t* rows32, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_rowgram: bad dtype %d", dtype);
   TTR_REQUIRE(R >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_rowgram: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && G, TTR_E_INVALID, "ttr_rowgram: null pointer");
-  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, nullptr, 0, 0, G, nparts, (hipStream_t)stream);
+  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, nullptr, 0, 0, G, nparts, (hipStream_t)stream, nullptr, rows32);
+}
+
+int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch) {
+  if (!dtype_ok(dtype) || I < 1 || n < 1 || batch < 1) return -1;
+  return qr_pushed_flag_offset(dtype, I, n, batch);
 }
 
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
@@ -987,14 +994,14 @@ int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, in
 int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2, int64_t strideV2,
                 const void* sigma, int64_t stride_sigma, int scale_right, void* right, int64_t ldr, int64_t strideR,
-                void* left, int64_t ldl, int64_t strideL, void* stream) {
+                void* left, int64_t ldl, int64_t strideL, const int32_t* rows32, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_project: bad dtype %d", dtype);
   TTR_REQUIRE(R >= 1 && n >= 1 && ro >= 1 && batch >= 0, TTR_E_INVALID, "ttr_project: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && V2 && right, TTR_E_INVALID, "ttr_project: null pointer");
   TTR_REQUIRE(!scale_right || sigma, TTR_E_INVALID, "ttr_project: scale_right needs sigma");
   return sweep_project_dispatch(dtype, R, n, ro, batch, M, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
-                                stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, (hipStream_t)stream);
+                                stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, (hipStream_t)stream, rows32);
 }
 
 int64_t ttr_colgram_workspace_bytes(int dtype, int64_t rows, int64_t n, int64_t batch) {

@@ -1506,6 +1506,14 @@ static int64_t pushed_rows(int64_t I, int dtype) {
   return I > 4 ? 512 * ceil_div(I, 8) : 256;
 }
 
+// Byte offset, inside the workspace of a pushed factorisation, of the per-item int32 flags "this item's level-0 blocks packed
+// their rows: rows kk >= 32 of everything ttr_qr_apply_pushed produces from it are exactly zero"; -1 when the batch is processed
+// in slices (> 65535 items: one flag array per slice).
+int64_t qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch) {
+  if (batch > kMaxBatchSlice) return -1;
+  return make_plan(pushed_rows(I, dtype), n, batch, dtype == TTR_F64).off_flag * (dtype == TTR_F64 ? 8 : 4);
+}
+
 int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch) {
   return qr_workspace_bytes(dtype, pushed_rows(I, dtype), n, batch);
 }

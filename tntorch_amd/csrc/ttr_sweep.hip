@@ -33,6 +33,7 @@ struct SweepArgs {
   T* G;             // [batch][nsplit][R][R]
   int nsplit;
   const int32_t* skip;  // optional [batch]: != 0 -> this item's workgroups return at once (its G is not written)
+  const int32_t* rows32;  // optional [batch] (rowgram, project): != 0 -> rows 32.. of this item's M are exactly zero and are not loaded
   // project
   const T* V2;      // R x R (columns = directions), first ro used
   int64_t ldv2, strideV2;
@@ -117,12 +118,15 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
     split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
     // (the next step's loads are issued before the current step's MFMAs: with 4 waves per SIMD the 40 MFMAs of a step do not
     // cover an HBM round trip)
+    // (rows32: the carry of a bond whose QR packed its rows -- ttr_qr_factor_pushed on an R factor of numerical rank <= 32 -- has
+    // exactly zero rows 32..: they are not loaded, their Gram tiles come out as the zeros they are)
+    const int Rl = (p.rows32 && p.rows32[b] != 0 && R > 32) ? 32 : R;
     auto load_slab = [&](int64_t c, Acc (&mw)[4]) {
       const int64_t col = c * 16 + 4 * g;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = 16 * t + cl;
-        const Pack<T, 4> x = load_pack<T, 4>(Mp + (int64_t)row * p.ldm + col, al, row < R ? p.n - col : 0);
+        const Pack<T, 4> x = load_pack<T, 4>(Mp + (int64_t)row * p.ldm + col, al, row < Rl ? p.n - col : 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) mw[t][r] = x.v[r];
       }
@@ -284,13 +288,14 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
                   ((reinterpret_cast<uintptr_t>(Ro) & (2 * sizeof(T) - 1)) == 0);
   int64_t cb, ce;
   split_range((p.n + 31) / 32, p.nsplit, split, cb, ce);
+  const int Rl = (p.rows32 && p.rows32[b] != 0 && R > 32) ? 32 : R;   // (see rotgram_kernel: zero rows are not loaded)
   for (int64_t c = cb + wave; c < ce; c += 4) {
     const int64_t col = c * 32 + 2 * cl;
     T bm[2][16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const int k = 4 * ks + g;
-      const Pack<T, 2> x = load_pack<T, 2>(Mp + (int64_t)k * p.ldm + col, al, k < R ? p.n - col : 0);
+      const Pack<T, 2> x = load_pack<T, 2>(Mp + (int64_t)k * p.ldm + col, al, k < Rl ? p.n - col : 0);
       bm[0][ks] = x.v[0];
       bm[1][ks] = x.v[1];
     }
@@ -716,9 +721,11 @@ int sweep_gram_parts(int64_t n, int64_t batch) { return pick_split(n, batch); }
 
 template <typename T>
 static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM, const void* V1,
-                      int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream, const int32_t* skip) {
+                      int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream, const int32_t* skip,
+                      const int32_t* rows32) {
   SweepArgs<T> p{};
   p.skip = skip;
+  p.rows32 = rows32;
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.G = (T*)G; p.nsplit = (int)nsplit;
@@ -730,6 +737,7 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
     if (V1) q.V1 = p.V1 + b0 * strideV1;
     q.G = p.G + b0 * nsplit * R * R;
     if (skip) q.skip = skip + b0;
+    if (rows32) q.rows32 = rows32 + b0;
     const dim3 grid((unsigned)nsplit, (unsigned)nb);
     if (V1) hipLaunchKernelGGL((rotgram_kernel<T, false>), grid, dim3(kThreads), 0, stream, q);
     else hipLaunchKernelGGL((rotgram_kernel<T, true>), grid, dim3(kThreads), 0, stream, q);
@@ -740,20 +748,21 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
 
 int sweep_gram_dispatch(int dtype, int64_t R, int64_t n, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
                         const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nsplit, hipStream_t stream,
-                        const int32_t* skip) {
+                        const int32_t* skip, const int32_t* rows32) {
   TTR_REQUIRE(R >= 1 && R <= 64, TTR_E_UNSUPPORTED, "ttr_rowgram / ttr_rotgram: %lld rows (the fused kernels hold <= 64)",
               (long long)R);
   TTR_REQUIRE(nsplit >= 1 && nsplit <= 65535, TTR_E_INVALID, "ttr_rowgram / ttr_rotgram: bad split %lld", (long long)nsplit);
-  if (dtype == TTR_F32) return gram_typed<float>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip);
-  return gram_typed<double>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip);
+  if (dtype == TTR_F32) return gram_typed<float>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip, rows32);
+  return gram_typed<double>(R, n, batch, Mx, ldm, strideM, V1, ldv1, strideV1, G, nsplit, stream, skip, rows32);
 }
 
 template <typename T>
 static int project_typed(int64_t R, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm, int64_t strideM,
                          const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2, int64_t strideV2,
                          const void* sigma, int64_t stride_sigma, int scale_right, void* right, int64_t ldr,
-                         int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream) {
+                         int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream, const int32_t* rows32) {
   SweepArgs<T> p{};
+  p.rows32 = rows32;
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.V2 = (const T*)V2; p.ldv2 = ldv2; p.strideV2 = strideV2;
@@ -771,6 +780,7 @@ static int project_typed(int64_t R, int64_t n, int64_t ro, int64_t batch, const 
     if (sigma) q.sigma = p.sigma + b0 * stride_sigma;
     q.right = p.right + b0 * strideR;
     if (left) q.left = p.left + b0 * strideL;
+    if (rows32) q.rows32 = rows32 + b0;
     hipLaunchKernelGGL(project_kernel<T>, dim3((unsigned)p.nsplit, (unsigned)nb), dim3(kThreads), 0, stream, q);
   }
   TTR_HIP_CHECK(hipGetLastError());
@@ -780,14 +790,15 @@ static int project_typed(int64_t R, int64_t n, int64_t ro, int64_t batch, const 
 int sweep_project_dispatch(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch, const void* Mx, int64_t ldm,
                            int64_t strideM, const void* V1, int64_t ldv1, int64_t strideV1, const void* V2, int64_t ldv2,
                            int64_t strideV2, const void* sigma, int64_t stride_sigma, int scale_right, void* right,
-                           int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream) {
+                           int64_t ldr, int64_t strideR, void* left, int64_t ldl, int64_t strideL, hipStream_t stream,
+                           const int32_t* rows32) {
   TTR_REQUIRE(R >= 1 && R <= 64 && ro >= 1 && ro <= R, TTR_E_UNSUPPORTED,
               "ttr_project: %lld rows / %lld kept (the fused kernel holds <= 64 rows)", (long long)R, (long long)ro);
   if (dtype == TTR_F32)
     return project_typed<float>(R, n, ro, batch, Mx, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
-                                stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, stream);
+                                stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, stream, rows32);
   return project_typed<double>(R, n, ro, batch, Mx, ldm, strideM, V1, ldv1, strideV1, V2, ldv2, strideV2, sigma,
-                               stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, stream);
+                               stride_sigma, scale_right, right, ldr, strideR, left, ldl, strideL, stream, rows32);
 }
 
 }  // namespace ttr

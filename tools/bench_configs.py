@@ -335,8 +335,9 @@ def c1(tn, dev, algorithm="svd", cpu=True, variant="randn", shape=None):
     nbytes = lambda sh: math.prod(sh) * 4
     # a shape fits next to its carry (1.35 x), or -- round 4 -- alone, with the first carry written IN PLACE over the consumed
     # front of the input (`Tensor.from_dense_consuming`: the input is destroyed, so every repetition regenerates it, untimed)
-    fits = lambda sh: nbytes(sh) * 1.35 <= free or nbytes(sh) + (9 << 30) <= free
+    fits = lambda sh: nbytes(sh) * 1.35 <= free or nbytes(sh) + (5 << 30) <= free   # (in place: the input + < 4 GiB of carries and workspaces)
     shape = shape or next(sh for sh in cands if fits(sh))
+    free_gib = free / 2 ** 30
     consume = not nbytes(shape) * 1.35 <= free
 
     def make(out=None):
@@ -388,7 +389,7 @@ def c1(tn, dev, algorithm="svd", cpu=True, variant="randn", shape=None):
         "oracle_check": dict(check, what="the TIMED result checked on the device: T is the orthogonal projection of X onto its "
                                         "right-orthonormal cores (<X,T> = ||T||^2, ||X-T||^2 = ||X||^2 - ||T||^2); the choice of the "
                                         "subspace against the oracle: tests/test_gpu_parity.py at 64^4"),
-        "in_place_first_carry": bool(consume),
+        "in_place_first_carry": bool(consume), "free_GiB_before": round(free_gib, 1),
         "big_bond_paths": _paths(again),
         "kernel_ms": _kinds(again),
         "workload": f"TT-SVD of a dense {name} fp32 tensor ({math.prod(shape) * 4 / 2 ** 30:.0f} GiB resident) to ranks_tt=16: the largest "
