@@ -173,7 +173,10 @@ int ttr_qr_factor_pushed_sum(int dtype, int64_t k, int64_t I, int64_t batch,
 int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch,
                         void* workspace, int64_t workspace_bytes,
                         const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
-                        void* Out, int64_t ldo, int64_t strideO, void* stream);
+                        void* Out, int64_t ldo, int64_t strideO, int skip_zero_rows, void* stream);
+/* `skip_zero_rows` != 0: for the items whose factorisation packed its rows (TTR_KNOB_QR_PACK; flags at
+ * ttr_qr_pushed_flag_offset) the exactly-zero rows kk >= 32 of Out are NOT written -- a third of the kernel's HBM traffic; the
+ * caller then reads Out only through kernels that take the item's flag (`rows32` of ttr_rowgram / ttr_rotgram / ttr_project). */
 /*
  * ttr_qr_apply_pushed that ALSO emits the row Gram matrix of its output, G = M M^T of the k x (I*kcols) right unfolding M of
  * Out (round.py:104-109: what the truncation of the next bond computes first), accumulated from the output tiles while
@@ -372,7 +375,8 @@ int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
  * zero rows kk >= 32). */
 int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch);
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
-                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip, void* stream);
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip,
+                const int32_t* rows32, void* stream);
 /*
  * When is the second pass needed?  The first Gram matrix G = M M^T carries sigma_i^2 with an ABSOLUTE error of c eps sigma_1^2
  * (c: a small constant of the fp32 accumulation), i.e. sigma_i and the unit norm of row i of `right` to c eps (sigma_1 /

@@ -87,7 +87,7 @@ _SIGNATURES = {
     "ttr_qr_apply_pushed": (
         c_int,
         [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
-         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p],
     ),
     "ttr_qr_apply_pushed_gram_parts": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "ttr_qr_apply_pushed_gram": (
@@ -128,7 +128,7 @@ _SIGNATURES = {
     "ttr_qr_pushed_flag_offset": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ttr_rotgram": (
         c_int,
-        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     ),
     "ttr_project": (
         c_int,
@@ -487,7 +487,7 @@ def qr_factor_pushed_sum(Rm: torch.Tensor, a4: torch.Tensor, b4: torch.Tensor) -
 
 @_on_device
 def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int] = None,
-             out: Optional[torch.Tensor] = None, want_gram: bool = False):
+             out: Optional[torch.Tensor] = None, want_gram: bool = False, skip_zero_rows: bool = False):
     """Out [batch, m, kcols] = Q @ C  (C: [batch, k, kcols]; None -> first ``kcols`` columns of Q).
     ``out``: optional contiguous destination (e.g. a batch slice of a larger result).
     ``want_gram``: return ``(Out, G)``; G = split partials [batch, parts, k, k] of the row Gram matrix of Out's
@@ -520,8 +520,11 @@ def qr_apply(f: QrFactors, C: Optional[torch.Tensor] = None, kcols: Optional[int
                                               Out.data_ptr(), kcols, f.m * kcols, G.data_ptr(), _stream())
             _check(code, "ttr_qr_apply_pushed_gram")
         else:
+            # skip_zero_rows: the rows kk >= 32 of packed items (f.rows32) stay unwritten -- only for results that are read
+            # through the rows32-aware kernels (rowgram / rotgram / project)
             code = L.ttr_qr_apply_pushed(dt, k, I, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
-                                         Out.data_ptr(), kcols, f.m * kcols, _stream())
+                                         Out.data_ptr(), kcols, f.m * kcols, int(bool(skip_zero_rows and f.rows32 is not None)),
+                                         _stream())
             _check(code, "ttr_qr_apply_pushed")
         return (Out, G) if want_gram else Out
     code = L.ttr_qr_apply(dt, f.m, f.n, f.batch, f.ws.data_ptr(), f.wsb, cptr, ldc, sC, kcols,
@@ -779,7 +782,8 @@ def rowgram(M: torch.Tensor, V1: Optional[torch.Tensor] = None, skip: Optional[t
         V1, ldv, sV = _mat(V1)
         assert V1.shape == (batch, R, R)
         _check(L.ttr_rotgram(dt, R, n, batch, M.data_ptr(), ldm, sM, V1.data_ptr(), ldv, sV, G.data_ptr(), parts,
-                             skip.data_ptr() if skip is not None else None, _stream()),
+                             skip.data_ptr() if skip is not None else None,
+                             rows32.data_ptr() if rows32 is not None else None, _stream()),
                "ttr_rotgram")
     return G
 

@@ -606,7 +606,7 @@ def truncate(
                     # an item the top-r kernel decided on eigenvalues carries ONLY its r leading eigenpairs: it must pass through,
                     # also when the same test on sigma = sqrt(lambda) rounds to the other side of the threshold ([B] int32 flags)
                     flat = torch.maximum(flat, top_flat)
-            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1, skip=flat), _hip.EIG_RAW, use_delta, delta2, cap,
+            V, sig, info = _hip.eigh_trunc(_hip.rowgram(M, V1, skip=flat, rows32=rows32), _hip.EIG_RAW, use_delta, delta2, cap,
                                            abs_floor=_hip.SOLVER_JACOBI_LIVE, delta2_dev=delta2_dev,
                                            skip_items=flat, sigma_in=sig1 if flat is not None else None)
         else:
@@ -1015,11 +1015,11 @@ if _FUSE_APPLY_GRAM:   # (its epilogue assumes the unpacked row map of the level
     _hip.set_knob(_hip.KNOB_QR_PACK, 0)
 
 
-def _apply_q(f, C: torch.Tensor, out: Optional[torch.Tensor] = None, want_gram: bool = False):
+def _apply_q(f, C: torch.Tensor, out: Optional[torch.Tensor] = None, want_gram: bool = False, skip_zero_rows: bool = False):
     if isinstance(f, _ExplicitQ):
         Q = _hip.gemm(f.Q, C, out=out)
         return (Q, None) if want_gram else Q
-    return _hip.qr_apply(f, C, out=out, want_gram=want_gram)
+    return _hip.qr_apply(f, C, out=out, want_gram=want_gram, skip_zero_rows=skip_zero_rows)
 
 
 # Sub-batch streams.  Within one tensor train the sweeps are a dependency chain, and some of its kernels are
@@ -1232,11 +1232,13 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
             if _FUSE_APPLY_GRAM:
                 M4, gram = _apply_q(f, left, want_gram=True)  # the apply kernel also accumulates M M^T where it can
             else:
-                M4 = _apply_q(f, left)
+                # (the carry only goes to the rows32-aware Gram / projection kernels below: the exactly-zero rows kk >= 32 of a
+                # packed item stay unwritten)
+                M4 = _apply_q(f, left, skip_zero_rows=(r0 == 64 and I * left.shape[2] >= 64))   # (>= 64 columns: the fused row kernels)
             M4 = M4.reshape(f.batch, r0, I, left.shape[2])
         Bt, R, I, rn = M4.shape
         # rows kk >= 32 of the carry are exactly zero for the items whose QR of this bond packed its rows
-        r32 = getattr(facs[mu][0], "rows32", None) if (mu < N - 1 and R == 64) else None
+        r32 = getattr(facs[mu][0], "rows32", None) if (mu < N - 1 and R == 64 and I * rn >= 64) else None
         alloc = None
         if arena is not None:
             def alloc(r, mu=mu, n=I * rn):

@@ -536,7 +536,7 @@ int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch
                                   int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
 int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
-                             int64_t strideO, void* G, hipStream_t stream);
+                             int64_t strideO, void* G, hipStream_t stream, int skip_zero_rows = 0);
 int64_t qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kc);
 int qr_max_cols(int dtype);
 int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
@@ -725,13 +725,13 @@ int ttr_qr_factor_pushed_sum(int dtype, int64_t k, int64_t I, int64_t batch, con
 
 int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* workspace,
                         int64_t workspace_bytes, const void* C, int64_t ldc, int64_t strideC, int64_t kcols, void* Out,
-                        int64_t ldo, int64_t strideO, void* stream) {
+                        int64_t ldo, int64_t strideO, int skip_zero_rows, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_qr_apply_pushed: bad dtype %d", dtype);
   TTR_REQUIRE(batch >= 0 && kcols >= 1 && kcols <= n, TTR_E_INVALID, "ttr_qr_apply_pushed: bad arguments");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(Out && workspace, TTR_E_INVALID, "ttr_qr_apply_pushed: null pointer");
   return qr_apply_pushed_dispatch(dtype, k, I, n, batch, workspace, workspace_bytes, C, ldc, strideC, kcols, Out, ldo,
-                                  strideO, nullptr, (hipStream_t)stream);
+                                  strideO, nullptr, (hipStream_t)stream, skip_zero_rows ? 1 : 0);
 }
 
 int64_t ttr_qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kcols) {
@@ -915,12 +915,13 @@ int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch
 }
 
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
-                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip, void* stream) {
+                const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip,
+                const int32_t* rows32, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_rotgram: bad dtype %d", dtype);
   TTR_REQUIRE(R >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_rotgram: bad shape");
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(M && G && V1, TTR_E_INVALID, "ttr_rotgram: null pointer");
-  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream, skip);
+  return sweep_gram_dispatch(dtype, R, n, batch, M, ldm, strideM, V1, ldv1, strideV1, G, nparts, (hipStream_t)stream, skip, rows32);
 }
 
 int ttr_eigsel_max_n(void) { return eigsel_max_n(); }

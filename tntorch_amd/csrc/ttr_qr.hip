@@ -959,6 +959,8 @@ struct QrApply {
   long long* dbg;  // optional: cycle stamps of block (0, 0) (diagnostics)
   const int32_t* pack_flag;  // level 0 of a PUSHED factorisation: != 0 for items the factor kernel packed (see QrLevel)
   int grid_swap;             // grid (batch, nb) instead of (nb, batch): block-major launch order (see QrLevel)
+  int skip_zero_rows;        // != 0: the exactly-zero rows kk >= 32 of a packed item's output are NOT written (the caller only reads
+                             // the result through kernels that take the item's rows32 flag: ttr_rowgram / ttr_rotgram / ttr_project)
 };
 
 template <typename T, int NT, int NTC, int NW>
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #pragma unroll
           for (int tc = 0; tc < NTC; ++tc) {
             o[(int64_t)((tm & 1) * 16 + M::row(0, r)) * kstride + tc * PW] = C[tm][tc][r];
-            o[(int64_t)((tm & 1) * 16 + M::row(0, r) + 32) * kstride + tc * PW] = T(0);
+            if (!p.skip_zero_rows) o[(int64_t)((tm & 1) * 16 + M::row(0, r) + 32) * kstride + tc * PW] = T(0);
           }
       }
     } else {
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
           for (int tc = 0; tc < NTC; ++tc) {
             if (tc * PW + cl < kc) {
               o[kk * kstride + tc * PW] = C[tm][tc][r];
-              o[(kk + 32) * kstride + tc * PW] = T(0);
+              if (!p.skip_zero_rows) o[(kk + 32) * kstride + tc * PW] = T(0);
             }
           }
         }
@@ -1380,7 +1382,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
 template <typename T, int NT, int NTC>
 static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const QrPlan& pl, const T* C, int64_t ldc,
                      int64_t strideC, int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream,
-                     int64_t o_cs = 1) {
+                     int64_t o_cs = 1, int skipz = 0) {
   const int L = pl.levels;
   for (int l = L - 1; l >= 0; --l) {
     QrApply<T> p;
@@ -1396,6 +1398,7 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
     p.Gp = (l == 0) ? Gp : nullptr;
     p.pack_flag = (l == 0 && pk > 0) ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
+    p.skip_zero_rows = (l == 0) ? skipz : 0;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     ProfScope prof(TTR_PROF_QR_APPLY, stream);
     p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? 1 : 0;
@@ -1441,16 +1444,16 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
 
 template <typename T, int NT>
 static int apply_nt(int64_t m, int n, int64_t batch, T* ws, const QrPlan& pl, const T* C, int64_t ldc, int64_t strideC,
-                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream, int64_t o_cs) {
-  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
-  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
-  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs);
+                    int kc, T* Out, int64_t ldo, int64_t strideO, int pk, int pI, T* Gp, hipStream_t stream, int64_t o_cs, int skipz) {
+  if (kc <= 16) return apply_run<T, NT, 1>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs, skipz);
+  if (kc <= 32) return apply_run<T, NT, 2>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs, skipz);
+  return apply_run<T, NT, 4>(m, n, batch, ws, ws, pl, C, ldc, strideC, kc, Out, ldo, strideO, pk, pI, Gp, stream, o_cs, skipz);
 }
 
 template <typename T>
 static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C, int64_t ldc,
                        int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO, int pk, int pI, void* Gp,
-                       hipStream_t stream, int64_t o_cs = 1) {
+                       hipStream_t stream, int64_t o_cs = 1, int skipz = 0) {
   if (batch > kMaxBatchSlice) {
     TTR_REQUIRE(ws_bytes >= qr_workspace_bytes(sizeof(T) == 8 ? TTR_F64 : TTR_F32, m, n, batch), TTR_E_WORKSPACE,
                 "ttr_qr_apply: workspace too small for batch %lld", (long long)batch);
@@ -1460,7 +1463,7 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
       const int64_t wsb = make_plan(m, n, nb, sizeof(T) == 8).total * (int64_t)sizeof(T);
       const int rc = apply_typed<T>(m, n, nb, wsp, wsb, C ? (const void*)((const T*)C + b0 * strideC) : nullptr, ldc, strideC, kc,
                                     (T*)Out + b0 * strideO, ldo, strideO, pk, pI,
-                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb, sizeof(T) == 8).nb[0] * (int64_t)(64 * 64)) : nullptr, stream, o_cs);
+                                    Gp ? (void*)((T*)Gp + b0 * make_plan(m, n, nb, sizeof(T) == 8).nb[0] * (int64_t)(64 * 64)) : nullptr, stream, o_cs, skipz);
       if (rc != TTR_OK) return rc;
       wsp += wsb;
     }
@@ -1472,9 +1475,9 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
   TTR_REQUIRE(kc >= 1 && kc <= 64 && kc <= n, TTR_E_UNSUPPORTED, "ttr_qr_apply: kcols = %lld outside [1, min(n, 64)]",
               (long long)kc);
   switch (nt_for(n)) {
-    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
-    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
-    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs);
+    case 1: return apply_nt<T, 1>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs, skipz);
+    case 2: return apply_nt<T, 2>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs, skipz);
+    default: return apply_nt<T, 4>(m, (int)n, batch, (T*)ws, pl, (const T*)C, ldc, strideC, (int)kc, (T*)Out, ldo, strideO, pk, pI, (T*)Gp, stream, o_cs, skipz);
   }
 }
 
@@ -1566,15 +1569,15 @@ int64_t qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, i
 
 int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch, void* ws, int64_t ws_bytes,
                              const void* C, int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo,
-                             int64_t strideO, void* G, hipStream_t stream) {
+                             int64_t strideO, void* G, hipStream_t stream, int skip_zero_rows) {
   const int rc = pushed_ok(dtype, k, 1, I, n);
   if (rc != TTR_OK) return rc;
   TTR_REQUIRE(!G || (qr_apply_pushed_gram_parts(dtype, k, I, n, kc) > 0 && ldo == kc), TTR_E_UNSUPPORTED,
               "ttr_qr_apply_pushed_gram: shape not covered by the fused Gram epilogue (see ttr_qr_apply_pushed_gram_parts)");
   const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32)
-    return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, G, stream);
-  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, nullptr, stream);
+    return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, G, stream, 1, skip_zero_rows);
+  return apply_typed<double>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, nullptr, stream, 1, skip_zero_rows);
 }
 
 }  // namespace ttr

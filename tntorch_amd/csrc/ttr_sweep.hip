@@ -148,12 +148,13 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
     // load).  The kernel runs at ~80 % of the fp32 MFMA rate like this (measured): wider loads only cost registers.
     int64_t cb, ce;
     split_range((p.n + 15) / 16, p.nsplit, split, cb, ce);
+    const int Rl = (p.rows32 && p.rows32[b] != 0 && R > 32) ? 32 : R;   // (zero rows 32..: not loaded -- they may not even be written)
     auto load_cols = [&](int64_t c, T (&a)[16]) {
       const int64_t c0 = c * 16;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const int k = 4 * ks + g;
-        a[ks] = (k < R && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
+        a[ks] = (k < Rl && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
       }
     };
     T a[16], an[16];
