@@ -164,13 +164,26 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // entry point takes any matrix.
     bool lower_nz = false;
     T sq_all = T(0), sq_low = T(0);
-    for (int idx = tid; idx < 64 * 64; idx += NTH) {
-      const int kk = idx >> 6, r0 = idx & 63;
-      const T rv = (kk < p.pk && r0 < p.pRin) ? Rm[(int64_t)kk * p.ldrm + r0] : T(0);
-      lower_nz = lower_nz || (kk > r0 && rv != T(0));
-      sq_all += rv * rv;
-      if (kk >= 32) sq_low += rv * rv;
-      Rs[kk * RLD + r0] = rv;
+    {
+      // all loads of the thread first (unconditional, from clamped offsets), then the stores: as one loop every iteration
+      // waited for its own global round trip -- eight in a row, ~20 k cycles at the head of every block (ISA, round 4)
+      constexpr int NE = 64 * 64 / NTH;
+      T rvv[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * NTH, kk = idx >> 6, r0 = idx & 63;
+        const bool ok = kk < p.pk && r0 < p.pRin;
+        rvv[e] = Rm[ok ? (int64_t)kk * p.ldrm + r0 : 0];
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * NTH, kk = idx >> 6, r0 = idx & 63;
+        const T rv = (kk < p.pk && r0 < p.pRin) ? rvv[e] : T(0);
+        lower_nz = lower_nz || (kk > r0 && rv != T(0));
+        sq_all += rv * rv;
+        if (kk >= 32) sq_low += rv * rv;
+        Rs[kk * RLD + r0] = rv;
+      }
     }
     wave_sum2(sq_all, sq_low);
     if (lane == 0) {
@@ -248,15 +261,21 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
             }
           }
         };
-        auto run_pass = [&]() {   // group 0 of the pass is already in bvA
+        // group 0 of the pass is already in bvA.  `im_next` >= 0: the first group of the NEXT pass (the absorbed block's mode
+        // index) is requested as soon as bvA is free, i.e. under the last group's MFMAs (an even number of groups; otherwise
+        // the caller loads it)
+        auto run_pass = [&](int im_next) -> bool {
+          bool prefetched = false;
           for (int grp = 0; grp < ngroups; grp += 2) {
             if (grp + 1 < ngroups) load_group(grp + 1, bvB);
             mma_group(grp, bvA);
             if (grp + 1 < ngroups) {
               if (grp + 2 < ngroups) load_group(grp + 2, bvA);
+              else if (im_next >= 0) { im_cur = im_next; load_group(0, bvA); prefetched = true; }
               mma_group(grp + 1, bvB);
             }
           }
+          return prefetched;
         };
         load_group(0, bvA);  // in flight while Rs is being staged (the same mode index whether the block packs or not)
         lds_barrier();
@@ -277,12 +296,12 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
           for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
         if (packed) tm_hi = 2;
-        run_pass();
+        const bool pre = run_pass(packed ? NW * partner_blk + wave_id : -1);
         if (packed) {   // second pass: the absorbed block's mode index into row tiles 2, 3 (Rm rows 0 .. 31 again)
           im_cur = NW * partner_blk + wave_id;
           tm_lo = 2; tm_hi = 4; tm_sub = 2;
-          load_group(0, bvA);
-          run_pass();
+          if (!pre) load_group(0, bvA);
+          (void)run_pass(-1);
         }
       };
       if (full) stream(IC<1>{});

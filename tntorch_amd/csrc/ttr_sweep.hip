@@ -99,14 +99,18 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
   Acc G[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) G[i] = M::zero();
+  // (row tiles of an item whose rows 32.. are exactly zero -- rows32 -- are skipped: 3 of the 10 tile products remain)
+  const int ntl = (IDENT && p.rows32 && p.rows32[b] != 0 && R > 32) ? 2 : 4;
   auto gram_update = [&](const Acc (&mw)[4]) {
     int idx = 0;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int tj = ti; tj < 4; ++tj) {
+        if (tj < ntl) {   // block-uniform
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
+          for (int r = 0; r < 4; ++r) G[idx] = M::mma(mw[ti][r], mw[tj][r], G[idx]);
+        }
         ++idx;
       }
   };
