@@ -551,6 +551,14 @@ def main():
                     "end": "ONE RCCL gather of the packed cores after the last step (inside the timed region)",
                     "none": "no gather"}[args.gather]) if dist_on else "single GPU",
             },
+            # data-dependent shortcuts that fire on this input (all decided per item on the device; knobs: include/ttround_hip.h)
+            "shortcuts": {
+                "input_structure": "t = g + g: every unfolding / R factor has numerical rank 32 of 64",
+                "qr_rank_skip": "panels whose remaining part is below 8 eps of their block are H = I (TTR_KNOB_QR_RANK_SKIP): 2 of 4 panels per block",
+                "qr_row_packing": "R factors of numerical rank <= 32: two mode indices per wave, half the level-0 blocks, block-major launch (TTR_KNOB_QR_PACK = 3)",
+                "rows32": "the carry of a packed bond has exactly zero rows 32..: not written by the apply, not loaded by rowgram / rotgram / project",
+                "flat_spectrum": "kept singular values within a factor 8: pass 2 skipped, pass 1 by the top-r solver",
+            },
             "nccl_ranks": nccl_ranks,
             "gather": gather_info,
             "allocator": getattr(timed_steps, "allocator", None),
