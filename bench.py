@@ -621,7 +621,7 @@ def main():
                         return t
                     el, _, _ = timed_steps(bstep, lambda: None, torch.cuda.synchronize, 2, 5)
                     extras["batch_4096"] = {"tensors_per_step": 2 * B, "ms_per_step": el / 5 * 1e3, "cores_per_s": 2 * B * N_CORES * 5 / el}
-                    del big
+                    del big, bstep   # (the closure's default argument holds the 26 GB input too)
                 except Exception as e:  # noqa: BLE001
                     extras["batch_4096"] = {"error": repr(e)[:200]}
                 torch.cuda.empty_cache()
@@ -649,7 +649,7 @@ def main():
                     ent["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in pk.items() if v["launches"] > 0}
                     ent["oracle_check"] = decaying_parity(dinp, dout, 0)
                     extras[f"decaying_spectrum_{decay}"] = ent
-                    del dinp, dout
+                    del dinp, dout, dstep   # (the closure's default argument holds the input too)
                 except Exception as e:  # noqa: BLE001
                     extras[f"decaying_spectrum_{decay}"] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
