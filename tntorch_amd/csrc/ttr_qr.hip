@@ -328,7 +328,24 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
       const T* __restrict__ Ca = p.Cn + bt * p.strideCn + (int64_t)imode * ca;
       const T* __restrict__ Cb = p.Cn2 + bt * p.strideCn2 + (int64_t)imode * cb;
       const int64_t sa = (int64_t)p.pI * ca, sb = (int64_t)p.pI * cb;
+      // (round 4: the loads of a K step are issued together, from clamped addresses, and the NEXT step's loads before this
+      // step's MFMAs -- as one load-use loop the phase was ksteps x NT serial global round trips, 64 for a 64 x 64 x 64 core)
+      auto load_step = [&](int ks, T (&bv)[NT]) {
+        const int r0 = ks * 4 + g;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          const int col = tn * PW + cl;
+          const bool in_a = col < ca;
+          const bool ok = ivalid && r0 < p.pRin && col < n && (in_a ? r0 < ra : r0 >= ra);
+          const T* __restrict__ src = in_a ? Ca + (ok ? (int64_t)r0 * sa + col : 0) : Cb + (ok ? (int64_t)(r0 - ra) * sb + (col - ca) : 0);
+          const T v = *src;
+          bv[tn] = ok ? v : T(0);
+        }
+      };
+      T bcur[NT], bnxt[NT];
+      if (ksteps > 0) load_step(0, bcur);
       for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) load_step(ks + 1, bnxt);
         const int r0 = ks * 4 + g;
         T av[4];
 #pragma unroll
@@ -338,15 +355,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           const int c0 = tn * PW;
           const bool all_a = c0 + PW <= ca, all_b = c0 >= ca;  // wave-uniform
           if ((all_a && ks * 4 >= ra) || (all_b && ks * 4 + 3 < ra)) continue;  // this tile's rows of the step are all zero
-          const int col = c0 + cl;
-          T bvv = T(0);
-          if (ivalid && r0 < p.pRin && col < n) {
-            if (col < ca) { if (r0 < ra) bvv = Ca[(int64_t)r0 * sa + col]; }
-            else if (r0 >= ra) bvv = Cb[(int64_t)(r0 - ra) * sb + (col - ca)];
-          }
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = M::mma(av[tm], bvv, acc[tm][tn]);
+          for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = M::mma(av[tm], bcur[tn], acc[tm][tn]);
         }
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) bcur[tn] = bnxt[tn];
       }
     }
     if (p.pack_flag && b == 0 && tid == 0) p.pack_flag[bt] = packed ? p.pack_ok : 0;
