@@ -656,6 +656,55 @@ def test_eigh_live_graded(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("parts", [1, 3])
+def test_eigh_live_prefix(dt, parts):
+    """TTR_SOLVER_JACOBI_LIVE, n = 64, restricts the solve to the leading block that holds every live index (G_ii above
+    (n eps)^2 max G_ii): items whose frozen tail is exactly zero (a packed bond: blockdiag(G11, 0)), items with a noise-level
+    tail coupled to the live block (frozen indices keep e_i and their own diagonal entry, sorted into place), an item with a live
+    index at the very end (nothing to cut) and a pass-through item."""
+    h = _hip()
+    g = torch.Generator().manual_seed(29)
+    B, n, m = 6, 64, 300
+    eps = torch.finfo(dt).eps
+    s = 2.0 ** (-0.4 * torch.arange(32, dtype=torch.float64))
+    rows = torch.zeros(B, n, m, dtype=torch.float64)
+    W = torch.linalg.qr(torch.randn(B, 32, 32, generator=g, dtype=torch.float64))[0]
+    W = torch.eye(32, dtype=torch.float64) + 1e-2 * (W - torch.eye(32, dtype=torch.float64))
+    Q = torch.linalg.qr(torch.randn(B, m, 32, generator=g, dtype=torch.float64))[0]
+    rows[:, :32] = (W * s[None, None, :]).transpose(1, 2) @ Q.transpose(1, 2)
+    noise = (0.01 * n * eps) * torch.randn(B, 32, m, generator=g, dtype=torch.float64) / m ** 0.5   # far below the frozen threshold
+    rows[2, 32:] = noise[2]
+    rows[3, 32:] = noise[3]
+    rows[4, 32:] = noise[4]
+    rows[4, 63] = 1e-2 * torch.randn(m, generator=g, dtype=torch.float64) / m ** 0.5                # item 4: live index 63
+    G = rows @ rows.transpose(1, 2)
+    Gp = (torch.stack([G * w for w in (0.5, 0.25, 0.25)], dim=1) if parts > 1 else G).to(dt).cuda()
+    skip = torch.tensor([0, 0, 0, 0, 0, 1], dtype=torch.int32, device="cuda")
+    sin = torch.rand(B, n, generator=g, dtype=torch.float64).sort(dim=1, descending=True).values.to(dt).cuda()
+    delta2 = float((noise[2] ** 2).sum()) * 4
+    V, sg, info = h.eigh_trunc(Gp, h.EIG_RAW, True, delta2, n, abs_floor=h.SOLVER_JACOBI_LIVE, skip_items=skip, sigma_in=sin)
+    V, sg, info = V.cpu().double(), sg.cpu().double(), info.cpu()
+    assert torch.equal(sg[5], sin[5].cpu().double()) and torch.equal(V[5], torch.eye(n, dtype=torch.float64))
+    Gd = (Gp.double().sum(dim=1) if parts > 1 else Gp.double()).cpu()
+    sref = torch.linalg.eigvalsh(Gd).flip(-1).clamp_min(0).sqrt()
+    for b in range(5):
+        assert (sg[b, :-1] >= sg[b, 1:]).all()                                           # sorted over the whole spectrum
+        assert (V[b].T @ V[b] - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
+        live = sref[b] > 4 * n * eps * sref[b, 0]
+        assert (((sg[b] - sref[b]).abs() / sref[b])[live]).max() < tol(dt, 2e-4, 1e-10)
+        assert (sg[b] - sref[b]).abs().max() < 4 * n * eps * sref[b, 0]
+        Rw = V[b].T @ rows[b]
+        Rn = Rw[live] / Rw[live].norm(dim=1, keepdim=True)
+        assert (Rn @ Rn.T - torch.eye(int(live.sum()), dtype=torch.float64)).abs().max() < tol(dt, 5e-4, 1e-9)
+        # the rank rule saw the whole spectrum: the longest tail with sum(sigma^2) <= delta2
+        tails = torch.cumsum((sg[b] ** 2).flip(0), 0).flip(0)
+        assert int(info[b]) == max(1, int((tails.to(dt) > torch.tensor(delta2, dtype=dt)).sum()))
+    for b in (0, 1):   # exactly zero tail: unit vectors, zero sigma, no coupling
+        assert (sg[b, 32:] == 0).all() and torch.equal(V[b, 32:, 32:], torch.eye(32, dtype=torch.float64))
+        assert (V[b, :32, 32:] == 0).all() and (V[b, 32:, :32] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("columns", [False, True])
 def test_orth_fixup(dt, columns):
     h = _hip()

@@ -290,9 +290,9 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_kernel(int r, int64_t n, 
 // (one pass, column chunks through LDS, products and sums in double), Gram-Schmidt of the dead
 // rows IN COEFFICIENT SPACE against everything before them (r x r matrices in LDS, double; the live rows are orthonormal
 // already and stay untouched), then X_dead <- W X in a second pass.  A dead vector whose remainder collapses (below 1 % of its
-// norm, or a zero / non-finite vector) is replaced by a hashed pseudo-random one, which the next round orthogonalises.  Two
-// rounds ("twice is enough": the second sees a Gram matrix within rounding of the identity), a third / fourth only after a
-// replacement.  Same semantics as the kernel above: genuine remainders are kept, live vectors are not touched.
+// norm, or a zero / non-finite vector) is replaced by a hashed pseudo-random one, which the next round orthogonalises.  A second
+// round when a remainder lost more than half of its squared norm ("twice is enough": the second sees a Gram matrix within
+// rounding of the identity), a third / fourth only after a replacement.  Same semantics as the kernel above: genuine remainders are kept, live vectors are not touched.
 constexpr int kOfMaxE = 32;        // tile elements per thread: r x CW <= 32 x 256 (CW = 256 up to 32 vectors, 128 above)
 
 inline size_t orth_fixup_lds_bytes(int r, int cw, size_t es) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
         }
     }
     if (tid < 64) regen[tid] = 0;
-    if (tid == 0) any_regen[0] = 0;
+    if (tid == 0) { any_regen[0] = 0; any_regen[1] = 0; }
     __syncthreads();
     // ---- the dead rows against everything before them, in coefficient space (double).  The live rows are orthonormal
     // (S_LL = I to rounding), so the remainders x_d - S_dL x_L have the Gram matrix C = S_DD - S_DL S_LD; with C = L L^T
@@ -433,6 +433,7 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
       if (tid > a && tid < nd) Cm[tid * ls + a] *= dinv; // (collapsed: the column is removed)
       if (tid == a) Cm[a * ls + a] = bad ? 1.0 : piv * dinv;
       if (tid == 0 && bad) { regen[first + a] = 1; any_regen[0] = 1; }
+      if (tid == 0 && !(piv > 0.5 * saa)) any_regen[1] = 1;   // lost more than half of its squared norm: orthogonalise twice
       __syncthreads();
       if (!bad) {
         const int rem = nd - a - 1;
@@ -503,7 +504,12 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
       }
     }
     __syncthreads();
-    if (round >= 1 && !any_regen[0]) break;
+    // "twice is enough" (Kahan / Parlett): a remainder that kept at least 1 / sqrt(2) of its vector's norm is orthogonal to
+    // the others to ~1.4 eps already -- the second round is only run when some vector lost more (or was replaced).  (Measured,
+    // round 4: on the decaying-spectrum batch every item needs it -- the dead rows are mostly leakage of the live ones.  Starting
+    // the dead rows from hashed vectors instead, one round: 11.3 -> 6.7 ms per step, but the approximation error of that batch
+    // rose from 8.6e-6 to 2.4e-5 -- the dead rows do carry part of the tail; not taken.)
+    if (!any_regen[0] && (round >= 1 || !any_regen[1])) break;
     __syncthreads();
   }
 }

@@ -110,8 +110,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   if (p.skip_flag && *p.skip_flag != 0) return;  // (wave-uniform: one word for the whole launch)
   const int tid = threadIdx.x;
   const int64_t bt = blockIdx.x;
-  const int n = p.n;
+  const int nf = p.n;
   if (p.skip_items && p.skip_items[bt] != 0) {  // (block-uniform) pass-through item, see EighArgs
+    const int n = nf;
     T* __restrict__ Vo = p.V + bt * p.strideV;
     for (int idx = tid; idx < n * n; idx += kThreads) {
       const int i = idx / n, j = idx - i * n;
@@ -144,6 +145,30 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
     return;
   }
+  // TTR_SOLVER_JACOBI_LIVE, n <= 64 (round 4): the solve is restricted to the LIVE PREFIX.  Indices with G_ii <= (n eps)^2 max G_ii
+  // are frozen (below): they never rotate, their eigenvector stays e_i and nothing that is read afterwards depends on their
+  // rows / columns -- so when every index from nl on is frozen (pass 1 sorts: the frozen ones are the tail), working on the
+  // leading nl x nl block gives the same result with (nl / n)^3 of the work.  A bond whose carry has zero rows 32.. (packed QR)
+  // has nl <= 32; a decaying bond sigma_j ~ 2^(-j/2) has nl = 34 of 64.  Decided from the diagonal (read from global memory by
+  // every wave, lane = index), before the LDS is carved; the tail's diagonal entries stay in registers for the epilogue's sort.
+  int nl = nf;
+  T dtail = T(0);
+  if (LDSRES && p.abs_floor == TTR_SOLVER_JACOBI_LIVE && !p.pair_tab && nf <= 64 && nf > 2) {
+    const int l = tid & 63;
+    if (l < nf) {
+      const T* __restrict__ Gd = p.G + bt * p.strideG + (int64_t)l * p.ldg + l;
+      dtail = Gd[0];
+      for (int pt = 1; pt < p.gparts; ++pt) dtail += Gd[pt * p.stride_gpart];   // (the summation order of the matrix load below)
+    }
+    T gmx = l < nf ? fabs(dtail) : T(0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmx = fmax(gmx, __shfl_xor(gmx, off, 64));
+    const T thr0 = (T)nf * Num<T>::eps();
+    const unsigned long long lv = __ballot(l < nf && !(dtail <= thr0 * thr0 * gmx));
+    nl = lv ? 64 - __clzll(lv) : 1;
+    if (nl < 2) nl = 2;
+  }
+  const int n = nl;
   const int ld = n + 1;
   const int ne = n + (n & 1);  // even number of players (phantom index n if n is odd)
   const int np = ne / 2;
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T* Gs;
   T* Vs;
   if (LDSRES) {
-    Vs = sg + 2 * ((n + 1) & ~1) + 2;
+    Vs = sg + 2 * ((nf + 1) & ~1) + 2;
     Gs = Vs + (size_t)n * ld;
   } else {
     Vs = p.ws + bt * (int64_t)2 * n * ld;
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       // G_ii <= (n eps)^2 max G_ii are the numerical null space of the input (their rows are rounding noise of the
       // pass-1 rotation): rotating them never terminates (the noise is regenerated by every update) and changes
       // nothing above the noise level, so they are frozen.
-      const T thr = (T)n * Num<T>::eps();
+      const T thr = (T)nf * Num<T>::eps();   // (nf: the thresholds do not depend on the live prefix)
       const T dead_below = thr * thr * gmax;
       for (int i = tid; i < n; i += kThreads) deadv[i] = (Gs[i * ld + i] <= dead_below) ? 1 : 0;
       __syncthreads();
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
 
   // LAPACK xGESVJ-style tolerance sqrt(n)*eps: with a bare eps the rounding noise of the updates keeps
   // regenerating off-diagonals at the eps level and the sweep loop never terminates.
-  const T eps = Num<T>::eps() * sqrt((T)n);
+  const T eps = Num<T>::eps() * sqrt((T)nf);
   const int m1 = ne - 1;
   const int k0 = tid / n, i0 = tid % n;            // item = tid + 256*e  <->  (k, i), advanced incrementally
   const int dk = kThreads / n, di = kThreads % n;
@@ -381,21 +406,22 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   }
 
   // ---- epilogue: clamp / sqrt / sort, Newton-Schulz re-orthogonalisation, permuted write, rank rule
-  T* sig = sg;            // [n] unsorted sigma
-  T* sig_sorted = sg + n; // [n]
-  int* posv = reinterpret_cast<int*>(smem_raw);  // [n] destination column of eigenvector i (the rotation table is
-                                                 // free now; its first array alone holds npad doubles >= n ints)
-  for (int i = tid; i < n; i += kThreads) {
-    T w = Gs[i * ld + i];
+  // (over all nf indices: the frozen tail beyond the live prefix takes part in the sort with its untouched diagonal entries)
+  T* sig = sg;             // [nf] unsorted sigma
+  T* sig_sorted = sg + nf; // [nf]
+  int* posv = reinterpret_cast<int*>(smem_raw);  // [nf] destination column of eigenvector i (the rotation table is free now:
+                                                 // 40 bytes per pair slot, at least 8 slots >= 64 ints when nf <= 64 > n)
+  for (int i = tid; i < nf; i += kThreads) {
+    T w = i < n ? Gs[i * ld + i] : dtail;        // (n < nf only when nf <= 64: tid = i = this lane's index)
     if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
     else { if (!(w > T(0))) w = T(0); }
     sig[i] = sqrt(w);
   }
   __syncthreads();
-  for (int i = tid; i < n; i += kThreads) {
+  for (int i = tid; i < nf; i += kThreads) {
     const T si = sig[i];
     int pos = 0;
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < nf; ++j) {
       const T sj = sig[j];
       pos += (sj > si) || (sj == si && j < i);
     }
@@ -427,10 +453,17 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j];
     }
   }
+  if (n < nf) {  // the frozen tail: unit eigenvectors, zeros elsewhere
+    for (int idx = tid; idx < nf * nf; idx += kThreads) {
+      const int row = idx / nf, j = idx - row * nf;
+      if (row >= n || j >= n) V[(int64_t)row * p.ldv + posv[j]] = (row == j) ? T(1) : T(0);
+    }
+  }
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
-  for (int i = tid; i < n; i += kThreads) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
+  for (int i = tid; i < nf; i += kThreads) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
   if (tid == 0) {
     int rank;
+    const int n = nf;   // (the rank rule sees the whole spectrum)
     const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
     if (sig_sorted[0] < T(1e-13)) {
       rank = 0;  // zero guard, round.py:137-145
