@@ -931,6 +931,53 @@ def test_eigh_top(dt, n, r):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("r", [32, 20])
+@pytest.mark.parametrize("parts", [1, 5])
+def test_eigh_top_zero_tail_is_solved_as_the_leading_block(dt, r, parts):
+    """ttr_eigh_top on 64 x 64 Gram matrices whose rows / columns 32.. are exactly zero (the carry of a packed bond): solved
+    as the leading 32 x 32 block.  Flat items: the r largest eigenpairs, zeros elsewhere; declined items (graded block): the
+    full decomposition blockdiag(V11, I) with 32 zero eigenvalues; rank / sigma / residuals as for the full-size solve.  An item
+    with one nonzero entry on the lower diagonal is not shrunk."""
+    h = _hip()
+    B, n = 12, 64
+    g = torch.Generator().manual_seed(100 + r + parts)
+    rows = torch.zeros(B, n, 200, dtype=torch.float64)
+    rows[:, :32] = torch.randn(B, 32, 200, generator=g, dtype=torch.float64)
+    rows[8:10, :32] *= (2.0 ** (-0.5 * torch.arange(32, dtype=torch.float64)))[None, :, None]     # graded: declined
+    rows[11, 40] = 0.5 * torch.randn(200, generator=g, dtype=torch.float64)                       # item 11: a live row below 32
+    G = rows @ rows.transpose(1, 2)
+    Gp = G.to(dt)
+    if parts > 1:
+        w = torch.tensor([0.5, 0.125, 0.125, 0.125, 0.125], dtype=dt)
+        Gp = Gp[:, None] * w[None, :, None, None]
+    Gd = (Gp.double().sum(dim=1) if parts > 1 else Gp.double())
+    V, sig, info, flat = h.eigh_top(Gp.cuda(), r, 0.125)
+    flat = flat.cpu()
+    assert flat[:8].tolist() == [1] * 8 and flat[8:10].tolist() == [0, 0]
+    it = flat.nonzero()[:, 0]
+    orth, res, serr = _top_errors(Gd[it].to(dt).cuda(), V[it.cuda()], sig[it.cuda()], r)
+    assert orth < tol(dt, 3e-6, 1e-14) and res < tol(dt, 3e-6, 1e-14) and serr < tol(dt, 3e-6, 1e-14)
+    assert float(V[it.cuda()][:, :, r:].abs().max()) == 0.0 and float(sig[it.cuda()][:, r:].abs().max()) == 0.0
+    assert info.cpu()[it].unique().tolist() == [r]
+    Vc, sc = V.cpu().double(), sig.cpu().double()
+    for b in range(10):
+        assert float(Vc[b, 32:, :32].abs().max()) == 0.0                                       # nothing leaks into the zero rows
+    for b in (8, 9):                                                                              # declined: the QL decomposition
+        assert torch.equal(Vc[b, 32:, 32:], torch.eye(32, dtype=torch.float64)) and float(sc[b, 32:].abs().max()) == 0.0
+        assert float(Vc[b, :32, 32:].abs().max()) == 0.0 and int(info[b]) == n      # (declined items: the full-size rank, as ever)
+        wref = torch.linalg.eigvalsh(Gd[b]).flip(-1).clamp_min(0)
+        assert ((sc[b] ** 2 - wref).abs().max() / wref[0]) < tol(dt, 2e-6, 1e-13)
+        assert (Gd[b] @ Vc[b] - Vc[b] * (sc[b] ** 2)[None, :]).abs().max() / wref[0] < tol(dt, 2e-5, 1e-12)
+        assert (Vc[b].T @ Vc[b] - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 1e-13)
+    # item 11 is a full-size problem: row 40 takes part
+    b = 11
+    k = r if int(flat[b]) else n
+    wref = torch.linalg.eigvalsh(Gd[b]).flip(-1).clamp_min(0)
+    assert ((sc[b, :k] ** 2 - wref[:k]).abs().max() / wref[0]) < tol(dt, 3e-6, 1e-13)
+    assert float(Vc[b, 40, :k].abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_eigh_top_declines_what_it_cannot_certify(dt):
     """Graded kept spectra, exactly and nearly multiple eigenvalues, identity, zero: flag 0 and the QL phase of the same launch
     delivers what ttr_eigh_trunc's tridiagonal solver delivers.  Pairs / triples just ABOVE the admitted distance (512 eps lambda_1)

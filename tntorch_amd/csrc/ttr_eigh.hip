@@ -614,8 +614,32 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   const int64_t bt = blockIdx.x;
-  const int n = p.n;
+  const int nf = p.n;
+  // Top-r launches (pass 1 of a batch-mode bond: G is a Gram matrix, so G_ii = 0 means a zero row / column): a 64 x 64 matrix whose
+  // diagonal is exactly zero from index 32 on -- the carry of a bond whose QR packed its rows (ttr_qr_pushed_flag_offset) -- is
+  // solved as its leading 32 x 32 block: half the reflectors at half the length, half the Sturm / twisted recurrences.  V comes
+  // out as blockdiag(V11, I) (qualified items: zeros beyond the r kept columns), sigma[32..] = 0.  Decided by every wave from the
+  // diagonal (lane = index), before the LDS is carved.
+  int n_shrunk = nf;
+  if (TOP && nf == 64) {
+    const T* __restrict__ Gd = p.G + bt * p.strideG + (int64_t)lane * p.ldg + lane;
+    T dg = T(0);
+    if (lane >= 32)
+      for (int pt = 0; pt < p.gparts; ++pt) dg += fabs(Gd[pt * p.stride_gpart]);
+    if (__ballot(dg != T(0)) == 0ull) n_shrunk = 32;
+  }
+  const int n = n_shrunk;
   const int ld = n + 1;
+  // beyond the solved block (n < nf): unit eigenvectors with zero eigenvalues, or nothing at all for an item of the top-r path
+  auto pad_tail = [&](bool ident, int t0, int nt) {
+    if (n == nf) return;
+    T* __restrict__ Vp = p.V + bt * p.strideV;
+    for (int idx = t0; idx < nf * nf; idx += nt) {
+      const int row = idx / nf, j = idx - row * nf;
+      if (row >= n || j >= n) Vp[(int64_t)row * p.ldv + j] = (ident && row == j) ? T(1) : T(0);
+    }
+    for (int i = n + t0; i < nf; i += nt) p.sigma[bt * p.stride_sigma + i] = T(0);
+  };
   T* A = reinterpret_cast<T*>(smem_raw);     // [n][ld]  G -> reflectors -> Q -> eigenvectors
   T* vs = A + n * ld + 3;                    // scratch region of 408 elements:
   T* wsv = vs + 64;                          //   wave 0: the broadcast arrays v / w of the tridiagonalisation (first 131 elements), then
@@ -631,13 +655,16 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale (both waves)
-  if (n == 64 && p.ldg == 64 && (p.stride_gpart & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
+  if ((n == 64 || (n == 32 && nf == 64)) && p.ldg == 64 && (p.stride_gpart & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(G) & (4 * sizeof(T) - 1)) == 0) {
     // a contiguous 64 x 64 matrix (+ split partials, e.g. the 8 per-block Gram partials of ttr_qr_apply_pushed_gram): four
     // elements per lane and load, the partials' loads of one position issued four at a time -- an element-wise loop has
     // one dependent load in flight per lane, which costs 20 us per partial and launch at B = 2048
     typedef T VT __attribute__((ext_vector_type(4)));
-    for (int it = 0; it < 8; ++it) {
-      const int e = (it * 2 * kWave + tid) * 4;
+    const int q4 = n >> 2;  // vectors of four per (stored) row of the block
+    for (int it = 0; it < (n * n) / (8 * kWave); ++it) {
+      const int q = it * 2 * kWave + tid, qr = q / q4;
+      const int e = qr * 64 + (q - qr * q4) * 4;   // element offset in the 64-column source
       const T* __restrict__ src = G + e;
       VT acc = *reinterpret_cast<const VT*>(src);
       int pt = 1;
@@ -717,7 +744,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   const bool vlive = lane < nvec && jv < rsel;
   T* const lamv = vsh;                                         // [64] eigenvalues (the tridiagonalisation's broadcast arrays are free by then)
   volatile int* const badf = meta + 3;                         // [1] some vector overflowed (a spare control word)
-  constexpr int ZLD = 36;                                      // Z[i][j] at A[i * ZLD + j] (A is free once Q sits in registers)
+  const int ZLD = n >= 40 ? 36 : n + 1;                        // Z[i][j] at A[i * ZLD + j] (A is free once Q sits in registers; n rows of <= 32 vectors fit A's n (n + 1))
   const T eps = Num<T>::eps();
   if (TOP && tid == 0) badf[0] = 0;
   // eigenvalues of this lane's group + the twisted factorisation of this lane's vector (everything a wave needs comes from
@@ -987,6 +1014,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
           const int row = idx / zc, c = rsel + idx - row * zc;
           Vo[(int64_t)row * p.ldv + c] = T(0);
         }
+        pad_tail(false, lane, kWave);
         return;
       }
       if (lane == 0 && p.top_flat) p.top_flat[bt] = 0;
@@ -1392,9 +1420,10 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     const int row = idx / n, j = idx - row * n;
     V[(int64_t)row * p.ldv + posv[j]] = A[row * ld + j];
   }
+  pad_tail(true, tid, 2 * kWave);
   if (tid == 0) {
     int rank;
-    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
+    const int64_t cap = p.rmax < (int64_t)nf ? p.rmax : (int64_t)nf;   // (nf: the zero eigenvalues beyond a shrunk block count)
     if (sig_sorted[0] < T(1e-13)) {
       rank = 0;  // zero guard, round.py:137-145
     } else if (!p.use_delta) {
