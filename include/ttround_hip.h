@@ -52,9 +52,9 @@ extern "C" {
                                 driver for n above the single-workgroup limit. */
 
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
-   ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top).  ttr_version() returns the value the library was built with; the Python
+   ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top; round 4: 8 = rows32 / skip_zero_rows, 9 = ttr_carry_rows32).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 8
+#define TTR_ABI_VERSION 9
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -245,9 +245,14 @@ int ttr_eigh_trunc(int dtype, int64_t n, int64_t batch,
  * The kernel decides PER ITEM whether that result can be trusted: the kept spectrum must be flat (sigma_r >= thr sigma_1 > 0, the
  * criterion of ttr_spectrum_flat) and free of close pairs (neighbouring kept eigenvalues >= 512 eps lambda_1 apart: inverse
  * iteration on isolated eigenvalues needs no reorthogonalisation beyond the Newton-Schulz polish).  flat[b] = 1: V[b][:, :r],
- * sigma[b][:r] = sqrt(lambda) (descending), the rest of V[b] / sigma[b] zero, info[b] = r.  flat[b] = 0: the item fell through to
+ * sigma[b][:r] = sqrt(lambda) (descending), the rest of V[b] / sigma[b] zero, info[b] = r.  flat[b] = 0 or 2: the item fell through to
  * the QL phase of the same launch and carries the full decomposition, exactly what ttr_eigh_trunc(eig_mode = TTR_EIG_RAW,
- * abs_floor = TTR_SOLVER_TRIDIAG, rmax = n) returns.  `flat` is optional.
+ * abs_floor = TTR_SOLVER_TRIDIAG, rmax = n) returns; 2 when its sigma pass ttr_spectrum_flat's batch-mode test (sigma_r >= thr
+ * sigma_1 > 0: declined for a close pair only), so that flat[b] != 0 IS the pass-through flag of the bond's second pass -- no
+ * ttr_spectrum_flat launch, no merge of two flag arrays (round 4; two launches per bond on a latency-bound chain).  `flat` is optional.
+ * A 64 x 64 matrix whose diagonal is exactly zero from index 32 on (the Gram matrix of a carry with zero rows 32.., a bond whose QR
+ * packed its rows) is solved as its leading 32 x 32 block (G must be a Gram matrix: G_ii = 0 => row i = 0): flat[b] = 1 as above,
+ * otherwise V[b] = blockdiag(V11, I), sigma[b][32:] = 0.
  */
 int ttr_eigh_top_ok(int64_t n, int64_t r);
 int ttr_eigh_top(int dtype, int64_t n, int64_t batch,
@@ -374,6 +379,13 @@ int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
  * byte offset ttr_qr_pushed_flag_offset (TTR_KNOB_QR_PACK: the carry ttr_qr_apply_pushed produces from such a factorisation has
  * zero rows kk >= 32). */
 int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch);
+/* The same flags for a carry that no fused push follows -- the LAST core of the left-to-right sweep, tensor.py:2053-2056's first
+ * truncation: flag[b] = 1 when rows 32.. of the 64 x cols matrix R[b] hold at most (c eps)^2 of ||R[b]||_F^2 (c =
+ * TTR_KNOB_QR_RANK_SKIP; the packing test of ttr_qr_factor_pushed).  The caller then hands `flag` to ttr_rowgram / ttr_rotgram /
+ * ttr_project as `rows32` for M = R x (last core): rows 32.. of M are below c eps ||M|| and are treated as zero, exactly as the
+ * packed push treats them at every other bond (ABI 9). */
+int ttr_carry_rows32(int dtype, int64_t cols, int64_t batch, const void* R, int64_t ldr, int64_t strideR, int32_t* flag,
+                     void* stream);
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1, void* G, int64_t nparts, const int32_t* skip,
                 const int32_t* rows32, void* stream);

@@ -21,3 +21,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_knobs(request):
+    """GPU tests that turn the library's diagnostic knobs (ttr_debug_set_knob) must not leak their setting into the tests that
+    run after them in the same process: the packing / rank-skip knobs are put back to their defaults after every GPU test."""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    import torch
+
+    if not torch.cuda.is_available():
+        return
+    from tntorch_amd import _hip, _hipops
+
+    if _hip._lib is None:   # nothing loaded, nothing to restore
+        return
+    _hip.set_knob(_hip.KNOB_QR_RANK_SKIP, 8)
+    _hip.set_knob(_hip.KNOB_QR_PACK, 0 if _hipops._FUSE_APPLY_GRAM else 3)

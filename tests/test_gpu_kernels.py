@@ -182,7 +182,7 @@ def test_qr_pushed_rank_deficient_R_packs_rows(dt, I, mixed, pack):
     the rounding level, Q stays orthonormal on its range, and a batch that mixes a rank-deficient and a full-rank item (decided
     per item on the device) handles both; I = 24 (3 blocks: odd) never packs."""
     h = _hip()
-    h.set_knob(h.KNOB_QR_PACK, pack)   # (off by default: measured without gain at scale; 1 / 2 = the two block pairings)
+    h.set_knob(h.KNOB_QR_PACK, pack)   # (3 = default; 1 / 2 = the item-major block pairings; the conftest fixture restores the default)
     g = torch.Generator().manual_seed(I + 7 * int(mixed))
     B, k, Rin, n = 3, 64, 64, 64
     top = torch.triu(torch.randn(B, 32, 64, generator=g, dtype=torch.float64))
@@ -207,7 +207,6 @@ def test_qr_pushed_rank_deficient_R_packs_rows(dt, I, mixed, pack):
         Qr = Q[bi][:, :r]
         assert (Qr.T @ Qr - torch.eye(r, dtype=torch.float64)).abs().max() < tol(dt, 3e-5, 1e-12)
     assert torch.equal(torch.tril(f.R, diagonal=-1), torch.zeros_like(f.R))
-    h.set_knob(h.KNOB_QR_PACK, 0)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -919,7 +918,7 @@ def test_eigh_top(dt, n, r):
     G = (Mx @ Mx.transpose(1, 2)).to(dt).cuda()
     V, sig, info, flat = h.eigh_top(G, r, 0.125)
     assert V.shape == (B, n, n) and sig.shape == (B, n) and flat.dtype == torch.int32
-    it, iq = flat.nonzero()[:, 0], (flat == 0).nonzero()[:, 0]
+    it, iq = (flat == 1).nonzero()[:, 0], (flat != 1).nonzero()[:, 0]   # (2: declined, but flat by its sigma)
     assert len(it) >= B - 2                                  # (a pair closer than 512 eps lambda_1 is possible, not likely)
     orth, res, serr = _top_errors(G[it], V[it], sig[it], r)
     assert orth < tol(dt, 3e-6, 1e-14) and res < tol(dt, 3e-6, 1e-14) and serr < tol(dt, 3e-6, 1e-14)
@@ -928,6 +927,31 @@ def test_eigh_top(dt, n, r):
     if len(iq):
         orth, res, serr = _top_errors(G[iq], V[iq], sig[iq], n)
         assert orth < tol(dt, 2e-5, 1e-13) and res < tol(dt, 2e-5, 1e-13)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_carry_rows32_flags(dt):
+    """ttr_carry_rows32: the packing test of the fused push on a stand-alone carry (the sweep's last core) -- rows 32.. hold at
+    most (8 eps)^2 of the squared norm; knob QR_PACK = 0 switches it off."""
+    h = _hip()
+    g = torch.Generator().manual_seed(3)
+    eps = torch.finfo(dt).eps
+    R = torch.randn(5, 64, 64, generator=g, dtype=torch.float64)
+    R[0, 32:] = 0
+    R[1, 32:] *= 2 * eps
+    R[2, 32:] *= 64 * eps
+    R[3, 40] *= 1e-3
+    R[3, 32:40] = 0
+    R[3, 41:] = 0
+    view = torch.zeros(5, 64, 80, dtype=dt)
+    view[:, :, :64] = R.to(dt)
+    Rd = view.cuda()[:, :, :64]                      # (leading dimension 80)
+    assert h.carry_rows32(Rd).tolist() == [1, 1, 0, 0, 0]
+    h.set_knob(h.KNOB_QR_PACK, 0)
+    try:
+        assert h.carry_rows32(Rd).tolist() == [0] * 5
+    finally:
+        h.set_knob(h.KNOB_QR_PACK, 3)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -954,7 +978,7 @@ def test_eigh_top_zero_tail_is_solved_as_the_leading_block(dt, r, parts):
     V, sig, info, flat = h.eigh_top(Gp.cuda(), r, 0.125)
     flat = flat.cpu()
     assert flat[:8].tolist() == [1] * 8 and flat[8:10].tolist() == [0, 0]
-    it = flat.nonzero()[:, 0]
+    it = (flat == 1).nonzero()[:, 0]
     orth, res, serr = _top_errors(Gd[it].to(dt).cuda(), V[it.cuda()], sig[it.cuda()], r)
     assert orth < tol(dt, 3e-6, 1e-14) and res < tol(dt, 3e-6, 1e-14) and serr < tol(dt, 3e-6, 1e-14)
     assert float(V[it.cuda()][:, :, r:].abs().max()) == 0.0 and float(sig[it.cuda()][:, r:].abs().max()) == 0.0
@@ -971,7 +995,7 @@ def test_eigh_top_zero_tail_is_solved_as_the_leading_block(dt, r, parts):
         assert (Vc[b].T @ Vc[b] - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 1e-13)
     # item 11 is a full-size problem: row 40 takes part
     b = 11
-    k = r if int(flat[b]) else n
+    k = r if int(flat[b]) == 1 else n
     wref = torch.linalg.eigvalsh(Gd[b]).flip(-1).clamp_min(0)
     assert ((sc[b, :k] ** 2 - wref[:k]).abs().max() / wref[0]) < tol(dt, 3e-6, 1e-13)
     assert float(Vc[b, 40, :k].abs().max()) > 1e-3
@@ -992,15 +1016,16 @@ def test_eigh_top_declines_what_it_cannot_certify(dt):
         lam = torch.tensor(spectrum, dtype=torch.float64) ** 2
         return ((Q * lam) @ Q.transpose(1, 2)).to(dt).cuda()
 
+    # (flag 2: declined by the top-r path, but the kept sigma of the full decomposition are flat -- the bond's pass-through flag)
     declined = {
-        "graded": gram([0.5 ** i for i in range(n)]),
-        "double": gram([1.0, 1.0] + [0.9 - 0.01 * i for i in range(n - 2)]),
-        "pairs at 100 eps": gram([(1.0 - 0.02 * (i // 2)) * (1.0 + 100 * e * (i % 2)) for i in range(n)]),
-        "identity": torch.eye(n, dtype=dt).repeat(B, 1, 1).cuda(),
+        "graded": (0, gram([0.5 ** i for i in range(n)])),
+        "double": (2, gram([1.0, 1.0] + [0.9 - 0.01 * i for i in range(n - 2)])),
+        "pairs at 100 eps": (2, gram([(1.0 - 0.02 * (i // 2)) * (1.0 + 100 * e * (i % 2)) for i in range(n)])),
+        "identity": (2, torch.eye(n, dtype=dt).repeat(B, 1, 1).cuda()),
     }
-    for name, G in declined.items():
+    for name, (flag, G) in declined.items():
         V, sig, info, flat = h.eigh_top(G, r, 0.125)
-        assert flat.tolist() == [0] * B, name
+        assert flat.tolist() == [flag] * B, name
         Vq, sq, iq = h.eigh_trunc(G, h.EIG_RAW, False, 0.0, n, abs_floor=h.SOLVER_TRIDIAG)
         assert torch.equal(info, iq), name
         assert ((sig - sq).abs().max() / sq.max()).item() < tol(dt, 1e-6, 1e-14), name

@@ -1190,8 +1190,14 @@ def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
     assert _hip.spectrum_flat(sg, 4, 0.25).tolist() == [1, 0, 0] and _hip.spectrum_flat(sg, 5, 0.02).tolist() == [1, 1, 0]
     inp = _metric_input(4, seed=11)
     calls = []
-    orig = _hip.spectrum_flat
-    monkeypatch.setattr(_hip, "spectrum_flat", lambda *a: calls.append(orig(*a)) or calls[-1])
+    orig = _hip.eigh_top      # (batch mode: the first-pass launch's flags ARE the pass-through flags, ttr_eigh_top -- no ttr_spectrum_flat launch)
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        calls.append((out[3] != 0).to(torch.int32))
+        return out
+
+    monkeypatch.setattr(_hip, "eigh_top", spy)
     res = {}
     for thr in (0.25, 0.0):
         monkeypatch.setattr(_hipops, "FLAT_SPECTRUM_THR", thr)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 8  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 9  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -102,6 +102,7 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
          c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
+    "ttr_carry_rows32": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "ttr_eigh_top_ok": (c_int, [c_int64, c_int64]),
     "ttr_eigh_top": (
@@ -581,7 +582,8 @@ def eigh_top_ok(n: int, r: int) -> bool:
 def eigh_top(G: torch.Tensor, r: int, thr: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Pass 1 of a batch-mode bond: symmetric [batch, n, n] (or split partials [batch, parts, n, n]), 40 <= n <= 64, rank cap
     r <= 32 (ttr_eigh_top).  Returns (V, sigma, info, flat): items with flat[b] = 1 carry their r largest eigenpairs (V[b][:, :r],
-    sigma[b][:r], zeros beyond), the others the full decomposition of ``eigh_trunc(G, EIG_RAW, ..., abs_floor=SOLVER_TRIDIAG)``."""
+    sigma[b][:r], zeros beyond), the others the full decomposition of ``eigh_trunc(G, EIG_RAW, ..., abs_floor=SOLVER_TRIDIAG)``
+    (flat[b] = 2 when its kept sigma pass ``spectrum_flat``'s batch-mode test, else 0)."""
     L = lib()
     dt = dtype_code(G.dtype)
     gparts, sGp = 1, 0
@@ -898,7 +900,7 @@ def pow2_normalize(x: torch.Tensor, expo_acc: Optional[torch.Tensor] = None, exp
     batch = x.shape[0]
     count = x[0].numel() if batch > 0 else 0
     out = None if exponent_only else torch.empty_like(x)
-    e = torch.zeros((batch,), dtype=torch.int32, device=x.device)
+    e = torch.empty((batch,), dtype=torch.int32, device=x.device)   # (every entry is written by the kernel)
     if batch == 0:
         return out, e
     _check(L.ttr_pow2_normalize(dt, count, batch, x.data_ptr(), count, out.data_ptr() if out is not None else None, count,
@@ -932,6 +934,21 @@ def scale_batch(x: torch.Tensor, scale=None, expo: Optional[torch.Tensor] = None
                              expo.data_ptr() if expo is not None else None, int(expo_sign),
                              out.data_ptr(), count, _stream()), "ttr_scale_batch")
     return out
+
+
+@_on_device
+def carry_rows32(R: torch.Tensor) -> torch.Tensor:
+    """[batch, 64, cols] -> int32 [batch]: 1 where rows 32.. of R[b] are negligible by the packing test of the fused push
+    (ttr_carry_rows32): the `rows32` flags of a carry that no ``qr_factor_pushed`` follows (the sweep's last core)."""
+    L = lib()
+    R, ldr, sR = _mat(R)
+    batch, rows, cols = R.shape
+    assert rows == 64
+    flag = torch.empty((batch,), dtype=torch.int32, device=R.device)
+    if batch:
+        _check(L.ttr_carry_rows32(dtype_code(R.dtype), cols, batch, R.data_ptr(), ldr, sR, flag.data_ptr(), _stream()),
+               "ttr_carry_rows32")
+    return flag
 
 
 @_on_device

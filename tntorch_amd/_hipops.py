@@ -594,7 +594,11 @@ def truncate(
                 V1, sig1, _ = _hip.eigh_trunc(G, _hip.EIG_RAW, False, 0.0, k, abs_floor=_hip.SOLVER_TRIDIAG)
                 top_flat = None
             flat = None
-            if FLAT_SPECTRUM_THR > 0:
+            if top_flat is not None and not use_delta:
+                # batch mode: the launch's flags are the pass-through flags already (1: top-r path; 2: declined there, but the
+                # full decomposition's kept sigma pass the same test) -- include/ttround_hip.h: ttr_eigh_top
+                flat = top_flat
+            elif FLAT_SPECTRUM_THR > 0:
                 # items whose KEPT singular values lie within a factor 8 of each other do not need the second pass (the first
                 # Gram matrix already carries them to a few eps; include/ttround_hip.h: ttr_spectrum_flat): their rotated
                 # Gram matrix is not formed and the pass-2 solver hands pass 1's result through.  Decided per item, on the
@@ -1206,6 +1210,13 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
             Rprev, _ = _hip.pow2_normalize(Rprev, expo_acc=expo)
         c[mu] = None
     last = c[N - 1]
+    # the first truncation's carry M = R x (last core): rows 32.. of M are negligible whenever those of R are -- the flags the
+    # packed push computes for every other bond (rank-inflated trains: half the rows of the first Gram / projection passes, and
+    # the first eigenproblem shrinks to 32 x 32 like the others)
+    r32_last = None
+    if (not _FUSE_APPLY_GRAM and Rprev is not None and Rprev.dim() == 3 and Rprev.shape[1] == 64 and Rprev.shape[0] == last.shape[0]
+            and last.shape[2] * last.shape[3] >= 64):
+        r32_last = _hip.carry_rows32(Rprev)
     c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
     if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
@@ -1238,7 +1249,10 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
             M4 = M4.reshape(f.batch, r0, I, left.shape[2])
         Bt, R, I, rn = M4.shape
         # rows kk >= 32 of the carry are exactly zero for the items whose QR of this bond packed its rows
-        r32 = getattr(facs[mu][0], "rows32", None) if (mu < N - 1 and R == 64 and I * rn >= 64) else None
+        if mu < N - 1:
+            r32 = getattr(facs[mu][0], "rows32", None) if (R == 64 and I * rn >= 64) else None
+        else:
+            r32 = r32_last if (R == 64 and I * rn >= 64) else None
         alloc = None
         if arena is not None:
             def alloc(r, mu=mu, n=I * rn):

@@ -188,6 +188,26 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+// flag[b] = 1 when rows 32.. of the 64-row matrix R[b] hold at most (c eps)^2 of its squared Frobenius norm -- the packing test of
+// the fused push + factor kernel (ttr_qr.hip: `packed`), for the LAST core of a sweep, which no push follows
+template <typename T>
+__global__ __launch_bounds__(kThreads) void carry_rows32_kernel(int64_t cols, const T* __restrict__ R, int64_t ldr, int64_t strideR,
+                                                                double ce2, int32_t* __restrict__ flag) {
+  __shared__ double red[kThreads / kWave];
+  const int64_t b = blockIdx.x;
+  const T* __restrict__ Rb = R + b * strideR;
+  double all = 0.0, low = 0.0;
+  for (int64_t idx = threadIdx.x; idx < 64 * cols; idx += kThreads) {
+    const int64_t i = idx / cols, j = idx - i * cols;
+    const double v = (double)Rb[i * ldr + j];
+    all += v * v;
+    if (i >= 32) low += v * v;
+  }
+  all = block_sum(all, red);
+  low = block_sum(low, red);
+  if (threadIdx.x == 0) flag[b] = (ce2 > 0.0 && low <= ce2 * all) ? 1 : 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pow2_normalize_kernel(const T* __restrict__ x, int64_t count, int64_t stride_x,
                                                                   T* __restrict__ out, int64_t stride_out,
@@ -918,6 +938,26 @@ int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
 int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch) {
   if (!dtype_ok(dtype) || I < 1 || n < 1 || batch < 1) return -1;
   return qr_pushed_flag_offset(dtype, I, n, batch);
+}
+
+int ttr_carry_rows32(int dtype, int64_t cols, int64_t batch, const void* R, int64_t ldr, int64_t strideR, int32_t* flag,
+                     void* stream) {
+  TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_carry_rows32: bad dtype %d", dtype);
+  TTR_REQUIRE(cols >= 1 && batch >= 0 && ldr >= cols, TTR_E_INVALID, "ttr_carry_rows32: bad shape");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(R && flag, TTR_E_INVALID, "ttr_carry_rows32: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  // the thresholds of the packing test (TTR_KNOB_QR_RANK_SKIP, TTR_KNOB_QR_PACK = 0: never)
+  const double ce = (g_qr_pack ? (double)g_rank_skip_c : 0.0) * (dtype == TTR_F32 ? 1.1920929e-07 : 2.220446049250313e-16);
+  ProfScope prof(TTR_PROF_MISC, s);
+  if (dtype == TTR_F32)
+    hipLaunchKernelGGL(carry_rows32_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, cols, (const float*)R, ldr, strideR,
+                       ce * ce, flag);
+  else
+    hipLaunchKernelGGL(carry_rows32_kernel<double>, dim3((unsigned)batch), dim3(kThreads), 0, s, cols, (const double*)R, ldr, strideR,
+                       ce * ce, flag);
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
 }
 
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,

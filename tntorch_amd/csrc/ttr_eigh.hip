@@ -1443,6 +1443,14 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     }
     p.info[bt] = rank;
     if (p.sweeps) p.sweeps[bt] = total_iter;
+    if constexpr (TOP) {
+      // an item the top-r path declined: ttr_spectrum_flat's batch-mode test on the full decomposition's sigma, so that the flags
+      // of a ttr_eigh_top launch are the pass-through flags of the bond (no separate launch for the test and for merging the two)
+      if (p.top_flat) {
+        const int kq = p.top_r < n ? (p.top_r < 1 ? 1 : p.top_r) : n;
+        p.top_flat[bt] = (sig_sorted[0] > T(0) && sig_sorted[kq - 1] >= (T)p.top_thr * sig_sorted[0]) ? 2 : 0;
+      }
+    }
   }
 }
 

@@ -128,9 +128,7 @@ class Tensor(object):
                 self.cores[n].requires_grad_()
                 if self.Us[n] is not None:
                     self.Us[n].requires_grad_()
-        if idxs is None:
-            idxs = [torch.arange(sh, device=self.cores[0].device) for sh in self.shape]
-        self.idxs = idxs
+        self._idxs = idxs   # (built on first access: `idxs` below -- N arange launches per constructed tensor otherwise)
         if eps is not None:  # tensor.py:436-439
             if isinstance(data, (list, tuple)):
                 if ranks_tt is not None or ranks_tucker is not None:
@@ -255,6 +253,17 @@ class Tensor(object):
 
     # ------------------------------------------------------------------ properties (tensor.py:836-919)
     @property
+    def idxs(self):
+        """tensor.py:433-435: one index vector per mode (identity indexing unless given to the constructor)."""
+        if self._idxs is None:
+            self._idxs = [torch.arange(sh, device=self.cores[0].device) for sh in self.shape]
+        return self._idxs
+
+    @idxs.setter
+    def idxs(self, value):
+        self._idxs = value
+
+    @property
     def shape(self):
         shape = []
         if self.batch:
@@ -307,7 +316,7 @@ class Tensor(object):
     def clone(self):
         """tensor.py:2213-2229."""
         Us = [None if U is None else U.clone() for U in self.Us]
-        return Tensor([c.clone() for c in self.cores], Us=Us, idxs=self.idxs, batch=self.batch)
+        return Tensor([c.clone() for c in self.cores], Us=Us, idxs=self._idxs, batch=self.batch)
 
     def to(self, device):
         """tensor.py:1689-1700 (in place, returns self)."""
@@ -342,7 +351,7 @@ class Tensor(object):
             else:
                 cores.append(c4[n].clone() if _clone else c4[n])
                 Us.append(None if self.Us[n] is None else (self.Us[n].clone() if _clone else self.Us[n]))
-        return Tensor(self._denorm(cores), Us=Us, idxs=self.idxs, batch=self.batch)
+        return Tensor(self._denorm(cores), Us=Us, idxs=self._idxs, batch=self.batch)
 
     # ------------------------------------------------------------------ arithmetic used around the hot path
     def _scalar_like(self, value):

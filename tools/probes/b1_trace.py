@@ -52,3 +52,9 @@ else:
           f"kernel time {busy / REPS / 1e3:.1f} us, idle {(span - busy) / REPS / 1e3:.1f} us")
     for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print(f"  {t / REPS / 1e3:8.1f} us/call  {c / REPS:5.1f} launches  {t / c / 1e3:7.1f} us each  {n}")
+    if len(sys.argv) > 3:  # the last call's kernels in launch order: start offset, duration, gap to the previous kernel
+        k = len(ev) // REPS
+        last = ev[-k:]
+        for i, (s, e, n) in enumerate(last):
+            gap = s - last[i - 1][1] if i else 0
+            print(f"  {(s - last[0][0]) / 1e3:8.1f} us  {(e - s) / 1e3:6.1f} us  gap {gap / 1e3:5.1f}  {n[:110]}")
