@@ -213,6 +213,9 @@ int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t
  * live direction gets the accuracy of a backward-stable SVD (LAPACK gesdd class, round.py:96) whatever its sigma.
  * `sweeps` (optional, [batch]) receives the number of sweeps (Jacobi) / QL iterations used.
  * eig_mode = TTR_EIG_MATCH_DIAG: see above (sigma[b] then follows V's column order; info as usual).
+ * TTR_EIG_RAW / TTR_EIG_REF clamp negative eigenvalues: G is taken to be positive semi-definite up to rounding (a Gram matrix).  The
+ * tridiagonal solver uses that for a 64 x 64 matrix whose diagonal is exactly zero from index 32 on (zero rows / columns: the
+ * carry of a bond whose QR packed its rows): it is solved as its leading 32 x 32 block, V[b] = blockdiag(V11, I), sigma[b][32:] = 0.
  * The input may be given as `gparts` partial matrices (split-K partials of a Gram kernel, `stride_gpart` elements
  * apart): G[b] = sum_p G[b * strideG + p * stride_gpart + ...]; gparts = 1 for a plain matrix.
  */

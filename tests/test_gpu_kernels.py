@@ -1067,3 +1067,33 @@ def test_eigh_topk_multiple_eigenvalues_are_declined_or_spanned(dt):
     assert _hipops._topk_one_pass(G, k) is None            # one collapsed item declines the batch ...
     res = _hipops._topk_one_pass(G[1:2], 3)                # ... the separated one alone is flat within a factor 8 at r = 3: accepted
     assert res is not None and res[2].tolist() == [3]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("mode", ["raw", "ref"])
+def test_eigh_tridiag_zero_tail_is_solved_as_the_leading_block(dt, mode):
+    """ttr_eigh_trunc, tridiagonal solver, on 64 x 64 Gram matrices with exactly zero rows / columns 32..: the leading block is
+    solved, V = blockdiag(V11, I), sigma[32:] = 0, the rank rule sees all 64 values (cap and tail energies) -- same results as
+    for a matrix that is not shrunk (one tiny nonzero entry on the lower diagonal keeps it at full size)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(77)
+    B, n = 4, 64
+    rows = torch.zeros(B, n, 150, dtype=torch.float64)
+    rows[:, :32] = torch.randn(B, 32, 150, generator=g, dtype=torch.float64) * (2.0 ** (-0.3 * torch.arange(32, dtype=torch.float64)))[None, :, None]
+    G = (rows @ rows.transpose(1, 2)).to(dt)
+    Gfull = G.clone()
+    Gfull[:, 50, 50] = torch.finfo(dt).tiny * 4       # not shrunk: the diagonal tail is not exactly zero
+    em = h.EIG_RAW if mode == "raw" else h.EIG_REF
+    delta2 = float(G[0].double().diagonal().sum()) * 1e-6
+    out = [h.eigh_trunc(x.cuda(), em, True, delta2, 48, abs_floor=h.SOLVER_TRIDIAG) for x in (G, Gfull)]
+    (V, sg, info), (Vf, sf, inf_f) = out
+    assert torch.equal(info, inf_f)
+    Vc, sc = V.cpu().double(), sg.cpu().double()
+    assert float(sc[:, 32:].abs().max()) == 0.0 and float((sc - sf.cpu().double()).abs().max() / sc.max()) < tol(dt, 2e-6, 1e-14)
+    eye = torch.eye(32, dtype=torch.float64)
+    for b in range(B):
+        assert torch.equal(Vc[b, 32:, 32:], eye) and float(Vc[b, :32, 32:].abs().max()) == 0.0 and float(Vc[b, 32:, :32].abs().max()) == 0.0
+        wref = torch.linalg.eigvalsh(G[b].double()).flip(-1).clamp_min(0)
+        assert ((sc[b] ** 2 - wref).abs().max() / wref[0]) < tol(dt, 2e-6, 1e-13)
+        assert (G[b].double() @ Vc[b] - Vc[b] * (sc[b] ** 2)[None, :]).abs().max() / wref[0] < tol(dt, 2e-5, 1e-12)
+        assert (Vc[b].T @ Vc[b] - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 1e-13)

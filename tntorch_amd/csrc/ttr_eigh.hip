@@ -615,13 +615,14 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   const int64_t bt = blockIdx.x;
   const int nf = p.n;
-  // Top-r launches (pass 1 of a batch-mode bond: G is a Gram matrix, so G_ii = 0 means a zero row / column): a 64 x 64 matrix whose
+  // Gram matrices (every launch but the block-Jacobi driver's TTR_EIG_MATCH_DIAG pair problems; G_ii = 0 means a zero row /
+  // column of a positive semi-definite matrix): a 64 x 64 matrix whose
   // diagonal is exactly zero from index 32 on -- the carry of a bond whose QR packed its rows (ttr_qr_pushed_flag_offset) -- is
   // solved as its leading 32 x 32 block: half the reflectors at half the length, half the Sturm / twisted recurrences.  V comes
   // out as blockdiag(V11, I) (qualified items: zeros beyond the r kept columns), sigma[32..] = 0.  Decided by every wave from the
   // diagonal (lane = index), before the LDS is carved.
   int n_shrunk = nf;
-  if (TOP && nf == 64) {
+  if ((TOP || p.eig_mode != TTR_EIG_MATCH_DIAG) && nf == 64) {   // (RAW / REF clamp negative eigenvalues: their input is a Gram matrix)
     const T* __restrict__ Gd = p.G + bt * p.strideG + (int64_t)lane * p.ldg + lane;
     T dg = T(0);
     if (lane >= 32)

@@ -2,7 +2,7 @@
 per-kind kernel time / launch counts of one call.   python tools/probes/c2_single_probe.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tools/
 import torch
 import tntorch_amd as tn
 import oracle
