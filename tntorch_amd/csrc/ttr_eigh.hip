@@ -711,8 +711,11 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   long long* const dbg = reinterpret_cast<long long*>(p.ws);  // diagnostics build: cycle stamps of matrix 0 (wave 0)
   int dbgi = 0;
 #define TTR_ESTAMP() do { if (dbg && bt == 0 && tid == 0) dbg[dbgi++] = (long long)clock64(); } while (0)
+  int dbgj = 32;  // wave 1's stamps (lane 0 of wave 1) go to slots 32..
+#define TTR_ESTAMP1() do { if (dbg && bt == 0 && tid == kWave) dbg[dbgj++] = (long long)clock64(); } while (0)
 #else
 #define TTR_ESTAMP() do {} while (0)
+#define TTR_ESTAMP1() do {} while (0)
 #endif
   TTR_ESTAMP();
   T* const rowp = A + lane * ld;
@@ -987,15 +990,19 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     if constexpr (TOP) {
       // ---- 2t. this wave's eigenvalues and twisted factorisations
       select();
+      TTR_ESTAMP();
       T nrm2 = T(1);
       if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
       if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
+      TTR_ESTAMP();
       __syncthreads();  // B1: all eigenvalues in lamv, wave 1 done with the reflectors in A
+      TTR_ESTAMP();
       if (qualifies()) {
         if (vlive) {
           const T inv = T(1) / sqrt(nrm2);
           (void)vector_pass(IC2<1>{}, inv);
         }
+        TTR_ESTAMP();
         __syncthreads();  // B2: Z complete
         // epilogue of wave 0: sigma, rank, flag, zero columns
         if (lane < n) {
@@ -1016,6 +1023,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
           Vo[(int64_t)row * p.ldv + c] = T(0);
         }
         pad_tail(false, lane, kWave);
+        TTR_ESTAMP();
         return;
       }
       if (lane == 0 && p.top_flat) p.top_flat[bt] = 0;
@@ -1204,9 +1212,11 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
           }
         }
       }
+      TTR_ESTAMP1();
       if constexpr (TOP) {
         // ---- 2t. this wave's eigenvalues and twisted factorisations (Q^T stays in the accumulators Z)
         select();
+        TTR_ESTAMP1();
         T nrm2 = T(1);
         if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
         if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
@@ -1216,7 +1226,9 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
             const T inv = T(1) / sqrt(nrm2);
             (void)vector_pass(IC2<1>{}, inv);
           }
+          TTR_ESTAMP1();
           __syncthreads();  // B2: Z complete in LDS
+          TTR_ESTAMP1();
           // ---- 4. V^T = P (Q Z)^T on the matrix cores
           T zr[4][4][2];  // Z[16 tm + row(lane, s)][16 tv + cl]
 #pragma unroll
@@ -1240,6 +1252,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
 #pragma unroll
                 for (int tv = 0; tv < 2; ++tv) C[tv][ti] = MF::mma(zr[tm][s][tv], Z[tm][ti][s], C[tv][ti]);
           }
+          TTR_ESTAMP1();
           Acc S[2][2];
 #pragma unroll
           for (int tv = 0; tv < 2; ++tv)
@@ -1294,6 +1307,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
 #pragma unroll
               for (int b2 = 0; b2 < 2; ++b2) Pt[a][b2] = Pu[a][b2];
           }
+          TTR_ESTAMP1();
           T* __restrict__ Vo = p.V + bt * p.strideV;
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti)
@@ -1310,6 +1324,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
                 if (v < rsel && i < n) Vo[(int64_t)i * p.ldv + v] = X[rr];
               }
             }
+          TTR_ESTAMP1();
           return;
         }
         __syncthreads();  // B1'
@@ -1557,6 +1572,10 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
 }
 
 // pass 1 of a batch-mode bond, n <= 64: the r largest eigenpairs (flat[b] = 1) or the full QL decomposition (flat[b] = 0) per item
+#ifdef TTR_EIGH_STAMPS
+static void* g_eigh_stamps = nullptr;   // diagnostics build: cycle stamps of matrix 0 of the next ttr_eigh_top launches (>= 64 int64)
+extern "C" void ttr_debug_set_eigh_stamps(void* p) { g_eigh_stamps = p; }
+#endif
 template <typename T>
 static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
                           void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int64_t r, double thr,
@@ -1568,6 +1587,9 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
   p.sigma = (T*)sigma; p.stride_sigma = stride_sigma;
   p.info = info; p.rmax = n; p.top_r = (int)r; p.top_flat = flat; p.top_thr = thr;
   p.eig_mode = TTR_EIG_RAW;
+#ifdef TTR_EIGH_STAMPS
+  p.ws = (T*)g_eigh_stamps;
+#endif
   ProfScope prof(TTR_PROF_EIGH, stream);
   hipLaunchKernelGGL((eigh_tridiag_kernel<T, true>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
   TTR_HIP_CHECK(hipGetLastError());
