@@ -653,6 +653,11 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   T* tauv = ev + 66;                         // [64]
   T* Tb = tauv + 64;                         // [16][17] compact-WY factor of a reflector block (Q formation)
   volatile int* meta = reinterpret_cast<volatile int*>(Tb + 16 * 17);  // [2][4]: m, ilast, done of the sweep in buffer 0 / 1
+  // top-r path: d_i and e_{i-1}^2 (clamped to the smallest normal; [0] = 0) for the Sturm counts, 16-byte aligned so that four
+  // steps' values come with two LDS reads
+  constexpr int kSel16 = 16 / (int)sizeof(T);
+  T* const dsel = A + ((n * ld + 3 + 408 + 66 * 2 + 64 + 16 * 17 + 8 + kSel16 - 1) / kSel16) * kSel16;   // [64]
+  T* const e2s = dsel + 64;                                                                                 // [64]
 
   const T* __restrict__ G = p.G + bt * p.strideG;
   // ---- load + scale (both waves)
@@ -771,14 +776,35 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     pivmin = Num<T>::tiny() * fmax(T(1), emax2) / eps;
     gl -= T(2.1) * tnorm * eps * n + T(2.1) * pivmin;
     gu += T(2.1) * tnorm * eps * n + T(2.1) * pivmin;
-    auto count_below = [&](T sigma) __attribute__((always_inline)) {  // number of eigenvalues < sigma
-      T q = dv[0] - sigma;
-      if (fabs(q) < pivmin) q = -pivmin;
-      int cnt = q < T(0) ? 1 : 0;
-      for (int i = 1; i < n; ++i) {
-        const T e = ev[i - 1];
-        q = dv[i] - sigma - fdiv_fast(e * e, q);
-        if (fabs(q) < pivmin) q = -pivmin;
+    // number of eigenvalues < sigma: the signs of the pivots q_i = d_i - sigma - e_{i-1}^2 / q_{i-1} of the LDL^T factorisation.  No
+    // pivot guard: a pivot that is exactly zero (or flushed to zero) gives e^2 / 0 = +inf, the next pivot is -inf (counted: the
+    // zero pivot stands for an eigenvalue AT sigma), the one after that d - sigma -- IEEE arithmetic does what the guard did
+    // (LAPACK dstebz's ieee variant); e^2 is clamped away from zero so that 0 * inf cannot occur.  Four steps per trip with two
+    // 16-byte LDS reads (cycle stamps, 32 x 32 problem: 57 k of 207 k cycles in this phase at ~127 cycles per step, 16 issue slots
+    // of the lone wave, before)
+    auto count_below = [&](T sigma) __attribute__((always_inline)) {
+      typedef T Q4 __attribute__((ext_vector_type(4)));
+      T q = T(1);
+      int cnt = 0;
+      int i = 0;
+      for (; i + 4 <= n; i += 4) {
+        Q4 d4, e4;
+        if constexpr (sizeof(T) == 4) {
+          d4 = *reinterpret_cast<const Q4*>(&dsel[i]); e4 = *reinterpret_cast<const Q4*>(&e2s[i]);
+        } else {
+          typedef T Q2 __attribute__((ext_vector_type(2)));
+          const Q2 da = *reinterpret_cast<const Q2*>(&dsel[i]), db = *reinterpret_cast<const Q2*>(&dsel[i + 2]);
+          const Q2 ea = *reinterpret_cast<const Q2*>(&e2s[i]), eb = *reinterpret_cast<const Q2*>(&e2s[i + 2]);
+          d4 = Q4{da[0], da[1], db[0], db[1]}; e4 = Q4{ea[0], ea[1], eb[0], eb[1]};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          q = (d4[u] - sigma) - fdiv_fast(e4[u], q);
+          cnt += q < T(0) ? 1 : 0;
+        }
+      }
+      for (; i < n; ++i) {
+        q = (dsel[i] - sigma) - fdiv_fast(e2s[i], q);
         cnt += q < T(0) ? 1 : 0;
       }
       return cnt;
@@ -882,8 +908,9 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off, 64));
     const T l0 = lamv[0], lr = lamv[rsel - 1];
     const T thr = (T)p.top_thr;
-    return l0 > T(0) && lr >= thr * thr * l0 && (rsel == 1 || gmin >= T(512) * eps * l0) && badf[0] == 0;
+    return l0 > T(0) && lr >= thr * thr * l0 && (rsel == 1 || gmin >= T(512) * eps * l0);
   };
+  T* const invn = wsh;   // [<= 32] 1 / ||x_j|| of the twisted vectors (the tridiagonalisation's second broadcast array is free by then)
 
   if (wv == 0) {
     // ---- 1. Householder tridiagonalisation (lower): reflector k annihilates A[k+2:, k]; a barrier after every block of 16
@@ -983,6 +1010,12 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
       if (below) rowp[k] = v;  // keep the reflector below the sub-diagonal
       if (lane == k) dv[k] = rowp[k];
       if (k == n - 2 && lane == n - 1) { dv[n - 1] = rowp[n - 1]; ev[n - 1] = T(0); }  // (before the barrier: wave 1 overwrites A with Q)
+      if (TOP && k == n - 2) {   // d / e are final: the Sturm counts' copies (both waves read them after the barrier below)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const T el = (lane >= 1 && lane < n) ? ev[lane - 1] : T(0);
+        dsel[lane] = lane < n ? dv[lane] : T(0);
+        e2s[lane] = lane == 0 ? T(0) : fmax(el * el, Num<T>::tiny());
+      }
       if ((k & 15) == 15 || k == n - 2) __syncthreads();
     }
     TTR_ESTAMP();
@@ -991,19 +1024,24 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
       // ---- 2t. this wave's eigenvalues and twisted factorisations
       select();
       TTR_ESTAMP();
-      T nrm2 = T(1);
-      if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
-      if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
       TTR_ESTAMP();
       __syncthreads();  // B1: all eigenvalues in lamv, wave 1 done with the reflectors in A
       TTR_ESTAMP();
-      if (qualifies()) {
+      bool taken = qualifies();
+      if (taken) {
+        // ONE pass over each vector: written unnormalised (x_twist = 1) together with its norm; 1 / ||x|| is applied where wave 1
+        // loads Z for the matrix cores.  (Round 4: a norm pass before the barrier and a scaled pass after it -- 14 k of a 32 x 32
+        // problem's 207 k cycles, on both waves.)  A vector that overflowed is only known afterwards: checked behind B2.
         if (vlive) {
-          const T inv = T(1) / sqrt(nrm2);
-          (void)vector_pass(IC2<1>{}, inv);
+          const T nrm2 = vector_pass(IC2<1>{}, T(1));
+          if (!(nrm2 < Num<T>::big_theta())) badf[0] = 1;
+          invn[jv] = T(1) / sqrt(nrm2);
         }
         TTR_ESTAMP();
         __syncthreads();  // B2: Z complete
+        taken = badf[0] == 0;
+      }
+      if (taken) {
         // epilogue of wave 0: sigma, rank, flag, zero columns
         if (lane < n) {
           T w = lane < rsel ? lamv[lane] * gmax : T(0);
@@ -1217,18 +1255,20 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
         // ---- 2t. this wave's eigenvalues and twisted factorisations (Q^T stays in the accumulators Z)
         select();
         TTR_ESTAMP1();
-        T nrm2 = T(1);
-        if (vlive) nrm2 = vector_pass(IC2<0>{}, T(0));
-        if (vlive && !(nrm2 < Num<T>::big_theta())) badf[0] = 1;
         __syncthreads();  // B1
-        if (qualifies()) {
+        bool taken = qualifies();
+        if (taken) {
           if (vlive) {
-            const T inv = T(1) / sqrt(nrm2);
-            (void)vector_pass(IC2<1>{}, inv);
+            const T nrm2 = vector_pass(IC2<1>{}, T(1));
+            if (!(nrm2 < Num<T>::big_theta())) badf[0] = 1;
+            invn[jv] = T(1) / sqrt(nrm2);
           }
           TTR_ESTAMP1();
           __syncthreads();  // B2: Z complete in LDS
           TTR_ESTAMP1();
+          taken = badf[0] == 0;
+        }
+        if (taken) {
           // ---- 4. V^T = P (Q Z)^T on the matrix cores
           T zr[4][4][2];  // Z[16 tm + row(lane, s)][16 tv + cl]
 #pragma unroll
@@ -1238,7 +1278,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
 #pragma unroll
               for (int tv = 0; tv < 2; ++tv) {
                 const int row = 16 * tm + MF::row(lane, s), col = 16 * tv + cl;
-                zr[tm][s][tv] = (row < n && col < rsel) ? A[row * ZLD + col] : T(0);
+                zr[tm][s][tv] = (row < n && col < rsel) ? A[row * ZLD + col] * invn[col] : T(0);
               }
           Acc C[2][4];  // (Q Z)^T: rows = vector, columns = matrix row
 #pragma unroll
@@ -1470,8 +1510,8 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   }
 }
 
-static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {  // A, 3 pad, 408 scratch, d / e (66 each), tau, T_b, 8 control words
-  return (((size_t)n * (n + 1) + 3 + 408 + 66 * 2 + 64 + 16 * 17 + 8) * elem + 15) & ~size_t(15);
+static size_t eigh_tridiag_lds_bytes(size_t elem, int64_t n) {  // A, 3 pad, 408 scratch, d / e (66 each), tau, T_b, 8 control words, d / e^2 of the Sturm counts (2 x 64, 16-byte aligned)
+  return (((size_t)n * (n + 1) + 3 + 408 + 66 * 2 + 64 + 16 * 17 + 8 + 4 + 128) * elem + 15) & ~size_t(15);
 }
 
 
