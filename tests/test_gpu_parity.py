@@ -672,6 +672,39 @@ def test_metric_config_vs_oracle():
         assert tt_rel_err(ours, [c[i] for c in inp]) <= 2e-5  # rank-32 redundant input is reproduced
 
 
+def test_mixed_rank_batch_vs_oracle():
+    """A batch whose items take DIFFERENT routes through the rank-revealing sweep (decided per item on the device): a rank-inflated
+    train (g + g, numerical rank 32 of 64: packed rows, 32 x 32 eigenproblems, flat spectra), a genuine rank-64 train (nothing
+    packed, full-size eigenproblems, the cut goes through a flat spectrum) and a train of numerical rank 20 (packed; 12 of the
+    32 kept directions are null: orthonormal completion).  Every item: the oracle's ranks, right-orthonormal cores, and an
+    approximation error equal to the oracle's (the truncated subspace of a flat spectrum is not unique: the trains themselves
+    are only compared where the input is reproduced)."""
+    N, I = 6, 64
+    torch.manual_seed(41)
+    g32 = oracle.tt_randn([I] * N, 32, dtype=torch.float32)
+    g20 = oracle.tt_randn([I] * N, 20, dtype=torch.float32)
+    pad = [torch.zeros((1 if k == 0 else 12, I, 1 if k == N - 1 else 12), dtype=torch.float32) for k in range(N)]
+    full = oracle.tt_randn([I] * N, 64, dtype=torch.float32)
+    items = [oracle.tt_add(g32, g32), full, oracle.tt_add(oracle.tt_add(g20, g20), oracle.tt_add(pad, pad))]
+    items = [[c / c.abs().max() for c in it] for it in items]          # (comparable core scales inside one batch)
+    assert all([tuple(c.shape) for c in it] == [tuple(c.shape) for c in items[0]] for it in items)
+    inp = [torch.stack([it[k] for it in items]) for k in range(N)]
+    t = gpu_tensor(inp, batch=True)
+    t.round_tt(rmax=32)
+    assert list(t.ranks_tt) == [1] + [32] * (N - 1) + [1]
+    for i, it in enumerate(items):
+        ours = to_list(t.cores, i)
+        ref = oracle.round_tt([c.clone() for c in it], rmax=32, algorithm="svd")
+        assert ranks(ours) == ranks(ref)
+        e_ours, e_ref = tt_rel_err(ours, it), tt_rel_err(ref, it)
+        assert abs(e_ours - e_ref) <= 2e-5 + 1e-3 * e_ref, (i, e_ours, e_ref)
+        if i != 1:
+            assert e_ours <= 2e-5 and tt_rel_err(ours, ref) <= 2e-5
+        assert _right_orth_err(ours) <= 5e-5, (i, _right_orth_err(ours))
+        so, sr = oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)
+        assert all(((x - y).abs().max() / y.max()).item() <= 2e-5 for x, y in zip(so, sr)), i
+
+
 def test_metric_config_properties():
     """Size-independent properties at the metric's full size (batch of 8)."""
     inp = _metric_input(8, seed=1)
