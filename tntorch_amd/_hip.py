@@ -1021,6 +1021,7 @@ KNOB_QR_STAMP_BX, KNOB_QR_STAMP_BY = 3, 4
 KNOB_QR_F64_NW4 = 5
 KNOB_QR_RANK_SKIP = 6
 KNOB_QR_PACK = 7
+KNOB_EIGH_SMALL = 8
 
 
 def set_knob(knob: int, value: int):

@@ -622,6 +622,7 @@ extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
 extern int g_qr_pack;
+extern int g_eigh_small;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 
@@ -1199,6 +1200,10 @@ int ttr_debug_set_knob(int knob, int value) {
       return TTR_OK;
     case TTR_KNOB_QR_STAMP_BY:
       g_qr_dbg_by = value;
+      return TTR_OK;
+    case TTR_KNOB_EIGH_SMALL:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
+      g_eigh_small = value;
       return TTR_OK;
     case TTR_KNOB_QR_PACK:
       TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: packing switch %d outside [0, 3]", value);

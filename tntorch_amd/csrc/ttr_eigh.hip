@@ -50,6 +50,7 @@ struct EighArgs {
   int abs_floor;     // 1: also skip rotations with |G_pq| <= tol * max|G_ii| (plain Gram input: its entries are
                      //    only accurate to eps*||G||, below that level rotations chase rounding noise forever)
   int32_t* sweeps;   // optional [batch]: sweeps used (diagnostics / convergence tests)
+  int top_pre;       // eigh_tridiag_kernel<T, true, 64>: the 32-row launch ran before this one (top_flat[b] != -1: item done)
   // rank rule with the bound on the DEVICE (one double per launch; overrides delta2): eps-mode sweeps enqueue every bond
   // without reading the norm back
   const double* delta2_dev;
@@ -607,14 +608,28 @@ using IC2 = std::integral_constant<int, I>;
 // Workgroup barriers are the only synchronisation: one per reflector block, then one per QL sweep (wave 0 arrives after
 // computing sweep s, wave 1 before replaying it, so wave 0 runs at most two sweeps ahead and never overwrites a buffer
 // that is still being replayed); the number of sweeps is data dependent, so every barrier's sweep carries a `done` word.
-template <typename T, bool TOP = false>
-__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
+//
+// NMAX = 32 (round 4; top-r launches only): the SAME kernel instantiated for problems of at most 32 rows -- the zero-tail items of a
+// 64 x 64 launch, i.e. every bond of a rank-inflated train.  One register allocation serves both waves and both problem sizes:
+// with 64 accumulator registers of Q^T and 64 pivots of the twisted factorisation the 64-row instance spills 107 VGPRs under its
+// four-waves-per-SIMD cap, and every unrolled loop walks 64 guarded steps.  At NMAX = 32 everything is half the size (16 + 32
+// registers), nothing spills, and wave 0 keeps its row of the matrix in REGISTERS through the fully unrolled tridiagonalisation.
+// It runs first; items without a zero tail get top_flat[b] = -1 and are solved by the NMAX = 64 launch that follows, which skips
+// everything else (items the top-r path declines fall through to the QL phase of their own launch, as ever: handing them to the
+// second launch made it as long as its slowest block -- 171 us per launch at B = 2048 for ~1 % of the items, measured).
+template <typename T, bool TOP = false, int NMAX = 64>
+__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
+  static_assert(NMAX == 64 || (NMAX == 32 && TOP), "the 32-row instance only exists for the top-r path");
+  constexpr int NT = NMAX / 16;   // 16-row tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   const int64_t bt = blockIdx.x;
   const int nf = p.n;
+  if constexpr (TOP && NMAX == 64) {
+    if (p.top_pre && p.top_flat[bt] != -1) return;   // (block-uniform) solved by the 32-row launch (which leaves -1 on the others)
+  }
   // Gram matrices (every launch but the block-Jacobi driver's TTR_EIG_MATCH_DIAG pair problems; G_ii = 0 means a zero row /
   // column of a positive semi-definite matrix): a 64 x 64 matrix whose
   // diagonal is exactly zero from index 32 on -- the carry of a bond whose QR packed its rows (ttr_qr_pushed_flag_offset) -- is
@@ -628,6 +643,12 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     if (lane >= 32)
       for (int pt = 0; pt < p.gparts; ++pt) dg += fabs(Gd[pt * p.stride_gpart]);
     if (__ballot(dg != T(0)) == 0ull) n_shrunk = 32;
+  }
+  if constexpr (NMAX == 32) {
+    if (n_shrunk != 32) {   // (block-uniform) not this launch's item
+      if (tid == 0) p.top_flat[bt] = -1;
+      return;
+    }
   }
   const int n = n_shrunk;
   const int ld = n + 1;
@@ -758,7 +779,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
   if (TOP && tid == 0) badf[0] = 0;
   // eigenvalues of this lane's group + the twisted factorisation of this lane's vector (everything a wave needs comes from
   // d / e in LDS, which are final before the tridiagonalisation's last barrier)
-  T Dp[64];      // D+_i for i <= twist, D-_i above it
+  T Dp[NMAX];    // D+_i for i <= twist, D-_i above it
   int twist = 0;
   T lam_vec = T(0), pivmin = T(0);
   auto select = [&]() __attribute__((always_inline)) {
@@ -834,7 +855,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     const T lam = lam_vec;
     T q = dv[0] - lam;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < NMAX; ++i) {
       if (i < n) {
         if (fabs(q) < pivmin) q = -pivmin;
         Dp[i] = q;
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     {
       T qm = T(0);
 #pragma unroll
-      for (int i = 63; i >= 0; --i) {
+      for (int i = NMAX - 1; i >= 0; --i) {
         if (i < n) {
           if (i == n - 1) qm = dv[i] - lam;
           else { const T e = ev[i]; if (fabs(qm) < pivmin) qm = -pivmin; qm = dv[i] - lam - fdiv_fast(e * e, qm); }
@@ -860,7 +881,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     {
       T qm = T(0);
 #pragma unroll
-      for (int i = 63; i >= 1; --i) {
+      for (int i = NMAX - 1; i >= 1; --i) {
         if (i < n) {
           if (i == n - 1) qm = dv[i] - lam;
           else { const T e = ev[i]; qm = dv[i] - lam - fdiv_fast(e * e, qm); }
@@ -876,7 +897,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     T nrm2 = T(1), xc = T(0);
     if (kWrite && twist < n) A[twist * ZLD + jv] = scale;
 #pragma unroll
-    for (int i = 62; i >= 0; --i) {  // upwards
+    for (int i = NMAX - 2; i >= 0; --i) {  // upwards
       if (i + 1 < n) {
         if (i + 1 == twist) xc = T(1);
         if (i < twist) {
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     }
     xc = T(0);
 #pragma unroll
-    for (int i = 0; i < 63; ++i) {  // downwards
+    for (int i = 0; i < NMAX - 1; ++i) {  // downwards
       if (i + 1 < n) {
         if (i == twist) xc = T(1);
         if (i >= twist) {
@@ -919,6 +940,79 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
     // registers (one entry per lane) and are broadcast through LDS arrays, the row is walked in
     // chunks of eight (loads, arithmetic, stores -- the element-by-element read-modify-write through LDS was serialised at
     // the full LDS latency by the possible aliasing of A with the broadcast arrays).
+    if constexpr (NMAX == 32) {
+      // The lane's ROW lives in registers (16 pairs) and the k loop is fully unrolled: column k of the own row, the chunks a step
+      // still touches (columns > k) and every register index are compile-time constants -- no row loads / stores through LDS
+      // (cycle stamps of one generic step at n = 32: 964 of 3.1 k cycles in the matrix-vector product, 1060 in the rank-2 update,
+      // nearly all of it 4-byte LDS traffic: the row stride n + 1 is odd).  Only the reflector (for wave 1's Q formation), d, e
+      // and tau go to LDS.  Same arithmetic as the generic loop below.
+      typedef T R2 __attribute__((ext_vector_type(2)));
+      R2 a2[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const T lo = (lane < n && 2 * j < n) ? rowp[2 * j] : T(0), hi = (lane < n && 2 * j + 1 < n) ? rowp[2 * j + 1] : T(0);
+        a2[j] = R2{lo, hi};
+      }
+#pragma unroll
+      for (int k = 0; k < 31; ++k) {
+        if (k + 1 < n) {   // (wave-uniform)
+          const bool below = lane >= k + 2 && lane < n;
+          const T ak = a2[k >> 1][k & 1];
+          const T xr = (lane >= k + 1 && lane < n) ? ak : T(0);
+          const T x = below ? xr : T(0);
+          const T alpha = lane_get(xr, k + 1);
+          const T xn2 = wave_sum_dpp(x * x);
+          T beta = alpha, t = T(0), v = (lane == k + 1) ? T(1) : T(0);
+          if (xn2 != T(0)) {
+            T scale;
+            householder_scalars(alpha, xn2, beta, t, scale);
+            if (below) v = x * scale;
+          }
+          if (lane == 0) { ev[k] = beta; tauv[k] = t; }
+          if (t != T(0)) {
+            const bool act = lane >= k + 1 && lane < n;
+            vsh[lane] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            R2 p0 = {T(0), T(0)}, p1 = {T(0), T(0)};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (4 * c + 3 >= k + 1 && 4 * c < n) {   // (columns <= k: v = 0 exactly)
+                const T4 vv = *reinterpret_cast<const T4*>(&vsh[4 * c]);
+                p0 += a2[2 * c] * R2{vv[0], vv[1]};
+                p1 += a2[2 * c + 1] * R2{vv[2], vv[3]};
+              }
+            }
+            T pr = (p0[0] + p0[1]) + (p1[0] + p1[1]);
+            pr = act ? pr * t : T(0);
+            const T dot = wave_sum_dpp(pr * v);
+            const T w = pr - T(0.5) * t * dot * v;
+            wsh[lane] = w;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const R2 mv = {-v, -v}, mw = {-w, -w};   // (lanes outside the trailing block: v = w = 0, their rows stay)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (4 * c + 3 >= k + 1 && 4 * c < n) {
+                const T4 vv = *reinterpret_cast<const T4*>(&vsh[4 * c]), ww = *reinterpret_cast<const T4*>(&wsh[4 * c]);
+                a2[2 * c] += mv * R2{ww[0], ww[1]};
+                a2[2 * c + 1] += mv * R2{ww[2], ww[3]};
+                a2[2 * c] += mw * R2{vv[0], vv[1]};
+                a2[2 * c + 1] += mw * R2{vv[2], vv[3]};
+              }
+            }
+          }
+          if (below) rowp[k] = v;  // the reflector below the sub-diagonal, for wave 1
+          if (lane == k) dv[k] = a2[k >> 1][k & 1];
+          if (k == n - 2 && lane == n - 1) { dv[k + 1] = a2[(k + 1) >> 1][(k + 1) & 1]; ev[k + 1] = T(0); }
+          if (k == n - 2) {   // d / e are final: the Sturm counts' copies (both waves read them after the barrier below)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const T el = (lane >= 1 && lane < n) ? ev[lane - 1] : T(0);
+            dsel[lane] = lane < n ? dv[lane] : T(0);
+            e2s[lane] = lane == 0 ? T(0) : fmax(el * el, Num<T>::tiny());
+          }
+          if ((k & 15) == 15 || k == n - 2) __syncthreads();
+        }
+      }
+    } else
     for (int k = 0; k + 1 < n; ++k) {
       const bool below = lane >= k + 2 && lane < n;
       const T xr = (lane >= k + 1 && lane < n) ? rowp[k] : T(0);  // column k of the trailing block (symmetric: own row)
@@ -1169,11 +1263,11 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
         if (row >= n || c >= n - 1 || row <= c) return T(0);
         return row == c + 1 ? T(1) : A[row * ld + c];
       };
-      Acc Z[4][4];
+      Acc Z[NT][NT];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) Z[tm][tn][r] = (16 * tm + MF::row(lane, r) == 16 * tn + cl) ? T(1) : T(0);
       for (int b = 0; b < nblk; ++b) {
@@ -1181,7 +1275,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
         const int c0 = 16 * b;
         {  // S = V_b^T V_b (rows <= c0 of V_b are zero: K starts at the block's first row tile)
           Acc s4[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
-          for (int tm = b; tm < 4; ++tm)
+          for (int tm = b; tm < NT; ++tm)
 #pragma unroll
             for (int sI = 0; sI < 4; ++sI) {
               const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
@@ -1218,35 +1312,41 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         // W = V_b^T Z (16 x 64): A[i][k] = V_b[row k][i], B = Z tiles from the accumulators
-        Acc W[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
-        for (int tm = b; tm < 4; ++tm)
+        Acc W[NT];
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) W[tn] = MF::zero();
+        for (int tm = b; tm < NT; ++tm)
 #pragma unroll
           for (int sI = 0; sI < 4; ++sI) {
             const T a = vb(16 * tm + MF::row(lane, sI), c0 + cl);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
+            for (int tn = 0; tn < NT; ++tn) {
               // (static register index for Z: tm is a runtime loop variable, so select the tile explicitly)
-              const T zb = tm == 0 ? Z[0][tn][sI] : (tm == 1 ? Z[1][tn][sI] : (tm == 2 ? Z[2][tn][sI] : Z[3][tn][sI]));
+              T zb;
+              if constexpr (NT == 4) zb = tm == 0 ? Z[0][tn][sI] : (tm == 1 ? Z[1][tn][sI] : (tm == 2 ? Z[2][tn][sI] : Z[3][tn][sI]));
+              else zb = tm == 0 ? Z[0][tn][sI] : Z[1][tn][sI];
               W[tn] = MF::mma(a, zb, W[tn]);
             }
           }
         // W2 = T_b^T W
-        Acc W2[4] = {MF::zero(), MF::zero(), MF::zero(), MF::zero()};
+        Acc W2[NT];
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) W2[tn] = MF::zero();
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) {
           const T a = Tb[MF::row(lane, sI) * SLD + cl];
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn) W2[tn] = MF::mma(a, W[tn][sI], W2[tn]);
+          for (int tn = 0; tn < NT; ++tn) W2[tn] = MF::mma(a, W[tn][sI], W2[tn]);
         }
         // Z -= V_b W2 (row tiles above the block's first row are untouched: V_b is zero there)
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
+        for (int tm = 0; tm < NT; ++tm) {
           if (tm < b) continue;  // wave-uniform
 #pragma unroll
           for (int sI = 0; sI < 4; ++sI) {
             const T a = -vb(16 * tm + cl, c0 + MF::row(lane, sI));
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
+            for (int tn = 0; tn < NT; ++tn) Z[tm][tn] = MF::mma(a, W2[tn][sI], Z[tm][tn]);
           }
         }
       }
@@ -1270,9 +1370,9 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
         }
         if (taken) {
           // ---- 4. V^T = P (Q Z)^T on the matrix cores
-          T zr[4][4][2];  // Z[16 tm + row(lane, s)][16 tv + cl]
+          T zr[NT][4][2];  // Z[16 tm + row(lane, s)][16 tv + cl]
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
+          for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1280,13 +1380,13 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
                 const int row = 16 * tm + MF::row(lane, s), col = 16 * tv + cl;
                 zr[tm][s][tv] = (row < n && col < rsel) ? A[row * ZLD + col] * invn[col] : T(0);
               }
-          Acc C[2][4];  // (Q Z)^T: rows = vector, columns = matrix row
+          Acc C[2][NT];  // (Q Z)^T: rows = vector, columns = matrix row
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti) {
+          for (int ti = 0; ti < NT; ++ti) {
 #pragma unroll
             for (int tv = 0; tv < 2; ++tv) C[tv][ti] = MF::zero();
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+            for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
               for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1300,7 +1400,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
             for (int tw = 0; tw < 2; ++tw) {
               S[tv][tw] = MF::zero();
 #pragma unroll
-              for (int tm = 0; tm < 4; ++tm)
+              for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) S[tv][tw] = MF::mma(zr[tm][s][tv], zr[tm][s][tw], S[tv][tw]);
             }
@@ -1350,7 +1450,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
           TTR_ESTAMP1();
           T* __restrict__ Vo = p.V + bt * p.strideV;
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
+          for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int tv = 0; tv < 2; ++tv) {
               Acc X = MF::zero();
@@ -1372,9 +1472,9 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 ? 4 : 2)) void eigh_trid
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // Q[j][i] = X[i][j]: the transposed store (wave 0 no longer reads A: its last access is before the last block's barrier)
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * tm + MF::row(lane, r), j = 16 * tn + cl;
@@ -1612,6 +1712,7 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
 }
 
 // pass 1 of a batch-mode bond, n <= 64: the r largest eigenpairs (flat[b] = 1) or the full QL decomposition (flat[b] = 0) per item
+int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 #ifdef TTR_EIGH_STAMPS
 static void* g_eigh_stamps = nullptr;   // diagnostics build: cycle stamps of matrix 0 of the next ttr_eigh_top launches (>= 64 int64)
 extern "C" void ttr_debug_set_eigh_stamps(void* p) { g_eigh_stamps = p; }
@@ -1631,6 +1732,11 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
   p.ws = (T*)g_eigh_stamps;
 #endif
   ProfScope prof(TTR_PROF_EIGH, stream);
+  if (n == 64 && flat && g_eigh_small) {   // zero-tail items first, in the 32-row instance (see the kernel)
+    hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
+    TTR_HIP_CHECK(hipGetLastError());
+    p.top_pre = 1;
+  }
   hipLaunchKernelGGL((eigh_tridiag_kernel<T, true>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
