@@ -38,6 +38,8 @@ for _ in range(2):
     out = step()
 torch.cuda.synchronize()
 _hipops.STREAM_CHUNKS_ENABLED = False
+step()   # (untimed: the kernels' first run on the single stream's queue -- scratch sizing, see bench.py)
+torch.cuda.synchronize()
 _hip.prof_enable(True)
 out = step()
 torch.cuda.synchronize()
