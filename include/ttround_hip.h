@@ -520,9 +520,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      item-major variants (measured without gain: the dispatcher stalls on alternating long / short
  *                      workgroups); 0 = never (required for ttr_qr_apply_pushed_gram, whose epilogue assumes the unpacked map). */
 #define TTR_KNOB_QR_PACK 7
-/*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top on 64 x 64 matrices first runs the 32-row instance of its kernel over the
- *                      zero-tail items (Gram matrices of packed bonds) and then the 64-row one over the rest; 0 = one launch,
- *                      the 64-row instance shrinks such items itself (A/B). */
+/*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
+ *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
+ *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items
+ *                      itself (A/B). */
 #define TTR_KNOB_EIGH_SMALL 8
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);

@@ -50,7 +50,7 @@ struct EighArgs {
   int abs_floor;     // 1: also skip rotations with |G_pq| <= tol * max|G_ii| (plain Gram input: its entries are
                      //    only accurate to eps*||G||, below that level rotations chase rounding noise forever)
   int32_t* sweeps;   // optional [batch]: sweeps used (diagnostics / convergence tests)
-  int top_pre;       // eigh_tridiag_kernel<T, true, 64>: the 32-row launch ran before this one (top_flat[b] != -1: item done)
+  int top_pre;       // eigh_tridiag_kernel<T, *, 64>: the 32-row launch ran before this one (info[b] != -1: item done)
   // rank rule with the bound on the DEVICE (one double per launch; overrides delta2): eps-mode sweeps enqueue every bond
   // without reading the norm back
   const double* delta2_dev;
@@ -614,12 +614,12 @@ using IC2 = std::integral_constant<int, I>;
 // with 64 accumulator registers of Q^T and 64 pivots of the twisted factorisation the 64-row instance spills 107 VGPRs under its
 // four-waves-per-SIMD cap, and every unrolled loop walks 64 guarded steps.  At NMAX = 32 everything is half the size (16 + 32
 // registers), nothing spills, and wave 0 keeps its row of the matrix in REGISTERS through the fully unrolled tridiagonalisation.
-// It runs first; items without a zero tail get top_flat[b] = -1 and are solved by the NMAX = 64 launch that follows, which skips
-// everything else (items the top-r path declines fall through to the QL phase of their own launch, as ever: handing them to the
+// It runs first (top-r launches and plain QL launches on Gram matrices alike); items without a zero tail get info[b] = -1 and are
+// solved by the NMAX = 64 launch that follows, which skips everything else (items the top-r path declines fall through to the QL phase of their own launch, as ever: handing them to the
 // second launch made it as long as its slowest block -- 171 us per launch at B = 2048 for ~1 % of the items, measured).
 template <typename T, bool TOP = false, int NMAX = 64>
 __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
-  static_assert(NMAX == 64 || (NMAX == 32 && TOP), "the 32-row instance only exists for the top-r path");
+  static_assert(NMAX == 64 || NMAX == 32, "64-row kernel and its 32-row instance");
   constexpr int NT = NMAX / 16;   // 16-row tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) 
   const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   const int64_t bt = blockIdx.x;
   const int nf = p.n;
-  if constexpr (TOP && NMAX == 64) {
-    if (p.top_pre && p.top_flat[bt] != -1) return;   // (block-uniform) solved by the 32-row launch (which leaves -1 on the others)
+  if constexpr (NMAX == 64) {
+    if (p.top_pre && p.info[bt] != -1) return;   // (block-uniform) solved by the 32-row launch (which leaves info = -1 on the others)
   }
   // Gram matrices (every launch but the block-Jacobi driver's TTR_EIG_MATCH_DIAG pair problems; G_ii = 0 means a zero row /
   // column of a positive semi-definite matrix): a 64 x 64 matrix whose
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) 
   }
   if constexpr (NMAX == 32) {
     if (n_shrunk != 32) {   // (block-uniform) not this launch's item
-      if (tid == 0) p.top_flat[bt] = -1;
+      if (tid == 0) p.info[bt] = -1;
       return;
     }
   }
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) 
           if (below) rowp[k] = v;  // the reflector below the sub-diagonal, for wave 1
           if (lane == k) dv[k] = a2[k >> 1][k & 1];
           if (k == n - 2 && lane == n - 1) { dv[k + 1] = a2[(k + 1) >> 1][(k + 1) & 1]; ev[k + 1] = T(0); }
-          if (k == n - 2) {   // d / e are final: the Sturm counts' copies (both waves read them after the barrier below)
+          if (TOP && k == n - 2) {   // d / e are final: the Sturm counts' copies (both waves read them after the barrier below)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const T el = (lane >= 1 && lane < n) ? ev[lane - 1] : T(0);
             dsel[lane] = lane < n ? dv[lane] : T(0);
@@ -1640,6 +1640,7 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
 }
 
+int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                       int64_t stride_gpart, void* V,
@@ -1666,8 +1667,13 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   p.max_sweeps = sizeof(T) == 8 ? 40 : 30;
   p.abs_floor = abs_floor;
   p.sweeps = sweeps;
-  if (abs_floor == TTR_SOLVER_TRIDIAG && n <= 64) {  // tridiagonal QL, one wave per matrix
+  if (abs_floor == TTR_SOLVER_TRIDIAG && n <= 64) {  // tridiagonal QL, two waves per matrix
     ProfScope prof(TTR_PROF_EIGH, stream);
+    if (n == 64 && g_eigh_small && eig_mode != TTR_EIG_MATCH_DIAG) {   // zero-tail Gram matrices first, in the 32-row instance
+      hipLaunchKernelGGL((eigh_tridiag_kernel<T, false, 32>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
+      TTR_HIP_CHECK(hipGetLastError());
+      p.top_pre = 1;
+    }
     hipLaunchKernelGGL(eigh_tridiag_kernel<T>, dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     return TTR_OK;
@@ -1712,7 +1718,6 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
 }
 
 // pass 1 of a batch-mode bond, n <= 64: the r largest eigenpairs (flat[b] = 1) or the full QL decomposition (flat[b] = 0) per item
-int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 #ifdef TTR_EIGH_STAMPS
 static void* g_eigh_stamps = nullptr;   // diagnostics build: cycle stamps of matrix 0 of the next ttr_eigh_top launches (>= 64 int64)
 extern "C" void ttr_debug_set_eigh_stamps(void* p) { g_eigh_stamps = p; }
@@ -1732,7 +1737,7 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
   p.ws = (T*)g_eigh_stamps;
 #endif
   ProfScope prof(TTR_PROF_EIGH, stream);
-  if (n == 64 && flat && g_eigh_small) {   // zero-tail items first, in the 32-row instance (see the kernel)
+  if (n == 64 && g_eigh_small) {   // zero-tail items first, in the 32-row instance (see the kernel)
     hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     p.top_pre = 1;
