@@ -411,3 +411,18 @@ def test_verbose_prints_the_reference_stage_lines(capsys):
     assert [ln.split(":")[0] for ln in capsys.readouterr().out.splitlines()] == ["Time (SVD)", "Time (product)"]
     t.round_tt(rmax=2)
     assert capsys.readouterr().out == ""
+
+
+def test_idxs_are_built_on_first_use_and_travel_with_the_tensor():
+    """tensor.py:433-435: `idxs` defaults to one arange per mode.  Here they are built on first access (N device launches per
+    constructed tensor otherwise, on a latency-bound path); given ones are kept, clones share them, assignment works."""
+    cores = oracle.tt_randn([3, 4, 5], 2, dtype=torch.float64)
+    t = tn.Tensor([c.clone() for c in cores])
+    assert t._idxs is None
+    assert [i.tolist() for i in t.idxs] == [list(range(3)), list(range(4)), list(range(5))]
+    assert t._idxs is not None and t.clone().idxs is t.idxs
+    given = [torch.arange(3), torch.tensor([0, 1, 1, 0]), torch.arange(5)]
+    u = tn.Tensor([c.clone() for c in cores], idxs=given)
+    assert u.idxs is given and u.clone().idxs is given
+    u.idxs = None
+    assert [len(i) for i in u.idxs] == [3, 4, 5]
