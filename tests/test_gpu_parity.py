@@ -705,6 +705,33 @@ def test_mixed_rank_batch_vs_oracle():
         assert all(((x - y).abs().max() / y.max()).item() <= 2e-5 for x, y in zip(so, sr)), i
 
 
+@pytest.mark.parametrize("batch", [True, False])
+def test_rank_cap_above_the_numerical_rank_of_a_packed_train(batch):
+    """rmax = 48 on a train of numerical rank 32 in 64 (g + g): every bond packs, its Gram matrix is solved as a 32 x 32 problem
+    (V = blockdiag(V11, I), sigma[32:] = 0), and 16 of the 48 directions under the cap are null -- batch mode keeps them
+    (orthonormal completion); the non-batch call applies the reference's rank rule to exact zeros (see below)."""
+    N, I = 5, 64
+    torch.manual_seed(7)
+    g = oracle.tt_randn([I] * N, 32, dtype=torch.float32)
+    it = [c / c.abs().max() for c in oracle.tt_add(g, g)]
+    if batch:
+        t = gpu_tensor([torch.stack([c, c]) for c in it], batch=True)
+    else:
+        t = gpu_tensor(it)
+    t.round_tt(rmax=48)
+    ours = to_list(t.cores, 1) if batch else to_list(t.cores)
+    ref = oracle.round_tt([c.clone() for c in it], rmax=48, algorithm="svd")
+    if batch:
+        assert ranks(ours) == [1] + [48] * (N - 1) + [1]     # round.py:149-150: batch mode keeps the cap
+    else:
+        # round.py:147-158 with delta = 0 cuts singular values that are EXACTLY zero.  The oracle's LAPACK returns 1e-7-level
+        # noise for the 16 null directions and keeps them (rank 48); here they are exact zeros (zero-tail Gram matrix) and
+        # the same rule cuts them: the numerical rank, never more than the reference's (DESIGN section 6)
+        assert ranks(ref) == [1] + [48] * (N - 1) + [1] and ranks(ours) == [1] + [32] * (N - 1) + [1]
+    assert tt_rel_err(ours, it) <= 2e-5
+    assert _right_orth_err(ours) <= 5e-5
+
+
 def test_metric_config_properties():
     """Size-independent properties at the metric's full size (batch of 8)."""
     inp = _metric_input(8, seed=1)
