@@ -286,6 +286,112 @@ def parity_check(inp, out, items):
             "ok": bool(ranks_ok and worst <= 2e-5)}
 
 
+LINE_LIMIT = 4096   # bytes of the ONE stdout line (round 4's 20.6 KB line was not parsed by the driver)
+FULL_SIDECAR = os.path.join("profiles", "bench_full_latest.json")
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (significant digits, not decimals: 1.3e6 cores/s and 2.6e-6 errors both survive)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{nd}g}")
+
+
+def _pick(d, keys, nd=4):
+    if not isinstance(d, dict):
+        return {}
+    out = {k: _r(d[k], nd) for k in keys if d.get(k) is not None}
+    return {k: v for k, v in out.items() if v is not None}   # (NaN / Infinity round to None: dropped, never printed)
+
+
+def compact_line(res):
+    """The ONE line bench.py prints (contract fields + `roofline` + `cpu_baseline` + one-number summaries); everything else
+    -- `configs`, `extras`, `roofline_per_kernel`, per-step records -- goes to the sidecar ``FULL_SIDECAR`` and to stderr.
+    tests/test_bench_cpu.py pins ``len(line) < LINE_LIMIT`` and the fields the driver checks."""
+    out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 7), _r(out["ms_per_step"], 6)
+    out["config"] = _pick(res.get("config", {}), ("workload", "tensors_per_gpu_per_step", "algorithm", "streams_per_gpu", "parallelism"))
+    ro = res.get("roofline") or {}
+    out["roofline"] = _pick(ro, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "frac_algorithmic",
+                                 "frac_hbm_traffic", "mfma_util", "avg_launch_ms", "launches", "input_aware"))
+    out["roofline"].setdefault("traffic", None)
+    cb = res.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "algorithm"))
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        out["speedup_vs_cpu_best"] = _r(res.get("speedup_vs_cpu_best"))
+    if res.get("parity"):
+        out["parity"] = _pick(res["parity"], ("ok", "rel_err_vs_oracle_svd", "ranks_identical", "bound", "error"))
+    out["sweep"] = _pick(res, ("gflops", "whole_sweep_hbm_frac", "whole_sweep_frac_of_mfma_f32_peak", "tensors_per_s"))
+    if res.get("kernel_ms_per_step"):
+        out["kernel_ms_per_step"] = {k: _r(v, 3) for k, v in res["kernel_ms_per_step"].items()}
+    if res.get("sweep_roofline"):
+        out["sweep_roofline"] = {k: _pick(v, ("bound", "frac", "frac_algorithmic")) for k, v in res["sweep_roofline"].items()}
+    if res.get("gather"):
+        out["gather"] = _pick(res["gather"], ("mode", "collectives_in_timed_region", "alone_ms", "compute_only_ms_per_step",
+                                              "bytes_per_peer_per_step", "per_link_GBs", "hidden_under_compute"))
+    ex = {}
+    for k, v in (res.get("extras") or {}).items():
+        if not isinstance(v, dict):
+            continue
+        e = _pick(v, ("ms_per_step", "cores_per_s", "speedup_vs_cpu_best", "ms_per_call"))
+        if "oracle_check" in v:
+            e["ok"] = bool(v["oracle_check"].get("ok"))
+        if "error" in v:
+            e["error"] = str(v["error"])[:80]
+        ex[k] = e
+    if ex:
+        out["extras"] = ex
+    cf = {}
+    for k, v in (res.get("configs") or {}).items():
+        if not isinstance(v, dict):
+            continue
+        e = _pick(v, ("ms",))
+        r2 = v.get("roofline") or {}
+        e.update(_pick(r2, ("bound", "frac")))
+        if isinstance(v.get("oracle_check"), dict):
+            e["ok"] = bool(v["oracle_check"].get("ok"))
+        for sub, key in (("single_tensor", "ms"), ("lowrank_variant", "ms"), ("whole_config_on_one_gpu", "ms")):
+            if isinstance(v.get(sub), dict) and key in v[sub]:
+                e[f"{sub}_ms"] = _r(v[sub][key])
+        if "speedup_vs_cpu" in v or "speedup_vs_cpu_extrapolated" in v:
+            e["x_cpu"] = _r(v.get("speedup_vs_cpu", v.get("speedup_vs_cpu_extrapolated")), 3)
+        if "error" in v:
+            e["error"] = str(v["error"])[:80]
+        cf[k] = e
+    if cf:
+        out["configs"] = cf
+    out["full"] = FULL_SIDECAR
+    line = json.dumps(out, allow_nan=False)
+    # (belt and braces: a line above the limit loses its optional blocks, never its contract fields)
+    for drop in ("kernel_ms_per_step", "sweep_roofline", "extras", "configs", "gather", "sweep"):
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, allow_nan=False)
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(res):
+    """Full object -> sidecar (+ gpurun_out/ when it exists, + stderr); compact line -> stdout (the LAST line, flushed)."""
+    full = json.dumps(res, default=str)
+    for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, os.path.basename(FULL_SIDECAR)), "w") as f:
+                    f.write(full + "\n")
+        except OSError as e:  # (a read-only tree must not cost the line)
+            print(f"bench.py: could not write {d}: {e!r}", file=sys.stderr)
+    print("bench.py full result: " + full, file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(res))
+    sys.stdout.flush()
+
+
 def timed_steps(step, drain, fence, warmup, steps, on_timed_start=None):
     out = None
     for _ in range(warmup):
@@ -682,7 +788,7 @@ def main():
             res["speedup_vs_cpu_best"] = cores_per_s / cb["value"]
             if "extras" in res and "single_tensor" in res["extras"]:
                 res["extras"]["single_tensor"]["speedup_vs_cpu_best"] = res["extras"]["single_tensor"]["cores_per_s"] / cb["value"]
-        print(json.dumps(res))
+        emit(res)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

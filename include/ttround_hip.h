@@ -184,6 +184,8 @@ int ttr_qr_apply_pushed(int dtype, int64_t k, int64_t I, int64_t n, int64_t batc
  * G: [batch][parts][k][k] contiguous split partials (both triangles), parts = ttr_qr_apply_pushed_gram_parts(...); the
  * eigensolver sums them on load (ttr_eigh_trunc's gparts).  parts == 0: this shape is not covered (fp32, k = 64, kcols = 32,
  * I a multiple of 8 are), call ttr_qr_apply_pushed + ttr_rowgram instead.  ldo must equal kcols.
+ * Requires TTR_KNOB_QR_PACK == 0 from before the factorisation until after this call (the epilogue walks the unpacked row map
+ * of the level-0 blocks); with the knob != 0 the call returns TTR_E_UNSUPPORTED instead of a Gram matrix with unwritten partials.
  */
 int64_t ttr_qr_apply_pushed_gram_parts(int dtype, int64_t k, int64_t I, int64_t n, int64_t kcols);
 int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t batch,

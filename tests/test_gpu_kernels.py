@@ -854,7 +854,24 @@ def test_qr_apply_pushed_gram(Rin, I, n):
     C = torch.randn(B, n, kc, generator=g).cuda()
     f = h.qr_factor_pushed(Rm, core)
     plain = h.qr_apply(f, C)
-    out, G = h.qr_apply(f, C, want_gram=True)
+    # row packing (default knob) and the fused Gram epilogue exclude each other: refused, not a Gram matrix with unwritten partials
+    with pytest.raises(RuntimeError):
+        h.qr_apply(f, C, want_gram=True)
+    h.set_knob(h.KNOB_QR_PACK, 0)
+    try:
+        f = h.qr_factor_pushed(Rm, core)
+        assert torch.equal(h.qr_apply(f, C), plain)   # (full-rank Rm: nothing packed either way)
+        out, G = h.qr_apply(f, C, want_gram=True)
+        out5, G5 = h.qr_apply(f, C[:, :, :5].contiguous(), want_gram=True)
+        # rank-32 Rm (what packs with the knob on): unpacked map, every partial written
+        Rlow = (torch.randn(B, k, 32, generator=g) @ torch.randn(B, 32, Rin, generator=g)).cuda()
+        flow = h.qr_factor_pushed(Rlow, core)
+        outl, Gl = h.qr_apply(flow, C, want_gram=True)
+    finally:
+        h.set_knob(h.KNOB_QR_PACK, 3)
+    Ml = outl.double().reshape(B, k, I * kc)
+    refl = Ml @ Ml.transpose(1, 2)
+    assert Gl is not None and (Gl.double().sum(dim=1) - refl).abs().max() / refl.abs().max() < 2e-6
     assert G is not None and G.shape == (B, I // 8, k, k)
     assert torch.equal(out, plain)
     M = out.double().reshape(B, k, I * kc)
@@ -867,7 +884,6 @@ def test_qr_apply_pushed_gram(Rin, I, n):
     sv = torch.linalg.svdvals(M)
     assert (sig.double() ** 2 - sv ** 2).abs().max() / sv.max() ** 2 < 1e-5  # eigenvalues of a Gram matrix: absolute accuracy
     # shapes the fused epilogue does not cover fall back to (Out, None)
-    out5, G5 = h.qr_apply(f, C[:, :, :5].contiguous(), want_gram=True)
     assert G5 is None and out5.shape == (B, k * I, 5)
 
 

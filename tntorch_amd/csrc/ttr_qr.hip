@@ -1606,6 +1606,12 @@ int qr_apply_pushed_dispatch(int dtype, int64_t k, int64_t I, int64_t n, int64_t
   if (rc != TTR_OK) return rc;
   TTR_REQUIRE(!G || (qr_apply_pushed_gram_parts(dtype, k, I, n, kc) > 0 && ldo == kc), TTR_E_UNSUPPORTED,
               "ttr_qr_apply_pushed_gram: shape not covered by the fused Gram epilogue (see ttr_qr_apply_pushed_gram_parts)");
+  // The Gram epilogue walks the UNPACKED row map of the level-0 blocks: a factorisation whose items may have packed their rows
+  // (TTR_KNOB_QR_PACK != 0 when ttr_qr_factor_pushed ran) cannot feed it -- an absorbed block would leave its partial unwritten.
+  // The knob has to be 0 from before the factorisation until after this call (tntorch_amd/_hipops.py: TTR_FUSE_APPLY_GRAM=1).
+  TTR_REQUIRE(!G || g_qr_pack == 0, TTR_E_UNSUPPORTED,
+              "ttr_qr_apply_pushed_gram: row packing is enabled (TTR_KNOB_QR_PACK = %d); the fused Gram epilogue needs it off "
+              "for the factorisation AND the apply", g_qr_pack);
   const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32)
     return apply_typed<float>(m, n, batch, ws, ws_bytes, C, ldc, strideC, kc, Out, ldo, strideO, (int)k, (int)I, G, stream, 1, skip_zero_rows);
