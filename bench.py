@@ -267,7 +267,8 @@ def cpu_baseline(budget_s=25.0):
 
 def parity_check(inp, out, items):
     """Items of the LAST timed step against the oracle's default algorithm (LAPACK gesdd, round.py:96): identical ranks,
-    ||ours - oracle|| / ||oracle|| through float64 TT inner products (tests/test_gpu_parity.py states the 2e-5 bound)."""
+    ||ours - oracle|| / ||oracle|| through float64 TT inner products (1e-5 in fp32, the bound of
+    tests/test_gpu_parity.py::test_metric_config_two_stream_path_vs_oracle; measured 2.6e-6)."""
     import math
 
     import oracle
@@ -282,8 +283,8 @@ def parity_check(inp, out, items):
         b = [c.double() for c in ref]
         aa, bb, ab = oracle.tt_dot(a, a), oracle.tt_dot(b, b), oracle.tt_dot(a, b)
         worst = max(worst, math.sqrt(max((aa + bb - 2 * ab).item(), 0.0) / bb.item()))
-    return {"items": list(items), "rel_err_vs_oracle_svd": worst, "ranks_identical": ranks_ok, "bound": 2e-5,
-            "ok": bool(ranks_ok and worst <= 2e-5)}
+    return {"items": list(items), "rel_err_vs_oracle_svd": worst, "ranks_identical": ranks_ok, "bound": 1e-5,
+            "ok": bool(ranks_ok and worst <= 1e-5)}
 
 
 LINE_LIMIT = 4096   # bytes of the ONE stdout line (round 4's 20.6 KB line was not parsed by the driver)

@@ -522,6 +522,15 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      item-major variants (measured without gain: the dispatcher stalls on alternating long / short
  *                      workgroups); 0 = never (required for ttr_qr_apply_pushed_gram, whose epilogue assumes the unpacked map). */
 #define TTR_KNOB_QR_PACK 7
+/*   (8 = TTR_KNOB_EIGH_SMALL, below)
+ *   TTR_KNOB_RANK_NOISE_FLOOR  c (default 0 = off): the rank rule of round.py:147-158 (eps mode: ttr_eigh_trunc with use_delta,
+ *                      ttr_spectrum_flat) sees every singular value at no less than c eps sigma_0.  Background: the zero-tail
+ *                      eigenproblems of a rank-deficient bond (t = g + g) return EXACT zeros for the null directions, which the
+ *                      rule cuts at any delta >= 0; LAPACK's gesdd -- the reference -- returns rounding noise of order eps sigma_0
+ *                      there, so `round_tt(rmax=48)` (eps = 1e-14 by default) on a numerically rank-32 fp32 train keeps 32..48
+ *                      directions depending on that noise.  c = 1 reproduces the reference's usual outcome (fp32: the cap;
+ *                      fp64: eps^2 < 1e-28, still cut); tntorch_amd sets it from TTR_STRICT_RANKS=1. */
+#define TTR_KNOB_RANK_NOISE_FLOOR 9
 /*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

@@ -263,7 +263,7 @@ def test_host_cp_als_golden():
         # (MKL's lstsq / eigh are not bit-reproducible from run to run, not even single-threaded: the factors of identical calls differ
         # by 0 ... 8e-11 here -- mostly exactly 0, the rank-5 case is the sensitive one -- and the reconstruction by up to 2e-13)
         assert max((a - b).abs().max().item() for a, b in zip(t.cores, g[name])) < 1e-7
-        assert abs(tn.relative_error(g["inp"], t).item() - runs[name]["relerr"]) < 1e-10
+        assert abs(tn.relative_error(g["inp"], t).item() - runs[name]["relerr"]) < 1e-12   # (observed: up to 2e-13)
     # CP factors behave as TT cores with diagonal slices everywhere else (tensor.py:1717-1769)
     ref = oracle.cp_to_dense(g["r5_it4"])
     assert (t.torch() - ref).norm() / ref.norm() < 2e-12   # (0 on most runs; 2.2e-13 seen once in ~30: a bound ~10x the observed noise)

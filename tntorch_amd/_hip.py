@@ -202,6 +202,10 @@ def lib():
             k, v = item.split("=")
             if L.ttr_debug_set_knob(int(k), int(v)) != 0:
                 raise ValueError(f"TTR_KNOBS: ttr_debug_set_knob({k}, {v}) rejected: " + L.ttr_last_error().decode(errors="replace"))
+        # TTR_STRICT_RANKS=1: eps-mode rank rule with LAPACK's noise floor for null directions (header: TTR_KNOB_RANK_NOISE_FLOOR;
+        # INTEGRATION.md "Ranks of rank-deficient trains")
+        if os.environ.get("TTR_STRICT_RANKS", "0") == "1":
+            L.ttr_debug_set_knob(9, 1)
         _lib = L
     return _lib
 
@@ -656,9 +660,10 @@ def bj_pair_tables(nbk: int, device) -> torch.Tensor:
 
 @_on_device
 def bj_sweeps(G: torch.Tensor, V: torch.Tensor, b: int, relative: bool, tol: float, max_sweeps: int) -> torch.Tensor:
-    """Block-Jacobi sweeps on G [B, n, n] / V [B, n, n] IN PLACE (ttr_bj_solve / ttr_bj_apply / ttr_bj_control), nothing
-    read back: every launch after convergence returns at once.  Returns the device control block (int32 [4]:
-    converged, -, sweeps performed, -) for diagnostics."""
+    """Block-Jacobi sweeps on G [B, n, n] / V [B, n, n] IN PLACE (ttr_bj_solve / ttr_bj_apply / ttr_bj_control).  The
+    convergence word is read back once per tranche of 8 sweeps (control flow only: the launches of a converged driver return at
+    their first instruction, but each still costs a launch).  Returns the device control block (int32 [4]: converged, -, sweeps
+    performed, -) for diagnostics."""
     L = lib()
     dt = dtype_code(G.dtype)
     Bt, n, _ = G.shape
@@ -1022,6 +1027,7 @@ KNOB_QR_F64_NW4 = 5
 KNOB_QR_RANK_SKIP = 6
 KNOB_QR_PACK = 7
 KNOB_EIGH_SMALL = 8
+KNOB_RANK_NOISE_FLOOR = 9
 
 
 def set_knob(knob: int, value: int):

@@ -113,6 +113,8 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     live = torch.sign(_hip.norm(A.reshape(Bt, -1))).clamp_min(1e-20)
     gen = torch.Generator(device=A.device)
 
+    Bt_all, sel = Bt, None   # (``sel``: positions of the items being refactored inside the full batch)
+
     def factor(perturb):
         """BCGS2 over the panels; ``perturb``: None or the [Bt] scale of the items' perturbation.  -> Q, R, [Bt] collapse flags."""
         R = torch.zeros((Bt, n, n), dtype=A.dtype, device=A.device)
@@ -125,7 +127,11 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
             W = W0.contiguous()
             if perturb is not None:
                 gen.manual_seed(0x5EED + j0)
-                noise = torch.randn((Bt, m, w), dtype=A.dtype, device=A.device, generator=gen)
+                # (drawn for the WHOLE batch and indexed by the items' positions: an item's perturbation does not depend on which
+                # of its neighbours collapsed, so the same tensor rounds bit-identically in any batch)
+                noise = torch.randn((Bt_all, m, w), dtype=A.dtype, device=A.device, generator=gen)
+                if sel is not None:
+                    noise = noise.index_select(0, sel)
                 eye = _hip.scale_batch(torch.eye(w, dtype=A.dtype, device=A.device).expand(Bt, w, w).contiguous(), scale=perturb)
                 _hip.gemm_axpby(noise, eye, W, delta, 1.0)         # W += delta * noise (zero items: += 0; rank-keeping items: untouched)
             else:
@@ -160,9 +166,9 @@ def _qr_blocked(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     elif bad.numel() > 0:
         # only the collapsing items are factored again (gather / scatter of those items: layout copies)
         A_all, live_all = A, live
-        A, live, Bt = A_all.index_select(0, bad).contiguous(), live_all.index_select(0, bad), int(bad.numel())
+        A, live, Bt, sel = A_all.index_select(0, bad).contiguous(), live_all.index_select(0, bad), int(bad.numel()), bad
         Qb, Rb, _ = factor(live)
-        A, live, Bt = A_all, live_all, A_all.shape[0]
+        A, live, Bt, sel = A_all, live_all, A_all.shape[0], None
         Q.index_copy_(0, bad, Qb)
         R.index_copy_(0, bad, Rb)
     return Q, _hip.scale_batch(R, expo=a_exp, expo_sign=+1)
@@ -1214,11 +1220,13 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
     # packed push computes for every other bond (rank-inflated trains: half the rows of the first Gram / projection passes, and
     # the first eigenproblem shrinks to 32 x 32 like the others)
     r32_last = None
-    if (not _FUSE_APPLY_GRAM and Rprev is not None and Rprev.dim() == 3 and Rprev.shape[1] == 64 and Rprev.shape[0] == last.shape[0]
-            and last.shape[2] * last.shape[3] >= 64):
-        r32_last = _hip.carry_rows32(Rprev)
     c[N - 1] = _hip.gemm(Rprev, last.reshape(last.shape[0], last.shape[1], -1)).reshape(
         last.shape[0], Rprev.shape[1], last.shape[2], last.shape[3])
+    if (not _FUSE_APPLY_GRAM and Rprev is not None and Rprev.dim() == 3 and Rprev.shape[1] == 64 and Rprev.shape[0] == last.shape[0]
+            and last.shape[2] * last.shape[3] >= 64):
+        # (the flag is computed on the carry M itself: what is dropped is below c eps ||M||_F whatever the conditioning of the last
+        # core -- round 4 tested R, whose small rows bound those of M only up to ||last||_2)
+        r32_last = _hip.carry_rows32(c[N - 1].reshape(last.shape[0], Rprev.shape[1], -1))
     if expo is not None:  # the last core carries ||X|| / 2^expo: bring it to O(1) as well (see above)
         c[N - 1], _ = _hip.pow2_normalize(c[N - 1], expo_acc=expo)
     st.lap("Orthogonalization time:")   # tensor.py:2032-2035 (here: the factorisations; Q stays implicit)
@@ -1463,7 +1471,10 @@ def dense_tt_svd(
         rn = t.rank
     if e is not None:
         C = _scale_batch(C, e, +1)
-    cores[0] = C.reshape(Bt, 1, shape[0], rn).contiguous()
+    c0 = C.reshape(Bt, 1, shape[0], rn).contiguous()
+    if consume_input and c0.untyped_storage().data_ptr() == X.untyped_storage().data_ptr():
+        c0 = c0.clone()   # (N == 2: the in-place carry IS core 0 -- the result must not live in, nor pin, the consumed input)
+    cores[0] = c0
     return cores  # type: ignore[return-value]
 
 

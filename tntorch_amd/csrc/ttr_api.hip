@@ -139,11 +139,15 @@ __global__ __launch_bounds__(kThreads) void mask_cols_kernel(int64_t rows, int64
 // each other: sigma[keep - 1] >= thr * sigma[0] > 0
 template <typename T>
 __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, const T* __restrict__ sigma, int64_t stride_sigma,
-                                     int use_delta, double delta2, const double* __restrict__ delta2_dev, int32_t* __restrict__ flat) {
+                                     int use_delta, double delta2, const double* __restrict__ delta2_dev, int32_t* __restrict__ flat,
+                                     int noise_c) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  const T* __restrict__ sg = sigma + b * stride_sigma;
-  const T s0 = sg[0];
+  const T* __restrict__ sgr = sigma + b * stride_sigma;
+  const T s0 = sgr[0];
+  // (the rank rule's view of the spectrum: rank_rule in ttr_common.h -- with TTR_KNOB_RANK_NOISE_FLOOR nothing lies below c eps sigma_0)
+  const T nfl = noise_c > 0 ? T(noise_c) * Num<T>::eps() * s0 : T(0);
+  auto sg = [&](int k) { const T v = sgr[k]; return v < nfl ? nfl : v; };
   int kp = keep;
   bool ok = s0 > T(0);
   const double d2 = use_delta ? (delta2_dev ? *delta2_dev : delta2) : 0.0;
@@ -155,26 +159,26 @@ __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, cons
     double acc = 0.0, tail_r = 0.0;
     int tail = 0;
     for (int k = n - 1; k >= 0; --k) {
-      acc += (double)sg[k] * (double)sg[k];
+      acc += (double)sg(k) * (double)sg(k);
       if (acc <= d2) { tail = n - k; tail_r = acc; } else break;
     }
     int r = n - tail;
     if (r < 1) r = 1;
     if (r > keep) {  // the cap decides as long as the rule cannot cut the keep-th value: tail(keep - 1) > delta^2 + E
       double tc = 0.0;
-      for (int k = n - 1; k >= keep - 1; --k) tc += (double)sg[k] * (double)sg[k];
+      for (int k = n - 1; k >= keep - 1; --k) tc += (double)sg(k) * (double)sg(k);
       ok = tc > d2 + E;
       kp = keep;
     } else {
       const int rr = n - tail;  // the rule's rank before the ">= 1" clamp
       const bool cut_safe = tail == 0 || tail_r <= d2 - E;  // what is cut stays cut
       bool keep_safe = true;                                 // the last kept value cannot be cut as well (rr = 0: rank 1 either way)
-      if (rr >= 1) keep_safe = tail_r + (double)sg[rr - 1] * (double)sg[rr - 1] > d2 + E;
+      if (rr >= 1) keep_safe = tail_r + (double)sg(rr - 1) * (double)sg(rr - 1) > d2 + E;
       ok = cut_safe && keep_safe;
       kp = r;
     }
   }
-  flat[b] = (ok && sg[kp - 1] >= thr * s0) ? 1 : 0;
+  flat[b] = (ok && sg(kp - 1) >= thr * s0) ? 1 : 0;
 }
 
 // Block-wide sum of doubles (256 threads), result in every thread.
@@ -622,6 +626,7 @@ extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
 extern int g_qr_pack;
+extern int g_rank_noise_c;
 extern int g_eigh_small;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
@@ -1031,10 +1036,10 @@ int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, in
   ProfScope prof(TTR_PROF_MISC, s);
   if (dtype == TTR_F32)
     hipLaunchKernelGGL(spectrum_flat_kernel<float>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, (float)thr,
-                       (const float*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat);
+                       (const float*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c);
   else
     hipLaunchKernelGGL(spectrum_flat_kernel<double>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, thr,
-                       (const double*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat);
+                       (const double*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
@@ -1204,6 +1209,10 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_EIGH_SMALL:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
       g_eigh_small = value;
+      return TTR_OK;
+    case TTR_KNOB_RANK_NOISE_FLOOR:
+      TTR_REQUIRE(value >= 0 && value <= 1024, TTR_E_INVALID, "ttr_debug_set_knob: rank-rule noise floor %d outside [0, 1024]", value);
+      g_rank_noise_c = value;
       return TTR_OK;
     case TTR_KNOB_QR_PACK:
       TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: packing switch %d outside [0, 3]", value);

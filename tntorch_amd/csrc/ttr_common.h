@@ -207,6 +207,31 @@ struct Num<double> {
   static __device__ __forceinline__ double larfg_floor() { return 1e-290; }
 };
 
+// Rank rule of round.py:147-158 on singular values sorted decreasing: drop the longest tail whose energy is <= delta^2 (`<=`),
+// rank = max(1, min(rmax, n - tail)); rank 0 = the zero guard of round.py:137-145.  `s` holds n_live values, entries
+// n_live .. n_full - 1 are exact zeros that were never computed (zero-tail eigenproblems).  `noise_c` > 0
+// (TTR_KNOB_RANK_NOISE_FLOOR): the rule sees every value at no less than noise_c eps sigma_0 -- what LAPACK's gesdd returns for
+// the null directions of a rank-deficient unfolding (the reference's ranks depend on that noise).
+template <typename T>
+__device__ __forceinline__ int rank_rule(const T* s, int n_live, int n_full, int64_t rmax, int use_delta, T d2, int noise_c) {
+  const int64_t cap = rmax < (int64_t)n_full ? rmax : (int64_t)n_full;
+  if (s[0] < T(1e-13)) return 0;
+  if (!use_delta) return (int)(cap < 1 ? 1 : cap);
+  const T fl = noise_c > 0 ? T(noise_c) * Num<T>::eps() * s[0] : T(0);
+  double acc = 0.0;
+  int tail = 0;
+  for (int k = n_full - 1; k >= 0; --k) {
+    T v = k < n_live ? s[k] : T(0);
+    if (v < fl) v = fl;
+    acc += (double)(v * v);
+    if ((T)acc <= d2) tail = n_full - k; else break;
+  }
+  int64_t rk = n_full - tail;
+  if (rk > cap) rk = cap;
+  if (rk < 1) rk = 1;
+  return (int)rk;
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

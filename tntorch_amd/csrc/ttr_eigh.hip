@@ -54,6 +54,7 @@ struct EighArgs {
   // rank rule with the bound on the DEVICE (one double per launch; overrides delta2): eps-mode sweeps enqueue every bond
   // without reading the norm back
   const double* delta2_dev;
+  int noise_c;           // TTR_KNOB_RANK_NOISE_FLOOR (ttr_common.h: rank_rule)
   // block-Jacobi pair problems (ttr_bj_solve): grid = pairs_per_item * items; problem (item, pair) is the 2b x 2b matrix
   // [[G_ii, G_ij], [G_ji, G_jj]] of blocks i = pair_tab[2 pair], j = pair_tab[2 pair + 1] of the item's n x n matrix
   const int32_t* pair_tab;
@@ -122,26 +123,8 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     const T* __restrict__ si = p.sigma_in + bt * p.stride_sigma_in;
     for (int i = tid; i < n; i += kThreads) p.sigma[bt * p.stride_sigma + i] = si[i];
     if (tid == 0) {  // the rank rule of the regular epilogue, on pass 1's sigma (ttr_spectrum_flat made sure pass 2 would agree)
-      const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
-      int rank;
-      if (si[0] < T(1e-13)) {
-        rank = 0;
-      } else if (!p.use_delta) {
-        rank = (int)(cap < 1 ? 1 : cap);
-      } else {
-        const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
-        double acc = 0.0;
-        int tail = 0;
-        for (int k = n - 1; k >= 0; --k) {
-          acc += (double)(si[k] * si[k]);
-          if ((T)acc <= d2) tail = n - k; else break;
-        }
-        int64_t rk = n - tail;
-        if (rk > cap) rk = cap;
-        if (rk < 1) rk = 1;
-        rank = (int)rk;
-      }
-      p.info[bt] = rank;
+      const T d2 = p.use_delta ? (T)(p.delta2_dev ? *p.delta2_dev : p.delta2) : T(0);
+      p.info[bt] = rank_rule<T>(si, n, n, p.rmax, p.use_delta, d2, p.noise_c);
       if (p.sweeps) p.sweeps[bt] = 0;
     }
     return;
@@ -463,28 +446,9 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
   for (int i = tid; i < nf; i += kThreads) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
   if (tid == 0) {
-    int rank;
-    const int n = nf;   // (the rank rule sees the whole spectrum)
-    const int64_t cap = p.rmax < (int64_t)n ? p.rmax : (int64_t)n;
-    if (sig_sorted[0] < T(1e-13)) {
-      rank = 0;  // zero guard, round.py:137-145
-    } else if (!p.use_delta) {
-      rank = (int)(cap < 1 ? 1 : cap);
-    } else {
-      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
-      double acc = 0.0;
-      int tail = 0;
-      for (int k = n - 1; k >= 0; --k) {
-        const double s2 = (double)(sig_sorted[k] * sig_sorted[k]);
-        acc += s2;
-        if ((T)acc <= d2) tail = n - k; else break;
-      }
-      int64_t rk = n - tail;
-      if (rk > cap) rk = cap;
-      if (rk < 1) rk = 1;
-      rank = (int)rk;
-    }
-    p.info[bt] = rank;
+    // (the rank rule sees the whole spectrum; zero guard: round.py:137-145)
+    const T d2 = p.use_delta ? (T)(p.delta2_dev ? *p.delta2_dev : p.delta2) : T(0);
+    p.info[bt] = rank_rule<T>(sig_sorted, nf, nf, p.rmax, p.use_delta, d2, p.noise_c);
     if (p.sweeps) p.sweeps[bt] = sweeps_used;
     if (p.rot_count && sweeps_used > 0) atomicAdd(p.rot_count, 1);
   }
@@ -1578,26 +1542,9 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) 
   }
   pad_tail(true, tid, 2 * kWave);
   if (tid == 0) {
-    int rank;
-    const int64_t cap = p.rmax < (int64_t)nf ? p.rmax : (int64_t)nf;   // (nf: the zero eigenvalues beyond a shrunk block count)
-    if (sig_sorted[0] < T(1e-13)) {
-      rank = 0;  // zero guard, round.py:137-145
-    } else if (!p.use_delta) {
-      rank = (int)(cap < 1 ? 1 : cap);
-    } else {
-      const T d2 = (T)(p.delta2_dev ? *p.delta2_dev : p.delta2);
-      double acc = 0.0;
-      int tail = 0;
-      for (int k = n - 1; k >= 0; --k) {
-        acc += (double)(sig_sorted[k] * sig_sorted[k]);
-        if ((T)acc <= d2) tail = n - k; else break;
-      }
-      int64_t rk = n - tail;
-      if (rk > cap) rk = cap;
-      if (rk < 1) rk = 1;
-      rank = (int)rk;
-    }
-    p.info[bt] = rank;
+    // (nf: the zero eigenvalues beyond a shrunk block count; zero guard: round.py:137-145)
+    const T d2 = p.use_delta ? (T)(p.delta2_dev ? *p.delta2_dev : p.delta2) : T(0);
+    p.info[bt] = rank_rule<T>(sig_sorted, n, nf, p.rmax, p.use_delta, d2, p.noise_c);
     if (p.sweeps) p.sweeps[bt] = total_iter;
     if constexpr (TOP) {
       // an item the top-r path declined: ttr_spectrum_flat's batch-mode test on the full decomposition's sigma, so that the flags
@@ -1640,6 +1587,7 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
 }
 
+int g_rank_noise_c = 0;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): see rank_rule (ttr_common.h)
 int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
@@ -1653,6 +1601,7 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
               (long long)nmax);
   EighArgs<T> p{};
   p.delta2_dev = delta2_dev;
+  p.noise_c = g_rank_noise_c;
   p.skip_items = skip_items; p.sigma_in = (const T*)sigma_in; p.stride_sigma_in = stride_sigma_in;
   TTR_REQUIRE(!skip_items || (sigma_in && !(abs_floor == TTR_SOLVER_TRIDIAG && n <= 64)), TTR_E_INVALID,
               "ttr_eigh_trunc: skip_items needs sigma_in and a Jacobi solver");

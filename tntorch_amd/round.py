@@ -5,7 +5,6 @@ behaviour): ``round_tt`` / ``round`` clone and call the in-place methods
 (round.py:7-49), ``truncated_svd`` is round.py:52-187.
 """
 
-import time
 from typing import Optional
 
 import torch

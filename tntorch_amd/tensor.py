@@ -18,7 +18,6 @@ other tensor-network formats of the reference are outside this package's scope a
 
 from __future__ import annotations
 
-import time
 from typing import Any, List, Optional, Sequence, Union
 
 import numpy as np
@@ -173,6 +172,11 @@ class Tensor(object):
         N = data.dim()
         rmax = list(ranks_tt) if hasattr(ranks_tt, "__len__") else [ranks_tt] * (N - 1)
         assert len(rmax) == N - 1
+        if data.shape[-1] > 64:
+            # (the in-place carry exists for the fused tall kernels, <= 64 columns: silently doubling the memory exactly where the
+            # caller said there is none would be the worst outcome)
+            raise NotImplementedError("from_dense_consuming: the last mode must be <= 64 (the in-place first carry needs the fused "
+                                      "column-sweep kernels); use tn.Tensor(data, ranks_tt=...)")
         cores = _hipops.dense_tt_svd(data[None], 1e-14, rmax, algorithm, False, consume_input=True)
         return cls([c[0] for c in cores])
 
@@ -322,6 +326,8 @@ class Tensor(object):
         """tensor.py:1689-1700 (in place, returns self)."""
         self.cores = [c.to(device) for c in self.cores]
         self.Us = [None if U is None else U.to(device) for U in self.Us]
+        if self._idxs is not None:   # tensor.py:1703-1704 (lazily built here: only when they exist)
+            self._idxs = [i.to(device) if torch.is_tensor(i) else i for i in self._idxs]
         return self
 
     def torch(self):
