@@ -138,25 +138,100 @@ def kernel_model():
     eig_flops = 2 * (N_CORES - 1) * 9.0 * Rr ** 3      # SURVEY 8d's 9 m^3 per eigenproblem
     gemm_flops = 2.0 * Rr * Rr * I                     # last-core push
     gemm_bytes = s * (Rr * Rr + 2 * Rr * I)
-    # flops the kernels actually EXECUTE (structure they exploit): the pushed R is upper triangular -- 10 of the 16
-    # (row tile, K group) products of R @ core; before its first panel the apply's C is [Top; 0] -- 7 of the 8 waves of
-    # a 512-row block skip that panel's W = V^T C
-    # Round 4: on THIS input (t = g + g: R factors and unfoldings of numerical rank 32 of 64) the factor kernel packs the 2048
-    # significant rows of a pushed unfolding into four leaf blocks (two mode indices per wave; R rows 32.. dropped: half the push,
-    # of which the triangular R skips 1/8) and factors only the first two panels of every block (the other two are below 8 eps of
-    # the block: H = I); the apply walks the two live panels of the four working leaves.  `frac` stays on the ALGORITHMIC flops.
-    rk = 32
-    leaf_exec = hh(leaf_rows, rk) + 4.0 * leaf_rows * rk * (n - rk)                 # 32 reflectors + their update of the other 32 columns
-    f_exec = mid * (4 * leaf_exec + leaf_exec + 2.0 * rk * Rr * I * n * (7.0 / 8.0)) + hh(I, n)
-    a_exec = mid * (4 + 1) * 4.0 * leaf_rows * rk * ro + 4.0 * I * n * ro
     return {
-        "qr_factor": {"flops": f_flops, "bytes": f_bytes, "executed_flops": f_exec},
-        "qr_apply": {"flops": a_flops, "bytes": a_bytes, "executed_flops": a_exec},
+        "qr_factor": {"flops": f_flops, "bytes": f_bytes},
+        "qr_apply": {"flops": a_flops, "bytes": a_bytes},
         "rowgram": {"flops": rg_flops, "bytes": rg_bytes},
         "rotgram": {"flops": ro_flops, "bytes": rg_bytes},
         "project": {"flops": pj_flops, "bytes": pj_bytes},
         "eigh": {"flops": eig_flops, "bytes": eig_bytes},
         "gemm": {"flops": gemm_flops, "bytes": gemm_bytes},
+    }
+
+
+CENSUS_KINDS = ("qr_factor", "qr_apply", "rowgram", "rotgram", "project", "gemm")   # kinds the library's census instruments
+
+
+def per_kind_roofline(prof, work, B, steps, pmc=None, model=None):
+    """Per kernel kind: device time (HIP events inside the library) against BOTH roofs, on the work the launches EXECUTED on this
+    input (`_hip.prof_collect_work`: read off the kernels' own per-item / per-block decisions) -- `frac` is the larger of the two
+    executed fractions and names the `bound`; the SURVEY-model (input-blind) figures stand beside it as `algorithmic` (their
+    fractions can exceed 1 where a launch skips work the model prices: that is what "algorithmic" means, not a utilisation)."""
+    model = model or kernel_model()
+    out = {}
+    for k, v in prof.items():
+        if v["launches"] == 0:
+            continue
+        sec = v["ms"] * 1e-3
+        entry = {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps}
+        if k in model:
+            fl, by = model[k]["flops"] * B * steps, model[k]["bytes"] * B * steps
+            entry["algorithmic"] = {"flops_per_step": fl / steps, "bytes_per_step": by / steps, "arithmetic_intensity": fl / by,
+                                    "TFLOPs": fl / sec / 1e12, "GBs": by / sec / 1e9,
+                                    "mfma_frac": fl / sec / 1e12 / MFMA_F32_PEAK_TF, "hbm_frac": by / sec / 1e9 / HBM_PEAK_GBS}
+        w = (work or {}).get(k)
+        if k in CENSUS_KINDS and w and (w["flops"] > 0 or w["bytes"] > 0):
+            tf, gbs = w["flops"] / sec / 1e12, w["bytes"] / sec / 1e9
+            ex = {"flops_per_step": w["flops"] / steps, "bytes_per_step": w["bytes"] / steps,
+                  "arithmetic_intensity": w["flops"] / w["bytes"] if w["bytes"] > 0 else None,
+                  "TFLOPs": tf, "GBs": gbs, "mfma_frac": tf / MFMA_F32_PEAK_TF, "hbm_frac": gbs / HBM_PEAK_GBS}
+            entry["executed"] = ex
+            entry["bound"] = "mfma" if ex["mfma_frac"] >= ex["hbm_frac"] else "hbm"
+            entry["frac"] = max(ex["mfma_frac"], ex["hbm_frac"])
+            if "algorithmic" in entry:
+                entry["executed_share_of_algorithmic_flops"] = w["flops"] / (entry["algorithmic"]["flops_per_step"] * steps)
+        elif k == "eigh":
+            entry["bound"], entry["frac"] = "valu", None   # serial VALU chains (no MFMA roof applies); time only
+        else:
+            entry["bound"], entry["frac"] = None, None
+        if pmc and k in pmc:
+            sc = B / pmc.get("_batch", B)
+            if pmc[k].get("hbm_bytes_per_step") is not None:
+                entry["traffic_bytes_per_step"] = pmc[k]["hbm_bytes_per_step"] * sc
+                entry["traffic_hbm_frac"] = entry["traffic_bytes_per_step"] / (entry["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if pmc[k].get("mfma_util") is not None:
+                entry["mfma_util"] = pmc[k]["mfma_util"]
+        out[k] = entry
+    return out
+
+
+def sweep_executed(per_kind, ms_per_step):
+    """The whole step on executed work: flops / bytes of the instrumented kinds over the step's wall time."""
+    fl = sum(v["executed"]["flops_per_step"] for v in per_kind.values() if "executed" in v)
+    by = sum(v["executed"]["bytes_per_step"] for v in per_kind.values() if "executed" in v)
+    sec = ms_per_step * 1e-3
+    return {"flops_per_step": fl, "bytes_per_step": by, "mfma_frac": fl / sec / 1e12 / MFMA_F32_PEAK_TF,
+            "hbm_frac": by / sec / 1e9 / HBM_PEAK_GBS, "kinds": [k for k, v in per_kind.items() if "executed" in v]}
+
+
+def headline_roofline(per_kind, dom, prof, steps, pmc_note=None):
+    """`roofline` of the JSON line: the kind with the largest device time, on EXECUTED work (`frac`, `bound`), with the algorithmic
+    (SURVEY-model) fraction on the same roof beside it, the counter traffic when profiles/pmc_latest.json describes this build."""
+    d = per_kind[dom]
+    launches = prof[dom]["launches"]
+    ex, al = d.get("executed"), d.get("algorithmic") or {}
+    bound = d.get("bound")
+    if ex is None:   # (a kind the census does not cover dominates: time only)
+        return {"kernel": dom, "bound": bound or "valu", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "avg_launch_ms": prof[dom]["ms"] / launches, "launches": launches, "input_aware": False}
+    if bound == "mfma":
+        ach, peak, unit, f_al = ex["TFLOPs"], MFMA_F32_PEAK_TF, "TFLOP/s", al.get("mfma_frac")
+    else:
+        ach, peak, unit, f_al = ex["GBs"], HBM_PEAK_GBS, "GB/s", al.get("hbm_frac")
+    traffic = d.get("traffic_bytes_per_step")
+    return {
+        "kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+        "frac_mfma_executed": ex["mfma_frac"], "frac_hbm_executed": ex["hbm_frac"], "frac_algorithmic": f_al,
+        "frac_mfma_algorithmic": al.get("mfma_frac"), "frac_hbm_algorithmic": al.get("hbm_frac"),
+        "executed_share_of_algorithmic_flops": d.get("executed_share_of_algorithmic_flops"),
+        "traffic": None if traffic is None else traffic * steps / launches,
+        "frac_hbm_traffic": d.get("traffic_hbm_frac"),
+        "traffic_note": pmc_note if traffic is None else "FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_latest.json, same kernel build)",
+        "mfma_util": d.get("mfma_util"),
+        "avg_launch_ms": prof[dom]["ms"] / launches, "launches": launches,
+        "executed_flops_per_launch": ex["flops_per_step"] * steps / launches,
+        "executed_bytes_per_launch": ex["bytes_per_step"] * steps / launches,
+        "ridge_flop_per_byte": RIDGE, "input_aware": True,
     }
 
 
@@ -316,8 +391,9 @@ def compact_line(res):
     out["value"], out["ms_per_step"] = _r(out["value"], 7), _r(out["ms_per_step"], 6)
     out["config"] = _pick(res.get("config", {}), ("workload", "tensors_per_gpu_per_step", "algorithm", "streams_per_gpu", "parallelism"))
     ro = res.get("roofline") or {}
-    out["roofline"] = _pick(ro, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "frac_algorithmic",
-                                 "frac_hbm_traffic", "mfma_util", "avg_launch_ms", "launches", "input_aware"))
+    out["roofline"] = _pick(ro, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_mfma_executed",
+                                 "frac_hbm_executed", "frac_algorithmic", "executed_share_of_algorithmic_flops", "frac_hbm_traffic",
+                                 "mfma_util", "avg_launch_ms", "launches", "input_aware"))
     out["roofline"].setdefault("traffic", None)
     cb = res.get("cpu_baseline")
     if cb:
@@ -326,7 +402,15 @@ def compact_line(res):
         out["speedup_vs_cpu_best"] = _r(res.get("speedup_vs_cpu_best"))
     if res.get("parity"):
         out["parity"] = _pick(res["parity"], ("ok", "rel_err_vs_oracle_svd", "ranks_identical", "bound", "error"))
+    if res.get("nccl_ranks") is not None:
+        out["nccl_ranks"] = res["nccl_ranks"]
     out["sweep"] = _pick(res, ("gflops", "whole_sweep_hbm_frac", "whole_sweep_frac_of_mfma_f32_peak", "tensors_per_s"))
+    if isinstance(res.get("whole_sweep_executed"), dict):
+        out["sweep"]["executed_hbm_frac"] = _r(res["whole_sweep_executed"].get("hbm_frac"))
+        out["sweep"]["executed_mfma_frac"] = _r(res["whole_sweep_executed"].get("mfma_frac"))
+    if isinstance(res.get("roofline_per_kernel"), dict):   # per kind: [bound, executed frac] (times: kernel_ms_per_step)
+        out["kinds"] = {k: [v.get("bound"), _r(v.get("frac"), 3)] for k, v in res["roofline_per_kernel"].items()
+                        if isinstance(v, dict) and v.get("frac") is not None}
     if res.get("kernel_ms_per_step"):
         out["kernel_ms_per_step"] = {k: _r(v, 3) for k, v in res["kernel_ms_per_step"].items()}
     if res.get("sweep_roofline"):
@@ -341,6 +425,10 @@ def compact_line(res):
         e = _pick(v, ("ms_per_step", "cores_per_s", "speedup_vs_cpu_best", "ms_per_call"))
         if "oracle_check" in v:
             e["ok"] = bool(v["oracle_check"].get("ok"))
+        if "whole_sweep_hbm_frac" in v:
+            e["hbm_frac"] = _r(v["whole_sweep_hbm_frac"], 3)
+        if isinstance(v.get("dominant"), dict):
+            e["dominant"] = [v["dominant"].get("kernel"), _r(v["dominant"].get("ms"), 3), _r(v["dominant"].get("frac"), 3)]
         if "error" in v:
             e["error"] = str(v["error"])[:80]
         ex[k] = e
@@ -368,7 +456,7 @@ def compact_line(res):
     out["full"] = FULL_SIDECAR
     line = json.dumps(out, allow_nan=False)
     # (belt and braces: a line above the limit loses its optional blocks, never its contract fields)
-    for drop in ("kernel_ms_per_step", "sweep_roofline", "extras", "configs", "gather", "sweep"):
+    for drop in ("kinds", "kernel_ms_per_step", "sweep_roofline", "extras", "configs", "gather", "sweep"):
         if len(line) < LINE_LIMIT:
             break
         out.pop(drop, None)
@@ -586,12 +674,13 @@ def main():
     t = tn.Tensor(inp, batch=True)
     t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
     torch.cuda.synchronize()
-    _hip.prof_enable(True)
+    _hip.prof_enable(2)   # per-kind device times + the executed-work census (include/ttround_hip.h: ttr_prof_collect_work)
     for _ in range(args.steps):
         t = tn.Tensor(inp, batch=True)
         t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
     torch.cuda.synchronize()
     prof = _hip.prof_collect()
+    work = _hip.prof_collect_work()
     _hip.prof_enable(False)
     _hipops.STREAM_CHUNKS_ENABLED = not args.single_stream
 
@@ -600,47 +689,9 @@ def main():
         tensors = B * world * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         cores_per_s = tensors * N_CORES / elapsed
-        model = kernel_model()
         pmc, pmc_note = load_pmc()
-        per_kind = {}
-        for k, v in prof.items():
-            if v["launches"] == 0 or k not in model:
-                continue
-            sec = v["ms"] * 1e-3
-            fl = model[k]["flops"] * B * args.steps
-            by = model[k]["bytes"] * B * args.steps
-            ai = fl / by
-            bound = "mfma" if ai > RIDGE else "hbm"
-            if k == "eigh":
-                bound = "valu"  # no MFMA in the eigensolvers: serial VALU chains (latency-bound); frac is vs the fp32 vector peak
-            tf, gbs = fl / sec / 1e12, by / sec / 1e9
-            entry = {
-                "ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
-                "flops_per_step": model[k]["flops"] * B, "bytes_per_step": model[k]["bytes"] * B,
-                "arithmetic_intensity": ai, "bound": bound,
-                "achieved_TFLOPs": tf, "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TF,
-                "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-                "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_F32_PEAK_TF,
-            }
-            if "executed_flops" in model[k]:  # (algorithmic flops count the dense products the kernels partly skip)
-                ex = model[k]["executed_flops"] * B * args.steps / sec / 1e12
-                entry["executed_TFLOPs"] = ex
-                entry["executed_frac_of_mfma_f32_peak"] = ex / MFMA_F32_PEAK_TF
-            if pmc and k in pmc:
-                sc = B / pmc.get("_batch", B)
-                if pmc[k].get("hbm_bytes_per_step") is not None:
-                    entry["traffic_bytes_per_step"] = pmc[k]["hbm_bytes_per_step"] * sc
-                if pmc[k].get("mfma_util") is not None:
-                    entry["mfma_util"] = pmc[k]["mfma_util"]
-            per_kind[k] = entry
+        per_kind = per_kind_roofline(prof, work, B, args.steps, pmc)
         dom = max(per_kind, key=lambda k: per_kind[k]["ms_per_step"])
-        d = per_kind[dom]
-        launches = prof[dom]["launches"]
-        if d["bound"] == "mfma":
-            ach, peak, unit = d["achieved_TFLOPs"], MFMA_F32_PEAK_TF, "TFLOP/s"
-        else:
-            ach, peak, unit = d["achieved_GBs"], HBM_PEAK_GBS, "GB/s"
-        traffic = d.get("traffic_bytes_per_step")
         res = {
             "metric": "TT rounding 64^8 rank-64 -> rank-32 (round_tt rmax=32), cores/s",
             "value": cores_per_s,
@@ -682,24 +733,8 @@ def main():
             "gflops": FLOP_PER_TENSOR * tensors / elapsed / 1e9,
             "whole_sweep_frac_of_mfma_f32_peak": FLOP_PER_TENSOR * tensors / elapsed / 1e12 / MFMA_F32_PEAK_TF,
             "whole_sweep_hbm_frac": BYTES_PER_TENSOR * tensors / elapsed / 1e9 / HBM_PEAK_GBS,
-            "roofline": {
-                "kernel": dom,
-                "bound": d["bound"],
-                "achieved": ach,
-                "peak": peak,
-                "unit": unit,
-                "frac": ach / peak,
-                "traffic": None if traffic is None else traffic * args.steps / launches,
-                "traffic_note": pmc_note if traffic is None else "FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_latest.json, same kernel build)",
-                "mfma_util": d.get("mfma_util"),
-                "avg_launch_ms": prof[dom]["ms"] / launches,
-                "executed_frac": d.get("executed_frac_of_mfma_f32_peak"),
-                "algorithmic_flops_per_launch": d["flops_per_step"] * args.steps / launches,
-                "algorithmic_bytes_per_launch": d["bytes_per_step"] * args.steps / launches,
-                "arithmetic_intensity": d["arithmetic_intensity"],
-                "ridge_flop_per_byte": RIDGE,
-                "launches": launches,
-            },
+            "whole_sweep_executed": sweep_executed(per_kind, ms_per_step),
+            "roofline": headline_roofline(per_kind, dom, prof, args.steps, pmc_note),
             "roofline_per_kernel": per_kind,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
         }
@@ -755,13 +790,20 @@ def main():
                     _hipops.STREAM_CHUNKS_ENABLED = False
                     dstep()   # (untimed: first use of this input's kernels on the single stream, see the headline's pass)
                     torch.cuda.synchronize()
-                    _hip.prof_enable(True)
+                    _hip.prof_enable(2)
                     dstep()
                     torch.cuda.synchronize()
                     pk = _hip.prof_collect()
+                    wk = _hip.prof_collect_work()
                     _hip.prof_enable(False)
                     _hipops.STREAM_CHUNKS_ENABLED = not args.single_stream
                     ent["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in pk.items() if v["launches"] > 0}
+                    pkr = per_kind_roofline(pk, wk, B, 1)
+                    ent["roofline_per_kernel"] = pkr
+                    ent["whole_sweep_executed"] = sweep_executed(pkr, ent["ms_per_step"])
+                    ent["whole_sweep_hbm_frac"] = BYTES_PER_TENSOR * B / (ent["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    dk = max(pkr, key=lambda k: pkr[k]["ms_per_step"])
+                    ent["dominant"] = {"kernel": dk, "ms": pkr[dk]["ms_per_step"], "bound": pkr[dk].get("bound"), "frac": pkr[dk].get("frac")}
                     ent["oracle_check"] = decaying_parity(dinp, dout, 0)
                     extras[f"decaying_spectrum_{decay}"] = ent
                     del dinp, dout, dstep   # (the closure's default argument holds the input too)

@@ -52,9 +52,10 @@ extern "C" {
                                 driver for n above the single-workgroup limit. */
 
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
-   ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top; round 4: 8 = rows32 / skip_zero_rows, 9 = ttr_carry_rows32).  ttr_version() returns the value the library was built with; the Python
+   ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top; round 4: 8 = rows32 / skip_zero_rows, 9 = ttr_carry_rows32;
+   round 5: 10 = ttr_round_tt, the whole sweep behind one call, + TTR_KNOB_RANK_NOISE_FLOOR).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 9
+#define TTR_ABI_VERSION 10
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -411,7 +412,10 @@ int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
  * (`skip_items`: V = I, sigma = sigma_in, rank rule as usual on sigma_in).
  */
 int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
-                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, void* stream);
+                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, const int32_t* rows32, void* stream);
+/* `rows32` (optional, ABI 10): the flags ttr_rowgram took for this bond -- sigma[32..] of a flagged item are structural zeros (exact
+ * in either pass), so in eps mode the rule's cut of them is certain and only the 32 computed values are tested for robustness:
+ * a rank-deficient train (t = g + g) rounded through the reference's NON-batch call skips its second Gram pass like a batch. */
 int ttr_project(int dtype, int64_t R, int64_t n, int64_t ro, int64_t batch,
                 const void* M, int64_t ldm, int64_t strideM,
                 const void* V1, int64_t ldv1, int64_t strideV1,
@@ -476,6 +480,41 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
 /* `rank_dev` (optional, device int32 [batch]): only the first min(r, rank_dev[b]) vectors of item b are looked at -- a sweep
  * that computes its factors at the rank cap and cuts them to the selected rank later does not complete vectors it drops. */
 
+/*
+ * The WHOLE rounding of a batch of tensor trains in ONE call (ABI 10): the left-to-right orthogonalisation loop of
+ * tensor.py:1905-1906 (tensor.py:1816-1832 per core) followed by the right-to-left truncation loop of tensor.py:2053-2083
+ * (round.py:52-187 per bond) -- the two Python loops of `Tensor.round_tt` (tensor.py:2008-2083).  The entry enqueues, on
+ * `stream`, the same kernels in the same order as the per-kernel entries above would be called by a host loop (results are
+ * bit-identical to that loop); it allocates nothing, synchronises nothing and reads nothing back.
+ *
+ *   shapes     host int64 [3 N]: (r0, I, r1) of every input core; cores_in[mu] = contiguous [batch][r0][I][r1] on the device
+ *   rcap       host int64 [N - 1] or NULL: rank cap of bond mu = 1 .. N-1 at index mu - 1 (>= 2^31 - 1: none, round.py:83-84)
+ *   algorithm  TTR_ALG_SVD (two Gram passes: the accuracy class of gesdd, round.py:96) / TTR_ALG_EIG (round.py:101-135)
+ *   eps_mode   0 = batch semantics (round.py:149-150: every bond is cut at its cap, eps is ignored; any batch);
+ *              1 = the reference's NON-batch rule for ONE train (batch == 1): delta = eps / max(1, sqrt(N - 1)) ||last core||
+ *              (tensor.py:2039-2051) is formed ON THE DEVICE, every bond is computed at its cap, the rank the rule of
+ *              round.py:147-158 selects is written to ranks_dev[mu - 1] and the cores are ZERO beyond the selected ranks: the
+ *              caller reads ranks_dev once, after the call, and slices (ranks_dev[i] == 0: the zero guard of round.py:137-145)
+ *   flat_thr   items whose kept singular values lie within a factor 1 / flat_thr skip the second Gram pass (ttr_spectrum_flat;
+ *              0 = never); use_eigh_top != 0: batch-mode first passes through ttr_eigh_top where ttr_eigh_top_ok
+ *   cores_out  cores_out[mu] = contiguous [batch][q_mu][I][q_{mu+1}], q_0 = r0 of core 0, q_N = r1 of the last core,
+ *              q_mu = max(1, min(rcap[mu - 1], rows of bond mu)) -- the ranks batch mode produces (fixed by the shapes)
+ *   zero_flag_dev  optional device int32 [1] (eps_mode 0): receives the largest rank-rule result of the FIRST truncation over the
+ *              batch; 0 = every item hit the zero guard (round.py:137-141) and the caller returns the rank-1 zero train
+ *   workspace  ttr_round_tt_workspace_bytes(...) bytes, caller-owned; the call may be repeated with the same workspace once the
+ *              previous one has completed on the stream
+ * Envelope: every TT rank <= ttr_qr_max_cols, every core inside the fused push (k, Rin <= 64, k I >= n), every bond a
+ * <= 64-row matrix with at least as many columns.  ttr_round_tt_workspace_bytes returns TTR_E_UNSUPPORTED (< 0) outside it:
+ * the caller then runs its own loop over the per-kernel entries.
+ */
+#define TTR_ALG_SVD 0
+#define TTR_ALG_EIG 1
+int64_t ttr_round_tt_workspace_bytes(int dtype, int64_t N, const int64_t* shapes, const int64_t* rcap, int64_t batch,
+                                     int eps_mode);
+int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, const void* const* cores_in, const int64_t* rcap,
+                 int algorithm, int eps_mode, double eps, double flat_thr, int use_eigh_top, void* const* cores_out,
+                 int32_t* ranks_dev, int32_t* zero_flag_dev, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Per-kernel device timing (HIP events on `stream`), used by bench.py for the roofline line. */
 #define TTR_PROF_GEMM 0
 #define TTR_PROF_QR_FACTOR 1
@@ -537,9 +576,14 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      itself (A/B). */
 #define TTR_KNOB_EIGH_SMALL 8
 int ttr_debug_set_knob(int knob, int value);
-int ttr_prof_enable(int on);
+int ttr_prof_enable(int on);   /* 0 = off, 1 = per-kind device times, 2 = times + executed-work census (ttr_prof_collect_work) */
 /* Synchronises the recorded events; fills total milliseconds and launch counts per kind; resets. */
 int ttr_prof_collect(double* ms, int64_t* launches);
+/* Census mode (ttr_prof_enable(2); ABI 10): flops / bytes the instrumented launches EXECUTED since the last collect, per kind --
+ * read off the same device-side decisions the kernels took (zero taus of rank-skipped / absorbed QR panels, packing flags,
+ * `rows32` and pass-through flags), by tiny kernels enqueued outside the timed scopes.  Instrumented: qr_factor, qr_apply (flops),
+ * rowgram, rotgram, project (flops and bytes), gemm (flops and bytes of the dense product).  Synchronises the device; resets. */
+int ttr_prof_collect_work(double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

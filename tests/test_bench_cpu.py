@@ -91,3 +91,26 @@ def test_stdout_line_is_compact_and_carries_the_contract_fields(tmp_path, capsys
     assert len(out_lines) == 1 and json.loads(out_lines[0])["roofline"]["frac"] > 0
     full = json.load(open(tmp_path / "profiles" / "bench_full_latest.json"))
     assert "roofline_per_kernel" in full and "configs" in full and "bench.py full result" in cap.err
+
+
+def test_per_kind_roofline_is_on_executed_work():
+    """`frac` of a kind = the larger of its two EXECUTED roofline fractions (census / measured time); the input-blind model stands
+    beside it as `algorithmic` and may exceed 1 where launches skip work; kinds without a census carry no fraction."""
+    B, steps = 2048, 5
+    model = bench.kernel_model()
+    prof = {k: {"ms": 10.0, "launches": 10} for k in ("qr_factor", "rotgram", "eigh", "misc")}
+    prof["gemm"] = {"ms": 0.0, "launches": 0}
+    work = {"qr_factor": {"flops": 0.3 * model["qr_factor"]["flops"] * B * steps, "bytes": 0.8 * model["qr_factor"]["bytes"] * B * steps},
+            "rotgram": {"flops": 1e9, "bytes": 1e9}, "eigh": {"flops": 0.0, "bytes": 0.0}, "misc": {"flops": 0.0, "bytes": 0.0}}
+    pk = bench.per_kind_roofline(prof, work, B, steps)
+    assert set(pk) == {"qr_factor", "rotgram", "eigh", "misc"}
+    q = pk["qr_factor"]
+    assert abs(q["executed_share_of_algorithmic_flops"] - 0.3) < 1e-12 and q["frac"] == max(q["executed"]["mfma_frac"], q["executed"]["hbm_frac"])
+    assert q["bound"] == ("mfma" if q["executed"]["mfma_frac"] >= q["executed"]["hbm_frac"] else "hbm")
+    assert pk["rotgram"]["algorithmic"]["mfma_frac"] > pk["rotgram"]["executed"]["mfma_frac"]     # (the model prices skipped work)
+    assert pk["eigh"]["frac"] is None and pk["eigh"]["bound"] == "valu" and pk["misc"]["frac"] is None
+    hl = bench.headline_roofline(pk, "qr_factor", prof, steps)
+    assert hl["input_aware"] and hl["frac"] == q["frac"] and hl["frac_algorithmic"] is not None and hl["traffic"] is None
+    sw = bench.sweep_executed(pk, 10.0)
+    assert sw["kinds"] == ["qr_factor", "rotgram"] and sw["flops_per_step"] > 0
+    assert bench.headline_roofline(pk, "eigh", prof, steps)["frac"] is None

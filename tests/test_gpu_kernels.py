@@ -1113,3 +1113,51 @@ def test_eigh_tridiag_zero_tail_is_solved_as_the_leading_block(dt, mode):
         assert ((sc[b] ** 2 - wref).abs().max() / wref[0]) < tol(dt, 2e-6, 1e-13)
         assert (G[b].double() @ Vc[b] - Vc[b] * (sc[b] ** 2)[None, :]).abs().max() / wref[0] < tol(dt, 2e-5, 1e-12)
         assert (Vc[b].T @ Vc[b] - torch.eye(n, dtype=torch.float64)).abs().max() < tol(dt, 2e-5, 1e-13)
+
+
+def test_executed_work_census_follows_the_kernels_decisions():
+    """ttr_prof_enable(2) / ttr_prof_collect_work: the flops / bytes the launches EXECUTED, read off the kernels' own per-item
+    decisions.  On the metric's shape a full-rank train executes (nearly) the algorithmic work; the rank-inflated t = g + g
+    executes well under half of the QR flops (packed rows, rank-skipped panels) and loads half the rows in the Gram /
+    projection kernels; the census itself does not change any result."""
+    import bench
+    from tntorch_amd import _hipops
+
+    h = _hip()
+    dev = torch.device("cuda", 0)
+    B = 4
+    gg = bench.make_input(B, dev, seed=5)
+    # bond sigma ~ 2^(-j/4): numerical rank 64 (sigma_63 / sigma_0 = 2e-5: no panel is skipped, nothing packs) and a kept
+    # spectrum that is NOT flat (sigma_31 / sigma_0 = 5e-3: the second Gram pass runs)
+    full = bench.make_decaying_input(B, dev, seed=5, decay=0.25)
+    model = bench.kernel_model()
+    res = {}
+    for name, inp in (("gg", gg), ("full", full)):
+        t0 = tn.Tensor(inp, batch=True); t0.round_tt(rmax=32)
+        h.prof_enable(2)
+        t = tn.Tensor(inp, batch=True); t.round_tt(rmax=32)
+        torch.cuda.synchronize()
+        prof, work = h.prof_collect(), h.prof_collect_work()
+        h.prof_enable(False)
+        assert all(torch.equal(a, b) for a, b in zip(t.cores, t0.cores))
+        res[name] = (prof, work)
+        pk = bench.per_kind_roofline(prof, work, B, 1)
+        for k in bench.CENSUS_KINDS:
+            if k in pk and pk[k].get("frac") is not None:
+                assert 0.0 < pk[k]["frac"] <= 1.0, (name, k, pk[k])          # executed work over measured time: below either roof
+        assert bench.headline_roofline(pk, max(pk, key=lambda k: pk[k]["ms_per_step"]), prof, 1)["input_aware"] in (True, False)
+    wf, wg = res["full"][1], res["gg"][1]
+    for k in ("qr_factor", "qr_apply"):
+        share_full = wf[k]["flops"] / (model[k]["flops"] * B)
+        share_gg = wg[k]["flops"] / (model[k]["flops"] * B)
+        assert 0.6 <= share_full <= 1.05, (k, share_full)      # (triangular R: 10 of 16 tiles of the push)
+        assert 0.15 <= share_gg <= 0.6 * share_full, (k, share_gg, share_full)
+    for k in ("rowgram", "project"):
+        assert wf[k]["bytes"] > 0 and 0.45 <= wg[k]["bytes"] / wf[k]["bytes"] <= 0.8, (k, wg[k], wf[k])
+    assert wg["rotgram"]["flops"] < 0.5 * wf["rotgram"]["flops"]       # flat kept spectra: the second Gram pass is passed through
+    h.prof_enable(True)                                               # times only: the counters stay untouched
+    t = tn.Tensor(gg, batch=True); t.round_tt(rmax=32)
+    torch.cuda.synchronize()
+    h.prof_collect()
+    h.prof_enable(False)
+    assert all(v["flops"] == 0 and v["bytes"] == 0 for v in h.prof_collect_work().values())

@@ -1243,6 +1243,7 @@ def test_eps_mode_without_rank_readbacks(dt, eps, alg, monkeypatch):
     (data-dependent ranks that differ from bond to bond), with and without an rmax cap, and on an all-zero train."""
     inp = _decaying_tt([12, 10, 9, 11, 8, 16], 14, 0.6, dt, seed=3)   # (every bond: rows <= columns, the fused kernels' side)
     from tntorch_amd import _hipops
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (the host loop's own two eps-mode sweeps; ttr_round_tt: next test)
     calls = []
     orig = _hipops._eps_deferred_ok
     monkeypatch.setattr(_hipops, "_eps_deferred_ok", lambda *a: calls.append(orig(*a)) or calls[-1])
@@ -1273,6 +1274,109 @@ def test_eps_mode_without_rank_readbacks(dt, eps, alg, monkeypatch):
     assert rel_diff(dense(out["1"][0]), dense(ref)) <= max(3 * eps, tol)
 
 
+def _sweep_both_ways(monkeypatch, make, call):
+    """Run ``call(tensor)`` on ``make()`` through ttr_round_tt and through the host loop over the per-kernel entries; returns the
+    two lists of cores and how many sweeps went through the one-call entry."""
+    from tntorch_amd import _hipops
+    out = {}
+    n0 = _hipops.SWEEP_C_CALLS
+    for on in (True, False):
+        monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", on)
+        t = make()
+        call(t)
+        out[on] = [c.clone() for c in t.cores]
+        if on:
+            used = _hipops.SWEEP_C_CALLS - n0
+    return out[True], out[False], used
+
+
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+@pytest.mark.parametrize("case", ["metric3", "metric130", "decay", "small_f64", "two_cores", "lead_rank", "c2_f64"])
+def test_whole_sweep_entry_is_bit_identical_to_the_host_loop_batch(case, alg, monkeypatch):
+    """ttr_round_tt (SURVEY 8b's `tt_round_sweep_batched_*`: tensor.py:1905-1906 + 2053-2083 behind ONE library call) enqueues
+    the same kernels in the same order as the host loop of `_round_tt_sweep`: the rounded cores are BIT-identical -- on the
+    metric's shape (one sub-batch, and two sub-batches on two streams writing the result arena), a decaying spectrum (no
+    shortcut fires), fp64, a two-core train, a train with a leading rank > 1, and the shape of BASELINE config C2."""
+    if case == "metric3":
+        inp, rmax = _metric_input(3, seed=11), 32
+    elif case == "metric130":
+        inp, rmax = _metric_input(130, seed=12), 32
+    elif case == "decay":
+        inp, rmax = [torch.stack([a, b]) for a, b in zip(_decaying_tt([64] * 5, 64, 0.5, torch.float32, seed=5),
+                                                           _decaying_tt([64] * 5, 64, 1.0, torch.float32, seed=6))], 32
+    elif case == "small_f64":
+        inp, rmax = [torch.stack([a, b]) for a, b in zip(_decaying_tt([12, 10, 9, 11, 8, 16], 14, 0.6, torch.float64, seed=3),
+                                                           _decaying_tt([12, 10, 9, 11, 8, 16], 14, 0.3, torch.float64, seed=4))], 5
+    elif case == "two_cores":
+        torch.manual_seed(3)
+        inp, rmax = [torch.randn(4, 1, 40, 24), torch.randn(4, 24, 48, 1)], 7
+    elif case == "lead_rank":
+        torch.manual_seed(4)
+        inp, rmax = [torch.randn(3, 3, 20, 16), torch.randn(3, 16, 12, 16), torch.randn(3, 16, 9, 2)], 6
+    else:
+        torch.manual_seed(5)
+        g = oracle.tt_randn([128] * 10, 32, dtype=torch.float64, batch_size=2)
+        inp, rmax = oracle.tt_add(g, g, batch=True), 32
+    a, b, used = _sweep_both_ways(monkeypatch, lambda: gpu_tensor(inp, batch=True), lambda t: t.round_tt(rmax=rmax, algorithm=alg))
+    assert used == (2 if case == "metric130" else 1)
+    assert [tuple(x.shape) for x in a] == [tuple(x.shape) for x in b]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(torch.isfinite(x).all() for x in a)
+
+
+@pytest.mark.parametrize("dt,eps", [(torch.float32, 1e-3), (torch.float64, 1e-6), (torch.float64, 1e-14)])
+@pytest.mark.parametrize("alg", ["svd", "eig"])
+def test_whole_sweep_entry_eps_mode_vs_host_loop_and_oracle(dt, eps, alg, monkeypatch):
+    """The reference's own call signature -- NON-batch `t.round_tt(eps=..., rmax=...)` (tensor.py:2008-2014) -- through
+    ttr_round_tt's eps mode (delta formed on the device, ranks read back ONCE): bit-identical to the host loop's deferred sweep,
+    same ranks as its bond-by-bond sweep, the oracle's ranks (+- 1 at the cut) and train; rank-1 zeros for an all-zero train."""
+    from tntorch_amd import _hipops
+    inp = _decaying_tt([12, 10, 9, 11, 8, 16], 14, 0.6, dt, seed=3)
+    monkeypatch.setenv("TTR_EPS_DEFERRED", "1")
+    for rmax in (None, 6):
+        a, b, used = _sweep_both_ways(monkeypatch, lambda: gpu_tensor(inp), lambda t: t.round_tt(eps=eps, rmax=rmax, algorithm=alg))
+        assert used == 1 and ranks(to_list(a)) == ranks(to_list(b)) and all(torch.equal(x, y) for x, y in zip(a, b))
+        assert all(x.is_contiguous() for x in a)
+        if rmax is None:
+            ref = oracle.round_tt([c.clone() for c in inp], eps=eps, algorithm=alg)
+            if alg == "svd" or eps > 1e-10:
+                assert all(abs(x - y) <= 1 for x, y in zip(ranks(to_list(a)), ranks(ref)))
+            assert rel_diff(dense(to_list(a)), dense(ref)) <= max(3 * eps, 2e-5 if dt == torch.float32 else 1e-10)
+            assert len(set(ranks(to_list(a))[1:-1])) > 1     # data-dependent ranks
+        else:
+            assert max(ranks(to_list(a))) <= 6
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", True)
+    n0 = _hipops.SWEEP_C_CALLS
+    z = gpu_tensor([torch.zeros_like(c) for c in inp])
+    z.round_tt(eps=eps, algorithm=alg)
+    assert _hipops.SWEEP_C_CALLS == n0 + 1 and ranks(to_list(z.cores)) == [1] * 7 and all((c == 0).all() for c in z.cores)
+    # the default policy (`auto`): a rank cap -> one call; no cap -> the bond-by-bond loop (computing every bond at full rank
+    # costs more than the readbacks save, `_eps_deferred_ok`)
+    monkeypatch.setenv("TTR_EPS_DEFERRED", "auto")
+    n0 = _hipops.SWEEP_C_CALLS
+    t = gpu_tensor(inp); t.round_tt(eps=eps, rmax=6, algorithm=alg)
+    u = gpu_tensor(inp); u.round_tt(eps=eps, algorithm=alg)
+    assert _hipops.SWEEP_C_CALLS == n0 + 1
+
+
+def test_whole_sweep_entry_declines_what_it_does_not_cover(monkeypatch):
+    """Outside ttr_round_tt's envelope (TT ranks above a TSQR panel, bonds with more rows than columns) the planner returns
+    TTR_E_UNSUPPORTED and the host loop runs -- same results as ever; zero batches keep the batch-mode zero guard."""
+    from tntorch_amd import _hip, _hipops
+    assert _hip.round_tt_plan(torch.float32, [(1, 16, 16), (16, 16, 256), (256, 16, 16), (16, 16, 1)], [4] * 3, 1, False) == -2
+    assert _hip.round_tt_plan(torch.float32, [(1, 64, 64)] + [(64, 64, 64)] * 6 + [(64, 64, 1)], [32] * 7, 2048, False) > 0
+    assert _hip.round_tt_plan(torch.float32, [(1, 64, 64), (64, 64, 1)], [32], 2, True) == -2       # eps mode rounds ONE train
+    torch.manual_seed(0)
+    X = torch.randn(16, 16, 16, 16)
+    n0 = _hipops.SWEEP_C_CALLS
+    t = tn.Tensor(X.cuda(), ranks_tt=4)
+    assert ranks(to_list(t.cores)) == [1, 4, 4, 4, 1]
+    z = gpu_tensor([torch.zeros(5, 1, 8, 6), torch.zeros(5, 6, 8, 6), torch.zeros(5, 6, 8, 1)], batch=True)
+    z.round_tt(rmax=3)
+    assert _hipops.SWEEP_C_CALLS == n0 + 1                       # (only the zero batch: the dense ctor has its own sweep)
+    assert [tuple(c.shape) for c in z.cores] == [(5, 1, 8, 1), (5, 1, 8, 1), (5, 1, 8, 1)] and all((c == 0).all() for c in z.cores)
+
+
 def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
     """Batch-mode 'svd' truncation: an item whose KEPT singular values lie within a factor 8 (here: 4) of each other is decided by the
     first Gram pass alone (ttr_spectrum_flat; the second pass exists for kept singular values far below sigma_1).  On the
@@ -1285,6 +1389,7 @@ def test_flat_spectrum_items_skip_the_second_gram_pass(monkeypatch):
     sg = torch.tensor([[4.0, 3.0, 2.0, 1.0, 0.1], [4.0, 3.0, 2.0, 0.9, 0.1], [0.0, 0.0, 0.0, 0.0, 0.0]], dtype=torch.float32).cuda()
     assert _hip.spectrum_flat(sg, 4, 0.25).tolist() == [1, 0, 0] and _hip.spectrum_flat(sg, 5, 0.02).tolist() == [1, 1, 0]
     inp = _metric_input(4, seed=11)
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (spies on the host loop's per-kernel calls)
     calls = []
     orig = _hip.eigh_top      # (batch mode: the first-pass launch's flags ARE the pass-through flags, ttr_eigh_top -- no ttr_spectrum_flat launch)
 
@@ -1328,6 +1433,7 @@ def test_top_r_first_pass_on_the_metric_shape(monkeypatch):
     against the oracle's LAPACK 'svd'."""
     from tntorch_amd import _hip, _hipops
     inp = _metric_input(4, seed=23)
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (spies on the host loop's per-kernel calls)
     calls = []
     orig = _hip.eigh_top
     monkeypatch.setattr(_hip, "eigh_top", lambda *a: calls.append(orig(*a)) or calls[-1])
@@ -1366,6 +1472,17 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
     assert _hip.spectrum_flat(sg, 8, 0.125, True, 0.0).tolist() == [0, 0, 0, 1]     # delta = 0: the batch criterion at keep = 8
     # fp32: E = 64 * 8 * 1.2e-7 = 6e-5 > delta^2 -- what is cut cannot be certified, only the nothing-to-cut item qualifies
     assert _hip.spectrum_flat(sg.float(), 8, 0.125, True, d2).tolist() == [0, 0, 0, 1]
+    # `rows32` items: sigma[32..] are structural zeros (exact in either pass) -- cutting them is certain, only the 32 computed values
+    # are tested.  fp32, eps = 1e-14 (what `t.round_tt(rmax=32)` passes on): a flat 32-value spectrum + 32 structural zeros qualifies
+    # with the flag, not without (without it the zeros are "values within E of delta^2")
+    s64 = torch.zeros(2, 64, dtype=torch.float32)
+    s64[:, :32] = torch.linspace(1.0, 0.6, 32)
+    s64[1, 31] = 1e-3                                                        # kept value far below sigma_1: needs the second pass
+    fl = torch.tensor([1, 1], dtype=torch.int32).cuda()
+    assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]
+    assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29).tolist() == [0, 0]
+    assert _hip.spectrum_flat(s64.cuda(), 48, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]     # the cap above the live block
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (below: spies on the host loop's per-kernel calls)
 
     torch.manual_seed(3)
     g = oracle.tt_randn([12] * 6, 6, dtype=torch.float64)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 9  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 10  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -103,7 +103,7 @@ _SIGNATURES = {
          c_int, c_int, c_double, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     ),
     "ttr_carry_rows32": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
-    "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "ttr_spectrum_flat": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_eigh_top_ok": (c_int, [c_int64, c_int64]),
     "ttr_eigh_top": (
         c_int,
@@ -165,10 +165,17 @@ _SIGNATURES = {
     "ttr_krp_contract": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_hadamard": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ttr_core_kron": (c_int, [c_int] + [c_int64] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ttr_round_tt_workspace_bytes": (c_int64, [c_int, c_int64, c_void_p, c_void_p, c_int64, c_int]),
+    "ttr_round_tt": (
+        c_int,
+        [c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
     "ttr_debug_set_qr_stamps": (c_int, [c_void_p]),
     "ttr_debug_set_knob": (c_int, [c_int, c_int]),
     "ttr_prof_enable": (c_int, [c_int]),
     "ttr_prof_collect": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
+    "ttr_prof_collect_work": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -755,7 +762,7 @@ def sweep_fused_ok(M: torch.Tensor) -> bool:
 
 @_on_device
 def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float, use_delta: bool = False, delta2: float = 0.0,
-                  delta2_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  delta2_dev: Optional[torch.Tensor] = None, rows32: Optional[torch.Tensor] = None) -> torch.Tensor:
     """int32 [batch]: 1 where sigma[b, r - 1] >= thr * sigma[b, 0] > 0 (sigma [batch, n] sorted decreasing), r = keep, or with
     ``use_delta`` the rank the tail-energy rule selects from these sigma provided that decision is robust (ttr_spectrum_flat)."""
     sigma = sigma.contiguous()
@@ -765,7 +772,8 @@ def spectrum_flat(sigma: torch.Tensor, keep: int, thr: float, use_delta: bool = 
         _check(lib().ttr_spectrum_flat(dtype_code(sigma.dtype), n, batch, sigma.data_ptr(), n, int(keep), float(thr),
                                        int(bool(use_delta)), float(delta2),
                                        delta2_dev.data_ptr() if delta2_dev is not None else None,
-                                       flat.data_ptr(), _stream()), "ttr_spectrum_flat")
+                                       flat.data_ptr(), rows32.data_ptr() if rows32 is not None else None, _stream()),
+               "ttr_spectrum_flat")
     return flat
 
 
@@ -1030,13 +1038,54 @@ KNOB_EIGH_SMALL = 8
 KNOB_RANK_NOISE_FLOOR = 9
 
 
+ALG_SVD, ALG_EIG = 0, 1
+RANK_NONE = 2**31 - 1   # rank cap meaning "none" (round.py:83-84)
+
+
+def round_tt_plan(dt: torch.dtype, shapes, rcap, batch: int, eps_mode: bool) -> int:
+    """Workspace bytes of ``round_tt_sweep`` for cores of ``shapes`` [(r0, I, r1), ...], or a negative status when the train
+    lies outside the envelope of ttr_round_tt (the caller then runs its own loop over the per-kernel entries)."""
+    N = len(shapes)
+    sh = (c_int64 * (3 * N))(*[int(v) for s3 in shapes for v in s3])
+    rc = (c_int64 * max(N - 1, 1))(*[int(r) for r in rcap])
+    return int(lib().ttr_round_tt_workspace_bytes(dtype_code(dt), N, sh, rc, int(batch), int(bool(eps_mode))))
+
+
+@_on_device
+def round_tt_sweep(cores, rcap, algorithm: str, eps_mode: bool, eps: float, flat_thr: float, use_eigh_top: bool, outs,
+                   ranks_dev: Optional[torch.Tensor], zero_flag: Optional[torch.Tensor], ws: torch.Tensor) -> None:
+    """ttr_round_tt: both sweeps of tensor.py:2008-2083 on contiguous [B, r0, I, r1] ``cores`` in ONE library call; the
+    rounded cores are written to ``outs`` (contiguous, at the rank caps).  See include/ttround_hip.h."""
+    N = len(cores)
+    B = cores[0].shape[0]
+    sh = (c_int64 * (3 * N))(*[int(v) for c in cores for v in c.shape[1:]])
+    rc = (c_int64 * max(N - 1, 1))(*[int(r) for r in rcap])
+    cin = (c_void_p * N)(*[c.data_ptr() for c in cores])
+    cout = (c_void_p * N)(*[o.data_ptr() for o in outs])
+    code = lib().ttr_round_tt(dtype_code(cores[0].dtype), N, sh, B, cin, rc, ALG_SVD if algorithm == "svd" else ALG_EIG,
+                              int(bool(eps_mode)), float(eps), float(flat_thr), int(bool(use_eigh_top)), cout,
+                              ranks_dev.data_ptr() if ranks_dev is not None else None,
+                              zero_flag.data_ptr() if zero_flag is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    _check(code, "ttr_round_tt")
+
+
 def set_knob(knob: int, value: int):
     """Diagnostics: select a kernel variant (see ttr_debug_set_knob in the header)."""
     _check(lib().ttr_debug_set_knob(int(knob), int(value)), "ttr_debug_set_knob")
 
 
-def prof_enable(on: bool):
-    lib().ttr_prof_enable(int(on))
+def prof_enable(on):
+    """False / True: per-kind device times; 2: also the executed-work census (``prof_collect_work``)."""
+    _check(lib().ttr_prof_enable(int(on)), "ttr_prof_enable")
+
+
+def prof_collect_work():
+    """{kind: {"flops": f, "bytes": b}} executed by the instrumented launches since the last collect (census mode)."""
+    n = len(PROF_KINDS)
+    fl = (c_double * n)()
+    by = (c_double * n)()
+    _check(lib().ttr_prof_collect_work(fl, by), "ttr_prof_collect_work")
+    return {k: {"flops": fl[i], "bytes": by[i]} for i, k in enumerate(PROF_KINDS)}
 
 
 def prof_collect():

@@ -611,7 +611,7 @@ def truncate(
                 # device.  Batch mode: the rank does not depend on the small singular values.  eps mode: the rank rule is
                 # evaluated on pass 1's sigma and the item only qualifies when pass 2 provably selects the same rank (fp64
                 # trains: config C2; in fp32 the error margin of pass 1's tail energies exceeds a delta of 1e-4 ||T||).
-                flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, use_delta, delta2, delta2_dev)
+                flat = _hip.spectrum_flat(sig1, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, use_delta, delta2, delta2_dev, rows32=rows32)
                 if top_flat is not None:
                     # an item the top-r kernel decided on eigenvalues carries ONLY its r leading eigenpairs: it must pass through,
                     # also when the same test on sigma = sqrt(lambda) rounds to the other side of the threshold ([B] int32 flags)
@@ -1168,11 +1168,79 @@ def round_tt(
     return [arena.full[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
 
 
+# The whole sweep behind ONE library call (ttr_round_tt, csrc/ttr_roundtt.hip): same kernels, same order, bit-identical results --
+# the ~80 launches of a train are enqueued from C++ instead of one ctypes call each (the host cost of a call: 1.2 ms -> what the
+# device needs).  TTR_SWEEP_C=0: always the Python loop below (A/B; tests cross-check the two).
+SWEEP_C_ENABLED = os.environ.get("TTR_SWEEP_C", "1") != "0"
+SWEEP_C_CALLS = 0   # (tests: how many sweeps went through ttr_round_tt)
+
+
+def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> Optional[List[torch.Tensor]]:
+    """``_round_tt_sweep`` through ttr_round_tt, or None when the train lies outside that entry's envelope (TT ranks above 64,
+    cores outside the fused push, bonds with more rows than columns, fused sums, the eps-mode cases the Python loop reads back
+    bond by bond)."""
+    global SWEEP_C_CALLS
+    N = len(c)
+    if N < 2 or any(not torch.is_tensor(x) for x in c) or c[0].dtype not in (torch.float32, torch.float64):
+        return None
+    Bt = c[0].shape[0]
+    if Bt < 1 or any(x.dtype != c[0].dtype or x.shape[0] != Bt for x in c):
+        return None
+    shapes = [tuple(x.shape[1:]) for x in c]
+    eps_mode = not batch
+    rcap = [_hip.RANK_NONE if r is None else max(1, min(int(r), _hip.RANK_NONE)) for r in rmax]
+    if eps_mode:
+        # the reference's non-batch rule with the ranks kept on the device (see ``_eps_deferred_ok``: same policy)
+        mode = os.environ.get("TTR_EPS_DEFERRED", "auto")
+        if mode == "0" or Bt != 1:
+            return None
+        k, elems = shapes[0][0], 0
+        for mu in range(N - 1):
+            elems += k * shapes[mu][1] * shapes[mu][2]
+            k = min(k * shapes[mu][1], shapes[mu][2])
+        elems += k * shapes[N - 1][1] * shapes[N - 1][2]
+        if mode != "1" and (elems > _EPS_DEFERRED_MAX_ELEMS or any(r is None for r in rmax)):
+            return None
+    wsb = _hip.round_tt_plan(c[0].dtype, shapes, rcap, Bt, eps_mode)
+    if wsb < 0:
+        return None
+    tails, out_r = _rounded_tails(shapes, rmax)
+    dev, dt = c[0].device, c[0].dtype
+    if arena is not None:
+        outs = [arena.slice(mu, chunk, tails[mu]) for mu in range(N)]
+    else:
+        outs = [torch.empty((Bt,) + tuple(tails[mu]), dtype=dt, device=dev) for mu in range(N)]
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    ranks_dev = torch.empty(N - 1, dtype=torch.int32, device=dev) if eps_mode else None
+    zf = torch.empty(1, dtype=torch.int32, device=dev) if (zflags is not None and not eps_mode) else None
+    use_top = EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0
+    _hip.round_tt_sweep([x.contiguous() for x in c], rcap, algorithm, eps_mode, eps if eps is not None else 0.0,
+                        max(FLAT_SPECTRUM_THR, 0.0), use_top, outs, ranks_dev, zf, ws)
+    SWEEP_C_CALLS += 1
+    if zf is not None:
+        zflags.append(_deferred_readback(zf))
+    out = [outs[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
+    if eps_mode:
+        # the ONE host synchronisation of the sweep: the selected ranks; the cores -- computed at their caps, zero beyond the
+        # selected ranks -- are cut to size (layout copies)
+        ranks = ranks_dev.tolist()                      # ranks[mu - 1] = rank of bond mu
+        if min(ranks) == 0:  # zero guard (round.py:137-145): the carry was zero from the first bond on
+            return [torch.zeros((1, shapes[0][0] if mu == 0 else 1, shapes[mu][1], shapes[N - 1][2] if mu == N - 1 else 1),
+                                dtype=dt, device=dev) for mu in range(N)]
+        bond = [shapes[0][0]] + ranks + [shapes[N - 1][2]]
+        out = [x[:, :bond[mu], :, :bond[mu + 1]].contiguous() for mu, x in enumerate(out)]
+    return out
+
+
 def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -> List[torch.Tensor]:
     """The two sweeps on one (sub-)batch; with an ``arena`` the resulting cores are written into its slices.
     ``zflags``: list that receives the deferred readback of "largest rank-rule result of the first truncation" (0 = every
     item of this sub-batch hit the zero guard); see ``round_tt``."""
     N = len(c)
+    if SWEEP_C_ENABLED and not VERBOSE and not _FUSE_APPLY_GRAM:
+        done = _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags)
+        if done is not None:
+            return done
     facs = []
     st = _Stage()
     Rprev = None  # R factor still to be pushed into the current core

@@ -60,6 +60,92 @@ ProfScope::~ProfScope() {
   if (idx < g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, stream);
 }
 
+// ------------------------------------------------------------------ executed-work census
+static int g_prof_level = 0;          // 0 off, 1 = times, 2 = times + executed-work census
+static double* g_work_dev = nullptr;  // [2 * TTR_PROF_NKINDS]: flops per kind, then bytes per kind
+
+bool work_census_on() { return g_prof_level >= 2 && g_work_dev != nullptr; }
+
+__global__ void work_items_kernel(const int32_t* __restrict__ f1, const int32_t* __restrict__ f2, int64_t batch, double fl0, double fl1,
+                                  double fl2, double fl3, double by0, double by1, double by2, double by3, double* __restrict__ out_fl,
+                                  double* __restrict__ out_by) {
+  __shared__ double red[2 * kThreads / kWave];
+  double a = 0.0, c = 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < batch; b += (int64_t)gridDim.x * kThreads) {
+    const int k = ((f1 && f1[b] != 0) ? 1 : 0) + ((f2 && f2[b] != 0) ? 2 : 0);
+    a += k == 0 ? fl0 : k == 1 ? fl1 : k == 2 ? fl2 : fl3;
+    c += k == 0 ? by0 : k == 1 ? by1 : k == 2 ? by2 : by3;
+  }
+  a = wave_sum(a); c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[kThreads / kWave + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / kWave; ++w) { a += red[w]; c += red[kThreads / kWave + w]; }
+    atomicAdd(out_fl, a);
+    atomicAdd(out_by, c);
+  }
+}
+
+void work_items(int kind, const int32_t* f1, const int32_t* f2, int64_t batch, const double fl[4], const double by[4], hipStream_t s) {
+  if (!work_census_on() || batch <= 0) return;
+  int64_t gx = ceil_div(batch, kThreads);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(work_items_kernel, dim3((unsigned)gx), dim3(kThreads), 0, s, f1, f2, batch, fl[0], fl[1], fl[2], fl[3], by[0], by[1],
+                     by[2], by[3], g_work_dev + kind, g_work_dev + TTR_PROF_NKINDS + kind);
+}
+
+template <typename T>
+__global__ void work_qr_taus_kernel(const T* __restrict__ tau, int64_t nblk, int64_t nb_per_item, int NP, int64_t m, int64_t rpb, int n,
+                                    int kc, int reads_input, double* __restrict__ out_fl, double* __restrict__ out_by) {
+  __shared__ double red[2 * kThreads / kWave];
+  double a = 0.0, by = 0.0;
+  const double s = (double)sizeof(T);
+  for (int64_t blk = (int64_t)blockIdx.x * kThreads + threadIdx.x; blk < nblk; blk += (int64_t)gridDim.x * kThreads) {
+    const T* __restrict__ t = tau + blk * NP;
+    int q = 0;
+    for (int pnl = 0; pnl < NP / 16; ++pnl) {
+      bool live = false;
+      for (int j = 0; j < 16; ++j) live = live || (t[16 * pnl + j] != T(0));
+      q += live ? 1 : 0;
+    }
+    const int64_t b = blk % nb_per_item;
+    double r = (double)(m - b * rpb < rpb ? m - b * rpb : rpb);
+    if (r < 0) r = 0;
+    double c = 16.0 * q;
+    if (c > n) c = n;
+    if (kc > 0) {
+      a += 4.0 * r * c * kc;
+      by += s * (r * c + (q > 0 ? r * kc : 0.0));                       // live reflectors read, the block's output rows written
+    } else {
+      a += 2.0 * r * c * c - 2.0 * c * c * c / 3.0 + 4.0 * r * c * (n - c);
+      by += s * (r * c + (q > 0 ? (double)n * n : 0.0) + (reads_input ? r * n : 0.0));   // reflectors + R written (+ the block read)
+    }
+  }
+  a = wave_sum(a); by = wave_sum(by);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[kThreads / kWave + (threadIdx.x >> 6)] = by; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / kWave; ++w) { a += red[w]; by += red[kThreads / kWave + w]; }
+    atomicAdd(out_fl, a);
+    atomicAdd(out_by, by);
+  }
+}
+
+void work_qr_taus(int kind, const void* tau, bool f64, int64_t nblk, int64_t nb_per_item, int NP, int64_t m, int64_t rpb, int n,
+                  int kc, bool reads_input, hipStream_t s) {
+  if (!work_census_on() || nblk <= 0) return;
+  int64_t gx = ceil_div(nblk, kThreads);
+  if (gx > 512) gx = 512;
+  double* fl = g_work_dev + kind;
+  double* by = g_work_dev + TTR_PROF_NKINDS + kind;
+  if (f64)
+    hipLaunchKernelGGL(work_qr_taus_kernel<double>, dim3((unsigned)gx), dim3(kThreads), 0, s, (const double*)tau, nblk, nb_per_item, NP, m,
+                       rpb, n, kc, reads_input ? 1 : 0, fl, by);
+  else
+    hipLaunchKernelGGL(work_qr_taus_kernel<float>, dim3((unsigned)gx), dim3(kThreads), 0, s, (const float*)tau, nblk, nb_per_item, NP, m,
+                       rpb, n, kc, reads_input ? 1 : 0, fl, by);
+}
+
 // ------------------------------------------------------------------ small kernels
 template <typename T>
 __global__ __launch_bounds__(kThreads) void norm_kernel(const T* __restrict__ x, int64_t count, int64_t stride_x,
@@ -140,9 +226,14 @@ __global__ __launch_bounds__(kThreads) void mask_cols_kernel(int64_t rows, int64
 template <typename T>
 __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, const T* __restrict__ sigma, int64_t stride_sigma,
                                      int use_delta, double delta2, const double* __restrict__ delta2_dev, int32_t* __restrict__ flat,
-                                     int noise_c) {
+                                     int noise_c, const int32_t* __restrict__ rows32, int n_full) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
+  // `rows32` items (the carry of a packed bond: rows 32.. are exactly zero, ttr_rowgram): sigma[32..] are STRUCTURAL zeros -- exact
+  // in pass 1 and in pass 2 alike -- so the rule's decision about them is certain and only the 32 computed values carry pass 1's
+  // error.  (With the noise floor of TTR_KNOB_RANK_NOISE_FLOOR they count as c eps sigma_0 and are treated like any other value.)
+  if (rows32 && rows32[b] != 0 && noise_c <= 0 && n > 32) n = 32;
+  if (keep > n) keep = n;
   const T* __restrict__ sgr = sigma + b * stride_sigma;
   const T s0 = sgr[0];
   // (the rank rule's view of the spectrum: rank_rule in ttr_common.h -- with TTR_KNOB_RANK_NOISE_FLOOR nothing lies below c eps sigma_0)
@@ -155,7 +246,7 @@ __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, cons
     // eps mode: the rank comes from the tail energies of pass 1's sigma, which carry an absolute error of up to E = 64 n eps sigma_1^2
     // (n values, each c eps sigma_1^2 off); the item only qualifies when the rule's decision is the same for every spectrum within E
     // of this one -- tail(r) <= delta^2 - E and tail(r - 1) > delta^2 + E at the selected rank r (rank cap binding: only the latter)
-    const double E = 64.0 * n * (double)Num<T>::eps() * (double)s0 * (double)s0;
+    const double E = 64.0 * n_full * (double)Num<T>::eps() * (double)s0 * (double)s0;
     double acc = 0.0, tail_r = 0.0;
     int tail = 0;
     for (int k = n - 1; k >= 0; --k) {
@@ -1025,7 +1116,8 @@ int ttr_tridiag_back(int dtype, int64_t n, int64_t batch, int64_t k, const void*
 }
 
 int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, int64_t stride_sigma, int64_t keep, double thr,
-                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, void* stream) {
+                      int use_delta, double delta2, const double* delta2_dev, int32_t* flat, const int32_t* rows32,
+                      void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_spectrum_flat: bad dtype %d", dtype);
   TTR_REQUIRE(n >= 1 && keep >= 1 && keep <= n && batch >= 0 && thr > 0.0 && thr <= 1.0 && delta2 >= 0.0, TTR_E_INVALID,
               "ttr_spectrum_flat: bad arguments");
@@ -1036,10 +1128,10 @@ int ttr_spectrum_flat(int dtype, int64_t n, int64_t batch, const void* sigma, in
   ProfScope prof(TTR_PROF_MISC, s);
   if (dtype == TTR_F32)
     hipLaunchKernelGGL(spectrum_flat_kernel<float>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, (float)thr,
-                       (const float*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c);
+                       (const float*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c, rows32, (int)n);
   else
     hipLaunchKernelGGL(spectrum_flat_kernel<double>, dim3(gx), dim3(kThreads), 0, s, batch, (int)n, (int)keep, thr,
-                       (const double*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c);
+                       (const double*)sigma, stride_sigma, use_delta, delta2, delta2_dev, flat, g_rank_noise_c, rows32, (int)n);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
@@ -1246,6 +1338,11 @@ int ttr_debug_set_knob(int knob, int value) {
 int ttr_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
+  g_prof_level = on;
+  if (on >= 2) {   // census mode: per-kind device counters (the only allocation this library ever makes; profiling runs only)
+    if (!g_work_dev) TTR_HIP_CHECK(hipMalloc((void**)&g_work_dev, 2 * TTR_PROF_NKINDS * sizeof(double)));
+    TTR_HIP_CHECK(hipMemset(g_work_dev, 0, 2 * TTR_PROF_NKINDS * sizeof(double)));
+  }
   return TTR_OK;
 }
 
@@ -1266,6 +1363,21 @@ int ttr_prof_collect(double* ms, int64_t* launches) {
     g_prof_pool.push_back({r.start, r.stop});
   }
   g_prof_recs.clear();
+  return TTR_OK;
+}
+
+int ttr_prof_collect_work(double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double host[2 * TTR_PROF_NKINDS] = {0};
+  if (g_work_dev) {
+    TTR_HIP_CHECK(hipDeviceSynchronize());
+    TTR_HIP_CHECK(hipMemcpy(host, g_work_dev, sizeof(host), hipMemcpyDeviceToHost));
+    TTR_HIP_CHECK(hipMemset(g_work_dev, 0, sizeof(host)));
+  }
+  for (int k = 0; k < TTR_PROF_NKINDS; ++k) {
+    if (flops) flops[k] = host[k];
+    if (bytes) bytes[k] = host[TTR_PROF_NKINDS + k];
+  }
   return TTR_OK;
 }
 

@@ -37,6 +37,24 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// ------------------------------------------------------------------ executed-work census (ttr_prof_enable(2))
+// The per-kind device times of the profiler say nothing about how much of a kernel's ALGORITHMIC work a launch performed: the
+// kernels decide per item / per block, on the device, to skip work the input does not need (rank-skipped panels and packed rows
+// of the QR blocks, `rows32` items of the Gram / projection kernels, pass-through items of the second Gram pass).  In census
+// mode every instrumented dispatcher enqueues, OUTSIDE its timed scope, a tiny kernel that reads the same device-side decisions
+// (taus, flags) and adds the flops / bytes the launch really executed to per-kind device counters (ttr_prof_collect_work).
+bool work_census_on();
+// adds fl[c] / by[c] for every item b of the batch, c = (f1 && f1[b] ? 1 : 0) + (f2 && f2[b] ? 2 : 0)
+void work_items(int kind, const int32_t* f1, const int32_t* f2, int64_t batch, const double fl[4], const double by[4], hipStream_t s);
+// QR blocks: `tau` holds nblk blocks of NP reflector scalars; a block's q live 16-column panels (any tau != 0) cost
+//   factor (kc == 0): 2 r c^2 - 2 c^3 / 3 + 4 r c (n - c), c = 16 q (Householder panels + update of the other columns)
+//   apply  (kc  > 0): 4 r c kc                               (W = V^T C and C -= V (T W))
+// with r = the block's rows: rpb, the last block of an item (nb blocks per item, m rows) what is left
+// bytes: live reflectors (r c) + R (n^2) written by a factoring block, + its r x n input when `reads_input` (every launch but
+// the fused push, whose core / Rm reads are charged per item); an applying block reads its live reflectors and writes r x kc
+void work_qr_taus(int kind, const void* tau, bool f64, int64_t nblk, int64_t nb_per_item, int NP, int64_t m, int64_t rpb, int n,
+                  int kc, bool reads_input, hipStream_t s);
+
 // ------------------------------------------------------------------ MFMA 16x16x4 wrappers
 // A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));

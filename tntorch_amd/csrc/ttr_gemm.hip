@@ -401,6 +401,13 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   p.rs = (const T*)rs; p.stride_rs = stride_rs; p.rs_mode = rs_mode;
   p.cs = (const T*)cs; p.stride_cs = stride_cs; p.cs_mode = cs_mode;
   p.batch = batch;
+  if (work_census_on()) {   // dense product: every tile is computed (the symmetric big-tile path: the upper tile triangle)
+    const double sfac = (sizeof(T) == 4 && A == B && lda == ldb && strideA == strideB && transA != transB && M == N && !rs && !cs && !axpby &&
+                         big_plan(TTR_F32, M, N, K, batch, true).use) ? 0.5 * (1.0 + 128.0 / (double)(M > 128 ? M : 128)) : 1.0;
+    const double fl[4] = {2.0 * (double)M * (double)N * (double)K * sfac, 0, 0, 0};
+    const double by[4] = {(double)sizeof(T) * ((double)M * K * (A == B ? 1.0 : 1.0) + (A == B ? 0.0 : (double)K * N) + (double)M * N), 0, 0, 0};
+    work_items(TTR_PROF_GEMM, nullptr, nullptr, batch, fl, by, stream);
+  }
   if constexpr (sizeof(T) == 4) {
     // symmetric product: the same matrix on both sides, transposed on exactly one (A^T A or A A^T), no epilogue
     const bool sym = A == B && lda == ldb && strideA == strideB && transA != transB && M == N && !rs && !cs && !axpby;

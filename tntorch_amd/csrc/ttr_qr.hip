@@ -1392,19 +1392,35 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.top = (l == L - 1);
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
-    ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-    p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? 1 : 0;
-    const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
     const bool pushed = (l == 0 && pu.Rm);
-    if (pl.nw[l] == 8 && g_qr_variant != 0) {
-      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, true>), grid, dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, true>), grid, dim3(512), 0, stream, p);
-    } else if (pl.nw[l] == 8) {
-      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, false>), grid, dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, false>), grid, dim3(512), 0, stream, p);
-    } else {
-      if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 4, false>), grid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 4, false>), grid, dim3(256), 0, stream, p);
+    {
+      ProfScope prof(TTR_PROF_QR_FACTOR, stream);
+      p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? 1 : 0;
+      const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
+      if (pl.nw[l] == 8 && g_qr_variant != 0) {
+        if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, true>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, true>), grid, dim3(512), 0, stream, p);
+      } else if (pl.nw[l] == 8) {
+        if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, false>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 8, false>), grid, dim3(512), 0, stream, p);
+      } else {
+        if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 4, false>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((qr_factor_kernel<T, NT, false, 4, false>), grid, dim3(256), 0, stream, p);
+      }
+    }
+    if (work_census_on()) {   // what this launch executed, from the taus / flags it left behind (outside the timed scope)
+      work_qr_taus(TTR_PROF_QR_FACTOR, p.tau, sizeof(T) == 8, batch * pl.nb[l], pl.nb[l], pl.npad, pl.m[l], 64 * pl.nw[l], n, 0, !pushed, stream);
+      if (pushed) {
+        // the fused push Rm (k x Rin) x core (Rin x I n): 16 x 16 (row tile, K group) products; an upper-triangular Rm skips the
+        // tiles below the diagonal (square Rm: T (T + 1) / 2 of T^2); a packed item only forms rows 0 .. 31 (7 of its 8 tiles)
+        const double full = 2.0 * pu.k * pu.Rin * (double)pu.I * n;
+        const int Tt = (pu.k + 15) / 16;
+        const double tri = (pu.k == pu.Rin && Tt >= 1) ? (double)(Tt + 1) / (2.0 * Tt) : 1.0;
+        const double fl[4] = {full * tri, 2.0 * 32 * pu.Rin * (double)pu.I * n * (7.0 / 8.0), 0.0, 0.0};
+        const double rd = (double)sizeof(T) * ((double)pu.Rin * pu.I * n + (double)pu.k * pu.Rin);   // the core and Rm, read once
+        const double by[4] = {rd, rd, 0.0, 0.0};
+        work_items(TTR_PROF_QR_FACTOR, p.pack_flag, nullptr, batch, fl, by, stream);
+      }
     }
   }
   TTR_HIP_CHECK(hipGetLastError());
@@ -1432,11 +1448,15 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     p.pack_flag = (l == 0 && pk > 0) ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
     p.skip_zero_rows = (l == 0) ? skipz : 0;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
-    ProfScope prof(TTR_PROF_QR_APPLY, stream);
-    p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? 1 : 0;
-    const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
-    if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 4>), grid, dim3(256), 0, stream, p);
+    {
+      ProfScope prof(TTR_PROF_QR_APPLY, stream);
+      p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? 1 : 0;
+      const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
+      if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 4>), grid, dim3(256), 0, stream, p);
+    }
+    if (work_census_on())
+      work_qr_taus(TTR_PROF_QR_APPLY, p.tau, sizeof(T) == 8, batch * pl.nb[l], pl.nb[l], pl.npad, pl.m[l], 64 * pl.nw[l], n, kc, false, stream);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;

@@ -734,6 +734,15 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.G = (T*)G; p.nsplit = (int)nsplit;
+  if (work_census_on()) {
+    // executed work per item: rows32 items load / multiply 32 of the R rows; pass-through items (skip) of the rotated pass do
+    // nothing.  Gram: 10 of the 16 tiles (symmetry); rotation V1^T M: R x Reff x n.
+    const double s = (double)sizeof(T), sym = 10.0 / 16.0;
+    auto gr = [&](double Re) { return 2.0 * Re * Re * (double)n * sym + (V1 ? 2.0 * (double)R * Re * (double)n : 0.0); };
+    const double fl[4] = {gr((double)R), gr(R > 32 ? 32.0 : (double)R), 0.0, 0.0};
+    const double by[4] = {s * R * (double)n, s * (R > 32 ? 32.0 : (double)R) * (double)n, 0.0, 0.0};
+    work_items(V1 ? TTR_PROF_ROTGRAM : TTR_PROF_ROWGRAM, rows32, skip, batch, fl, by, stream);
+  }
   ProfScope prof(V1 ? TTR_PROF_ROTGRAM : TTR_PROF_ROWGRAM, stream);
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
@@ -775,6 +784,12 @@ static int project_typed(int64_t R, int64_t n, int64_t ro, int64_t batch, const 
   p.right = (T*)right; p.ldr = ldr; p.strideR = strideR;
   p.left = (T*)left; p.ldl = ldl; p.strideL = strideL;
   p.nsplit = pick_split(n, batch);
+  if (work_census_on()) {   // right = U^T M: ro x Reff x n; reads Reff rows, writes ro rows
+    const double s = (double)sizeof(T), Re = R > 32 ? 32.0 : (double)R;
+    const double fl[4] = {2.0 * R * (double)ro * (double)n, 2.0 * Re * (double)ro * (double)n, 0.0, 0.0};
+    const double by[4] = {s * (R + ro) * (double)n, s * (Re + ro) * (double)n, 0.0, 0.0};
+    work_items(TTR_PROF_PROJECT, rows32, nullptr, batch, fl, by, stream);
+  }
   ProfScope prof(TTR_PROF_PROJECT, stream);
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
