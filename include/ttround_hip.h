@@ -570,6 +570,16 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      directions depending on that noise.  c = 1 reproduces the reference's usual outcome (fp32: the cap;
  *                      fp64: eps^2 < 1e-28, still cut); tntorch_amd sets it from TTR_STRICT_RANKS=1. */
 #define TTR_KNOB_RANK_NOISE_FLOOR 9
+/*   TTR_KNOB_ORTH_ROUNDS  (default 4) upper bound on the rounds of ttr_orth_fixup's block variant (diagnostics: what a round costs;
+ *                      fewer than the data needs leaves the completed directions short of orthonormal).  In census mode
+ *                      (ttr_prof_enable(2)) the MISC counters receive flops += rounds executed, bytes += items with dead directions. */
+#define TTR_KNOB_ORTH_ROUNDS 10
+/*   TTR_KNOB_JACOBI_LIVE_WAVE  1 (default) = ttr_eigh_trunc with TTR_SOLVER_JACOBI_LIVE on n <= 64 runs ONE wave per matrix (no
+ *                      cross-wave barrier in the round loop); 0 = the four-wave kernel (A/B). */
+#define TTR_KNOB_JACOBI_LIVE_WAVE 11
+/*   TTR_KNOB_ORTH_V2  1 (default) = ttr_orth_fixup's block variant for <= 32 vectors runs the round-5 inner loops (wide LDS operand
+ *                      reads with a permuted K order, dead tile rows only, chunk columns split over the four waves); 0 = round 4's (A/B). */
+#define TTR_KNOB_ORTH_V2 12
 /*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

@@ -1036,6 +1036,9 @@ KNOB_QR_RANK_SKIP = 6
 KNOB_QR_PACK = 7
 KNOB_EIGH_SMALL = 8
 KNOB_RANK_NOISE_FLOOR = 9
+KNOB_ORTH_ROUNDS = 10
+KNOB_JACOBI_LIVE_WAVE = 11
+KNOB_ORTH_V2 = 12
 
 
 ALG_SVD, ALG_EIG = 0, 1

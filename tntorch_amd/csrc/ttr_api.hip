@@ -417,11 +417,20 @@ inline size_t orth_fixup_lds_bytes(int r, int cw, size_t es) {
 
 // kOfCW: columns per chunk (a chunk = one global round trip + two barriers: 64 columns left the kernel latency-bound on
 // them); kOfLd: tile row stride
-template <typename T, int kOfCW>
-__global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t es,
+// V2 (round 5, the CW = 256 instance, i.e. up to 32 vectors -- every bond of a rank-32 rounding): the same two passes per round with
+// their inner loops rebuilt around the LDS.  Round 4's loops issued one ds_read_b32 per MFMA operand and waited for it (184 VGPRs:
+// two waves per SIMD, nothing to hide the latency with): 12 us per 32 x 256 chunk and pass, measured (profiles/r05_decay_probe.txt:
+// 0.76 ms per launch and round at B = 2048) against ~1 us of MFMA time.  Here (a) the Gram pass reads its operands as ds_read_b128
+// with the K index permuted (lane (i, q) takes columns 16 g + 4 q + j for the j-th MFMA of column group g: any K order is a valid
+// sum), computes only the tile rows that hold dead vectors, and the four waves split the chunk's 16-column groups (partials added
+// through S in wave order: deterministic); (b) the apply pass keeps its W operands in registers for the whole pass and reads the
+// tile with a K permutation that spreads a wave's four K rows over all 64 banks.
+template <typename T, int kOfCW, bool V2>
+__global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t es,
                                                                     int64_t strideX, const T* __restrict__ sigma,
                                                                     int64_t stride_sigma, double dead_rel,
-                                                                    const int32_t* __restrict__ rank_dev) {
+                                                                    const int32_t* __restrict__ rank_dev, int max_rounds,
+                                                                    double* __restrict__ census) {
   constexpr int kOfLd = kOfCW + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char of_smem[];
   const int r_launch = r;
@@ -478,7 +487,9 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
     }
   };
 
-  for (int round = 0; round < 4; ++round) {
+  if (census && tid == 0) atomicAdd(census + TTR_PROF_NKINDS + TTR_PROF_MISC, 1.0);   // census: items with dead rows ...
+  for (int round = 0; round < max_rounds; ++round) {
+    if (census && tid == 0) atomicAdd(census + TTR_PROF_MISC, 1.0);                   // ... and the rounds they took
     // ---- S = X X^T on the matrix cores: wave w owns the 16-row tile w of S (all column tiles); fp32 accumulators are
     // flushed into double sums after every chunk (64 products per entry), fp64 accumulates in place
     double sacc[4][4];
@@ -493,6 +504,36 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
       stage(reg);
       __syncthreads();
       if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);   // the next chunk's loads fly under this chunk's products
+      if constexpr (V2) {
+        // nt <= 2 tile rows; sacc[2 tr + v] = tile (tr, v) of S for the tile rows tr >= tr0 that hold dead vectors
+        typename Mfma<T>::Acc acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = Mfma<T>::zero();
+        const int tr0 = first >> 4;
+        const T* __restrict__ xr = tile + (lane & 15) * kOfLd + 4 * (lane >> 4);
+#pragma unroll
+        for (int g = 0; g < kOfCW / 64; ++g) {
+          const int k0 = 16 * (wv + 4 * g);
+          typedef T tv4 __attribute__((ext_vector_type(4)));
+          const tv4 x0 = *reinterpret_cast<const tv4*>(xr + k0);
+          const tv4 x1 = nt > 1 ? *reinterpret_cast<const tv4*>(xr + 16 * kOfLd + k0) : tv4{0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (tr0 == 0) {
+              acc[0] = Mfma<T>::mma(x0[j], x0[j], acc[0]);
+              if (nt > 1) acc[1] = Mfma<T>::mma(x0[j], x1[j], acc[1]);
+            }
+            if (nt > 1) {
+              acc[2] = Mfma<T>::mma(x1[j], x0[j], acc[2]);
+              acc[3] = Mfma<T>::mma(x1[j], x1[j], acc[3]);
+            }
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[v][u] += (double)acc[v][u];
+      } else {
       if (wv < nt) {
         typename Mfma<T>::Acc acc[4];
 #pragma unroll
@@ -510,8 +551,27 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
 #pragma unroll
           for (int u = 0; u < 4; ++u) sacc[v][u] += (double)acc[v][u];
       }
+      }
     }
     __syncthreads();
+    if constexpr (V2) {
+      // the four waves' partial sums, added in wave order (deterministic); tile (tr, v) lives in sacc[2 tr + v]
+      for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+          for (int tv = 0; tv < 4; ++tv) {
+            const int tr = tv >> 1, v = tv & 1;
+            if (tr < (first >> 4) || tr >= nt || v >= nt) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              double* dst = S + (16 * tr + Mfma<T>::row(lane, u)) * ls + 16 * v + (lane & 15);
+              *dst = (w == 0 ? 0.0 : *dst) + sacc[tv][u];
+            }
+          }
+        }
+        __syncthreads();
+      }
+    } else {
     if (wv < nt) {
 #pragma unroll
       for (int v = 0; v < 4; ++v)
@@ -519,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
 #pragma unroll
           for (int u = 0; u < 4; ++u) S[(16 * wv + Mfma<T>::row(lane, u)) * ls + 16 * v + (lane & 15)] = sacc[v][u];
         }
+    }
     }
     if (tid < 64) regen[tid] = 0;
     if (tid == 0) { any_regen[0] = 0; any_regen[1] = 0; }
@@ -588,6 +649,8 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
       __syncthreads();
     }
     // ---- X_dead <- W X  (regenerated rows: hashed pseudo-random values, orthogonalised by the next round)
+    // V2: K index of MFMA m for lane group q = 4 q + (m & 3) + 16 (m >> 2) -- the four K rows a wave reads per MFMA lie 4 rows
+    // apart (16 banks at the tile's row stride of cw + 4 words: conflict-free); the W operands of the whole pass sit in registers
     fetch(0, reg);
     for (int64_t c0 = 0; c0 < n; c0 += kOfCW) {
       const int cw = (int)((n - c0) < kOfCW ? (n - c0) : kOfCW);
@@ -597,12 +660,33 @@ __global__ __launch_bounds__(kThreads) void orth_fixup_block_kernel(int r, int64
       if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);
       // wave w: the 16-column blocks w, w + 4, .. of the chunk, every 16-row tile that holds dead rows; W (double in LDS) is the A
       // operand in the matrix precision -- the second round sees W = I + O(first round's error), which restores full accuracy
+      T wreg[2][8];
+      if constexpr (V2) {   // (once per chunk: 16 LDS reads for the chunk's 16 column blocks)
+#pragma unroll
+        for (int iu = 0; iu < 2; ++iu)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const int it = (first >> 4) + iu, kk = 4 * (lane >> 4) + (m & 3) + 16 * (m >> 2);
+            wreg[iu][m] = (it < nt && m < 4 * nt) ? (T)S[(size_t)(16 * it + (lane & 15)) * ls + kk] : T(0);
+          }
+      }
       for (int cb = wv; cb < kOfCW / 16; cb += 4)
       for (int it = first >> 4; it < nt; ++it) {
         typename Mfma<T>::Acc acc = Mfma<T>::zero();
+        if constexpr (V2) {
+          const int iu = it - (first >> 4);
+          const T* __restrict__ bcol = tile + 4 * (lane >> 4) * kOfLd + 16 * cb + (lane & 15);
+          T bv[8];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) bv[m] = m < 4 * nt ? bcol[((m & 3) + 16 * (m >> 2)) * kOfLd] : T(0);
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+            if (m < 4 * nt) acc = Mfma<T>::mma(iu == 0 ? wreg[0][m] : wreg[1][m], bv[m], acc);
+        } else {
         const double* __restrict__ wrow = S + (size_t)(16 * it + (lane & 15)) * ls + (lane >> 4);   // (the dead rows of S hold W_D now)
         const T* __restrict__ bcol = tile + (lane >> 4) * kOfLd + 16 * cb + (lane & 15);
         for (int k0 = 0; k0 < 16 * nt; k0 += 4) acc = Mfma<T>::mma((T)wrow[k0], bcol[k0 * kOfLd], acc);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int d = 16 * it + Mfma<T>::row(lane, u), c = 16 * cb + (lane & 15);
@@ -718,6 +802,7 @@ extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
 extern int g_qr_pack;
 extern int g_rank_noise_c;
+extern int g_jacobi_live_wave;
 extern int g_eigh_small;
 
 static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
@@ -1227,6 +1312,9 @@ int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int6
   return TTR_OK;
 }
 
+static int g_orth_v2 = 1;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2, 0): round 4's inner loops (A/B)
+static int g_orth_rounds = 4;   // ttr_debug_set_knob(TTR_KNOB_ORTH_ROUNDS): rounds of the block orthonormal completion (diagnostics)
+
 int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
                    int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
                    void* stream) {
@@ -1239,15 +1327,21 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
   if (r <= 64) {  // the block variant (Gram matrix + coefficient-space Gram-Schmidt + one small product per round)
     const int cw = r <= 32 ? 256 : 128;
     const size_t lds = orth_fixup_lds_bytes((int)r, cw, dtype == TTR_F32 ? 4 : 8);
-#define TTR_OF_LAUNCH(T_, CW_)                                                                                                  \
+#define TTR_OF_LAUNCH(T_, CW_, V2_)                                                                                             \
     do {                                                                                                                          \
-      auto kern = orth_fixup_block_kernel<T_, CW_>;                                                                               \
+      auto kern = orth_fixup_block_kernel<T_, CW_, V2_>;                                                                          \
       if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, n, (T_*)X, vec_stride, elem_stride, strideX, \
-                         (const T_*)sigma, stride_sigma, dead_rel, rank_dev);                                                      \
+                         (const T_*)sigma, stride_sigma, dead_rel, rank_dev, g_orth_rounds, work_census_on() ? g_work_dev : nullptr); \
     } while (0)
-    if (dtype == TTR_F32) { if (cw == 256) TTR_OF_LAUNCH(float, 256); else TTR_OF_LAUNCH(float, 128); }
-    else { if (cw == 256) TTR_OF_LAUNCH(double, 256); else TTR_OF_LAUNCH(double, 128); }
+    if (dtype == TTR_F32) {
+      if (cw == 256 && g_orth_v2) TTR_OF_LAUNCH(float, 256, true);
+      else if (cw == 256) TTR_OF_LAUNCH(float, 256, false);
+      else TTR_OF_LAUNCH(float, 128, false);
+    } else {   // (fp64: round 4's loops -- the V2 instance would spill at two waves per SIMD)
+      if (cw == 256) TTR_OF_LAUNCH(double, 256, false);
+      else TTR_OF_LAUNCH(double, 128, false);
+    }
 #undef TTR_OF_LAUNCH
   } else if (dtype == TTR_F32)
     hipLaunchKernelGGL(orth_fixup_kernel<float>, dim3((unsigned)batch), dim3(kThreads), 0, s, (int)r, n, (float*)X,
@@ -1301,6 +1395,18 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_EIGH_SMALL:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
       g_eigh_small = value;
+      return TTR_OK;
+    case TTR_KNOB_ORTH_V2:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: orth_fixup variant %d outside [0, 1]", value);
+      g_orth_v2 = value;
+      return TTR_OK;
+    case TTR_KNOB_JACOBI_LIVE_WAVE:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: pass-2 Jacobi switch %d outside [0, 1]", value);
+      g_jacobi_live_wave = value;
+      return TTR_OK;
+    case TTR_KNOB_ORTH_ROUNDS:
+      TTR_REQUIRE(value >= 1 && value <= 4, TTR_E_INVALID, "ttr_debug_set_knob: %d rounds outside [1, 4]", value);
+      g_orth_rounds = value;
       return TTR_OK;
     case TTR_KNOB_RANK_NOISE_FLOOR:
       TTR_REQUIRE(value >= 0 && value <= 1024, TTR_E_INVALID, "ttr_debug_set_knob: rank-rule noise floor %d outside [0, 1024]", value);

@@ -106,8 +106,8 @@ __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, do
 }
 constexpr int UNR = 8;          // rotation items batched per thread (n = 64: exactly one batch per phase)
 
-template <typename T, bool LDSRES>
-__global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
+template <typename T, bool LDSRES, int NTH = kThreads>
+__global__ __launch_bounds__(NTH) void eigh_jacobi_kernel(EighArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (p.skip_flag && *p.skip_flag != 0) return;  // (wave-uniform: one word for the whole launch)
   const int tid = threadIdx.x;
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   if (p.skip_items && p.skip_items[bt] != 0) {  // (block-uniform) pass-through item, see EighArgs
     const int n = nf;
     T* __restrict__ Vo = p.V + bt * p.strideV;
-    for (int idx = tid; idx < n * n; idx += kThreads) {
+    for (int idx = tid; idx < n * n; idx += NTH) {
       const int i = idx / n, j = idx - i * n;
       Vo[(int64_t)i * p.ldv + j] = (i == j) ? T(1) : T(0);
     }
     const T* __restrict__ si = p.sigma_in + bt * p.stride_sigma_in;
-    for (int i = tid; i < n; i += kThreads) p.sigma[bt * p.stride_sigma + i] = si[i];
+    for (int i = tid; i < n; i += NTH) p.sigma[bt * p.stride_sigma + i] = si[i];
     if (tid == 0) {  // the rank rule of the regular epilogue, on pass 1's sigma (ttr_spectrum_flat made sure pass 2 would agree)
       const T d2 = p.use_delta ? (T)(p.delta2_dev ? *p.delta2_dev : p.delta2) : T(0);
       p.info[bt] = rank_rule<T>(si, n, n, p.rmax, p.use_delta, d2, p.noise_c);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     const int b = p.pair_b;
     const int64_t ri = (int64_t)p.pair_tab[2 * pair] * b, rj = (int64_t)p.pair_tab[2 * pair + 1] * b;
     const T* __restrict__ G = p.G + item * p.strideG;
-    for (int idx = tid; idx < n * n; idx += kThreads) {
+    for (int idx = tid; idx < n * n; idx += NTH) {
       const int i = idx / n, j = idx % n;
       const int64_t gi = i < b ? ri + i : rj + (i - b), gj = j < b ? ri + j : rj + (j - b);
       Gs[i * ld + j] = G[gi * p.ldg + gj];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
   } else {
   const T* __restrict__ G = p.G + bt * p.strideG;
-  for (int idx = tid; idx < n * n; idx += kThreads) {
+  for (int idx = tid; idx < n * n; idx += NTH) {
     const int i = idx / n, j = idx % n;
     T gv = G[(int64_t)i * p.ldg + j];
     for (int pt = 1; pt < p.gparts; ++pt) gv += G[pt * p.stride_gpart + (int64_t)i * p.ldg + j];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       // nothing above the noise level, so they are frozen.
       const T thr = (T)nf * Num<T>::eps();   // (nf: the thresholds do not depend on the live prefix)
       const T dead_below = thr * thr * gmax;
-      for (int i = tid; i < n; i += kThreads) deadv[i] = (Gs[i * ld + i] <= dead_below) ? 1 : 0;
+      for (int i = tid; i < n; i += NTH) deadv[i] = (Gs[i * ld + i] <= dead_below) ? 1 : 0;
       __syncthreads();
     } else {
       floor_abs = fmax(floor_abs, Num<T>::eps() * sqrt((T)n) * gmax);
@@ -234,11 +234,11 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   const T eps = Num<T>::eps() * sqrt((T)nf);
   const int m1 = ne - 1;
   const int k0 = tid / n, i0 = tid % n;            // item = tid + 256*e  <->  (k, i), advanced incrementally
-  const int dk = kThreads / n, di = kThreads % n;
+  const int dk = NTH / n, di = NTH % n;
   // 2x2-block phase mapping: sub-groups of cw lanes <-> column pairs, (wave, sub-group) <-> row pairs
   const int cw = np <= 32 ? 32 : 64;
   const int kc_l = (tid & 63) & (cw - 1);
-  const int krs = 4 * (64 / cw);                       // row-pair stride between a thread's blocks
+  const int krs = (NTH / 64) * (64 / cw);                       // row-pair stride between a thread's blocks
   const int kr0 = (tid >> 6) * (64 / cw) + (tid & 63) / cw;
 
   // Convergence scan, before every sweep: does any off-diagonal entry pass the rotation test?  One pass over the
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     // exactly the test of phase 1, on exactly the element phase 1 reads (G[p][q] of the schedule's ordered pair:
     // the two-sided updates leave G symmetric only to rounding, so testing the other triangle could disagree
     // with phase 1 at the threshold and keep a finished matrix spinning until max_sweeps)
-    for (int idx = tid; idx < m1 * np; idx += kThreads) {
+    for (int idx = tid; idx < m1 * np; idx += NTH) {
       const int r = idx / np, k = idx - r * np;
       int pp, qq;
       if (k == 0) { pp = ne - 1; qq = r % m1; }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     sweeps_used = sweep + 1;
     for (int r = 0; r < m1; ++r) {
       // ---- phase 1: rotations of this round (one thread per pair)
-      for (int k = tid; k < np; k += kThreads) {
+      for (int k = tid; k < np; k += NTH) {
         int pp, qq;
         if (k == 0) { pp = ne - 1; qq = r % m1; }
         else { pp = (r + k) % m1; qq = (r - k + m1) % m1; }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
       }
       // ---- V <- V J  (columns p,q; lanes walk rows).  Independent of the G blocks: same barrier interval.
       for (int base = tid, kb_ = k0, ib_ = i0; base < np * n;) {
-        if (base + (UNR - 1) * kThreads < np * n) {  // fast path, branch-free (same argument as above)
+        if (base + (UNR - 1) * NTH < np * n) {  // fast path, branch-free (same argument as above)
           T cv[UNR], sv[UNR], vp[UNR], vq[UNR];
           int ap[UNR], aq[UNR];
           int k = kb_, i = ib_;
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
             Vs[ap[u]] = cv[u] * vp[u] - sv[u] * vq[u];
             Vs[aq[u]] = sv[u] * vp[u] + cv[u] * vq[u];
           }
-          base += UNR * kThreads; kb_ = k; ib_ = i;
+          base += UNR * NTH; kb_ = k; ib_ = i;
         } else {
           int k = kb_, i = ib_;
-          for (; base < np * n; base += kThreads) {
+          for (; base < np * n; base += NTH) {
             const T sv = st[k], cv = ct[k];
             const int ap = i * ld + pq_p[k], aq = i * ld + pq_q[k];
             const T vp = Vs[ap], vq = Vs[aq];
@@ -395,14 +395,14 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T* sig_sorted = sg + nf; // [nf]
   int* posv = reinterpret_cast<int*>(smem_raw);  // [nf] destination column of eigenvector i (the rotation table is free now:
                                                  // 40 bytes per pair slot, at least 8 slots >= 64 ints when nf <= 64 > n)
-  for (int i = tid; i < nf; i += kThreads) {
+  for (int i = tid; i < nf; i += NTH) {
     T w = i < n ? Gs[i * ld + i] : dtail;        // (n < nf only when nf <= 64: tid = i = this lane's index)
     if (p.eig_mode == TTR_EIG_REF) { if (w < T(0)) w = T(1e-8); }
     else { if (!(w > T(0))) w = T(0); }
     sig[i] = sqrt(w);
   }
   __syncthreads();
-  for (int i = tid; i < nf; i += kThreads) {
+  for (int i = tid; i < nf; i += NTH) {
     const T si = sig[i];
     int pos = 0;
     for (int j = 0; j < nf; ++j) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
   T* __restrict__ V = p.V + bt * p.strideV;
   if (sizeof(T) == 4 && any_work) {
     // E = V^T V - I (double accumulation) overwrites G, which is no longer needed
-    for (int idx = tid; idx < n * n; idx += kThreads) {
+    for (int idx = tid; idx < n * n; idx += NTH) {
       const int i = idx / n, j = idx - i * n;
       double a = 0.0;
       for (int k = 0; k < n; ++k) a += (double)Vs[k * ld + i] * (double)Vs[k * ld + j];
@@ -425,26 +425,26 @@ __global__ __launch_bounds__(kThreads) void eigh_jacobi_kernel(EighArgs<T> p) {
     }
     __syncthreads();
     // V' = V - 0.5 V E, written straight to the output with the columns permuted into sorted order
-    for (int idx = tid; idx < n * n; idx += kThreads) {
+    for (int idx = tid; idx < n * n; idx += NTH) {
       const int row = idx / n, j = idx - row * n;
       T a = 0;
       for (int k = 0; k < n; ++k) a += Vs[row * ld + k] * Gs[k * ld + j];
       V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j] - T(0.5) * a;
     }
   } else {  // double accumulation is already orthogonal to ~1e-14 (or V is still exactly the identity)
-    for (int idx = tid; idx < n * n; idx += kThreads) {
+    for (int idx = tid; idx < n * n; idx += NTH) {
       const int row = idx / n, j = idx - row * n;
       V[(int64_t)row * p.ldv + posv[j]] = Vs[row * ld + j];
     }
   }
   if (n < nf) {  // the frozen tail: unit eigenvectors, zeros elsewhere
-    for (int idx = tid; idx < nf * nf; idx += kThreads) {
+    for (int idx = tid; idx < nf * nf; idx += NTH) {
       const int row = idx / nf, j = idx - row * nf;
       if (row >= n || j >= n) V[(int64_t)row * p.ldv + posv[j]] = (row == j) ? T(1) : T(0);
     }
   }
   T* __restrict__ sout = p.sigma + bt * p.stride_sigma;
-  for (int i = tid; i < nf; i += kThreads) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
+  for (int i = tid; i < nf; i += NTH) sout[i] = p.eig_mode == TTR_EIG_MATCH_DIAG ? sig[i] : sig_sorted[i];
   if (tid == 0) {
     // (the rank rule sees the whole spectrum; zero guard: round.py:137-145)
     const T d2 = p.use_delta ? (T)(p.delta2_dev ? *p.delta2_dev : p.delta2) : T(0);
@@ -1588,6 +1588,7 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
 }
 
 int g_rank_noise_c = 0;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): see rank_rule (ttr_common.h)
+int g_jacobi_live_wave = 1;  // ttr_debug_set_knob(TTR_KNOB_JACOBI_LIVE_WAVE, 0): the four-wave kernel for pass 2 as well (A/B)
 int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
@@ -1636,7 +1637,16 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   }
   const size_t lds = eigh_lds_bytes(sizeof(T), n, ldsres);
   ProfScope prof(TTR_PROF_EIGH, stream);
-  if (ldsres) {
+  if (ldsres && abs_floor == TTR_SOLVER_JACOBI_LIVE && n <= 64 && g_jacobi_live_wave) {
+    // Pass 2 of the 'svd' truncation (nearly diagonal, graded; the live prefix is ~n / 2): ONE wave per matrix.  With four
+    // waves a round of the parallel-order Jacobi is all synchronisation -- 2.5 us per round measured at n_live = 35
+    // (profiles/r05_decay_probe.txt: 0.8 ms per launch of 2048 matrices, 4.5 sweeps) for ~20 flops per thread; a lone wave
+    // needs no cross-wave barrier at all.
+    auto kern = eigh_jacobi_kernel<T, true, kWave>;
+    if (lds > 64 * 1024)
+      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds, stream, p);
+  } else if (ldsres) {
     auto kern = eigh_jacobi_kernel<T, true>;
     if (lds > 64 * 1024)
       TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
