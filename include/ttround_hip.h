@@ -574,8 +574,9 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      fewer than the data needs leaves the completed directions short of orthonormal).  In census mode
  *                      (ttr_prof_enable(2)) the MISC counters receive flops += rounds executed, bytes += items with dead directions. */
 #define TTR_KNOB_ORTH_ROUNDS 10
-/*   TTR_KNOB_JACOBI_LIVE_WAVE  1 (default) = ttr_eigh_trunc with TTR_SOLVER_JACOBI_LIVE on n <= 64 runs ONE wave per matrix (no
- *                      cross-wave barrier in the round loop); 0 = the four-wave kernel (A/B). */
+/*   TTR_KNOB_JACOBI_LIVE_WAVE  1 = ttr_eigh_trunc with TTR_SOLVER_JACOBI_LIVE on n <= 64 runs ONE wave per matrix (no cross-wave
+ *                      barrier in the round loop): measured SLOWER (1.25 vs 0.80 ms per launch of 2048 matrices, round 5);
+ *                      0 (default) = the four-wave kernel. */
 #define TTR_KNOB_JACOBI_LIVE_WAVE 11
 /*   TTR_KNOB_ORTH_V2  1 (default) = ttr_orth_fixup's block variant for <= 32 vectors runs the round-5 inner loops (wide LDS operand
  *                      reads with a permuted K order, dead tile rows only, chunk columns split over the four waves); 0 = round 4's (A/B). */

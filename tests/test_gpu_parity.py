@@ -1489,7 +1489,7 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
     inp = oracle.tt_add(g, g)   # TT ranks 12, numerical ranks 6 (3e6 entries: compared densely -- tt_rel_err resolves 1e-8)
     calls = []
     orig = _hip.spectrum_flat
-    monkeypatch.setattr(_hip, "spectrum_flat", lambda *a: calls.append(orig(*a)) or calls[-1])
+    monkeypatch.setattr(_hip, "spectrum_flat", lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1])
     res = {}
     for thr in (0.125, 0.0):
         monkeypatch.setattr(_hipops, "FLAT_SPECTRUM_THR", thr)

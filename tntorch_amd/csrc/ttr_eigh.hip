@@ -1588,7 +1588,11 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
 }
 
 int g_rank_noise_c = 0;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): see rank_rule (ttr_common.h)
-int g_jacobi_live_wave = 1;  // ttr_debug_set_knob(TTR_KNOB_JACOBI_LIVE_WAVE, 0): the four-wave kernel for pass 2 as well (A/B)
+// ttr_debug_set_knob(TTR_KNOB_JACOBI_LIVE_WAVE, 1): pass 2 with ONE wave per matrix.  REFUTED by measurement (round 5,
+// profiles/r05_decay_probe.txt): 1.25 instead of 0.80 ms per launch of 2048 matrices at n_live = 35 (eigh 14.3 instead of 10.0 ms
+// per step), 0.38 instead of 0.26 ms at n_live = 18 -- a round of the parallel-order Jacobi is ~7000 scattered LDS accesses, not
+// synchronisation: a quarter of the lanes take longer over them than the barriers of four waves cost.  Kept for the A/B.
+int g_jacobi_live_wave = 0;
 int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
@@ -1638,10 +1642,7 @@ static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_
   const size_t lds = eigh_lds_bytes(sizeof(T), n, ldsres);
   ProfScope prof(TTR_PROF_EIGH, stream);
   if (ldsres && abs_floor == TTR_SOLVER_JACOBI_LIVE && n <= 64 && g_jacobi_live_wave) {
-    // Pass 2 of the 'svd' truncation (nearly diagonal, graded; the live prefix is ~n / 2): ONE wave per matrix.  With four
-    // waves a round of the parallel-order Jacobi is all synchronisation -- 2.5 us per round measured at n_live = 35
-    // (profiles/r05_decay_probe.txt: 0.8 ms per launch of 2048 matrices, 4.5 sweeps) for ~20 flops per thread; a lone wave
-    // needs no cross-wave barrier at all.
+    // (diagnostic variant, see g_jacobi_live_wave: ONE wave per matrix -- measured slower than the four-wave kernel)
     auto kern = eigh_jacobi_kernel<T, true, kWave>;
     if (lds > 64 * 1024)
       TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
