@@ -581,6 +581,17 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
 /*   TTR_KNOB_ORTH_V2  1 (default) = ttr_orth_fixup's block variant for <= 32 vectors runs the round-5 inner loops (wide LDS operand
  *                      reads with a permuted K order, dead tile rows only, chunk columns split over the four waves); 0 = round 4's (A/B). */
 #define TTR_KNOB_ORTH_V2 12
+/*   TTR_KNOB_QR_INTERLEAVE  1 (default) = the block-major launches of TTR_KNOB_QR_PACK = 3 (ttr_qr_factor_pushed level 0,
+ *                      ttr_qr_apply_pushed level 0) order the workgroups of each half item by item (an item's working blocks follow
+ *                      each other), so that resident workgroups differ in the address bits their block index fixes -- HBM channel
+ *                      spreading; 0 = all items' block 0, then all items' block 1, ... (round 4; A/B). */
+#define TTR_KNOB_QR_INTERLEAVE 13
+/*   TTR_KNOB_SWEEP_STAGGER  the fused <= 64-row sweep kernels walk an item's columns starting at step (item index mod steps) and
+ *                      wrap around, so that resident workgroups do not read the same column offsets (= the same HBM channels:
+ *                      every item's rows are ldm elements apart and aligned alike) at the same time.  1 (default) = ttr_project only
+ *                      (independent columns: bit-identical results); 2 = ttr_rowgram / ttr_rotgram as well (their sums are then
+ *                      accumulated in an item-dependent order); 0 = in order (A/B). */
+#define TTR_KNOB_SWEEP_STAGGER 14
 /*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

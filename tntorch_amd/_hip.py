@@ -1039,6 +1039,8 @@ KNOB_RANK_NOISE_FLOOR = 9
 KNOB_ORTH_ROUNDS = 10
 KNOB_JACOBI_LIVE_WAVE = 11
 KNOB_ORTH_V2 = 12
+KNOB_QR_INTERLEAVE = 13
+KNOB_SWEEP_STAGGER = 14
 
 
 ALG_SVD, ALG_EIG = 0, 1

@@ -430,8 +430,13 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
                                                                     int64_t strideX, const T* __restrict__ sigma,
                                                                     int64_t stride_sigma, double dead_rel,
                                                                     const int32_t* __restrict__ rank_dev, int max_rounds,
-                                                                    double* __restrict__ census) {
+                                                                    double* __restrict__ census, long long* __restrict__ dbg) {
   constexpr int kOfLd = kOfCW + 4;
+  // (diagnostics, ttr_debug_set_qr_stamps with TTR_KNOB_QR_STAMP_BX = -1: item 0 stamps its phases -- start, then per round: Gram
+  // pass done, coefficients done, apply pass done)
+  int dbgi = 0;
+  auto ostamp = [&]() { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[dbgi++] = (long long)clock64(); };
+  ostamp();
   extern __shared__ __attribute__((aligned(16))) unsigned char of_smem[];
   const int r_launch = r;
   const int64_t b = blockIdx.x;
@@ -487,6 +492,15 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
     }
   };
 
+  // Chunk order.  Every item's vectors lie 4 n bytes apart (8 KB at the metric's bonds), so the 32 row pieces of chunk c of EVERY
+  // item share their address bits 10 .. 12: workgroups that walk their chunks in step keep hitting the same eighth of the HBM
+  // channels (measured, round 5: 13.5 us per 32 KB chunk and workgroup = 1.2 TB/s chip-wide with the loads of a whole chunk in
+  // flight per workgroup; profiles/r05_orth_stamps.txt).  V2: item b starts at chunk b mod nch and wraps around -- at any moment
+  // the resident workgroups cover all chunk phases.  (The Gram sums are then added in an item-dependent order: double
+  // accumulation across chunks, so an item's result depends on its position in the batch at the 1e-16 level of S only.)
+  const int nch = (int)((n + kOfCW - 1) / kOfCW);
+  const int rot = V2 ? (int)(b % nch) : 0;
+  auto chunk_c0 = [&](int tq) { int c = tq + rot; if (c >= nch) c -= nch; return (int64_t)c * kOfCW; };
   if (census && tid == 0) atomicAdd(census + TTR_PROF_NKINDS + TTR_PROF_MISC, 1.0);   // census: items with dead rows ...
   for (int round = 0; round < max_rounds; ++round) {
     if (census && tid == 0) atomicAdd(census + TTR_PROF_MISC, 1.0);                   // ... and the rounds they took
@@ -498,12 +512,12 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
 #pragma unroll
       for (int v = 0; v < 4; ++v) sacc[u][v] = 0.0;
     T reg[kOfMaxE];
-    fetch(0, reg);
-    for (int64_t c0 = 0; c0 < n; c0 += kOfCW) {
+    fetch(chunk_c0(0), reg);
+    for (int tq = 0; tq < nch; ++tq) {
       __syncthreads();
       stage(reg);
       __syncthreads();
-      if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);   // the next chunk's loads fly under this chunk's products
+      if (tq + 1 < nch) fetch(chunk_c0(tq + 1), reg);   // the next chunk's loads fly under this chunk's products
       if constexpr (V2) {
         // nt <= 2 tile rows; sacc[2 tr + v] = tile (tr, v) of S for the tile rows tr >= tr0 that hold dead vectors
         typename Mfma<T>::Acc acc[4];
@@ -584,6 +598,7 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
     if (tid < 64) regen[tid] = 0;
     if (tid == 0) { any_regen[0] = 0; any_regen[1] = 0; }
     __syncthreads();
+    ostamp();
     // ---- the dead rows against everything before them, in coefficient space (double).  The live rows are orthonormal
     // (S_LL = I to rounding), so the remainders x_d - S_dL x_L have the Gram matrix C = S_DD - S_DL S_LD; with C = L L^T
     // (Cholesky) the rows of  L^-1 [-S_DL, I]  are the coefficients of the orthonormalised dead vectors.  A pivot below 1e-4
@@ -648,45 +663,24 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
       }
       __syncthreads();
     }
+    ostamp();
     // ---- X_dead <- W X  (regenerated rows: hashed pseudo-random values, orthogonalised by the next round)
-    // V2: K index of MFMA m for lane group q = 4 q + (m & 3) + 16 (m >> 2) -- the four K rows a wave reads per MFMA lie 4 rows
-    // apart (16 banks at the tile's row stride of cw + 4 words: conflict-free); the W operands of the whole pass sit in registers
-    fetch(0, reg);
-    for (int64_t c0 = 0; c0 < n; c0 += kOfCW) {
+    fetch(chunk_c0(0), reg);
+    for (int tq = 0; tq < nch; ++tq) {
+      const int64_t c0 = chunk_c0(tq);
       const int cw = (int)((n - c0) < kOfCW ? (n - c0) : kOfCW);
       __syncthreads();
       stage(reg);
       __syncthreads();
-      if (c0 + kOfCW < n) fetch(c0 + kOfCW, reg);
+      if (tq + 1 < nch) fetch(chunk_c0(tq + 1), reg);
       // wave w: the 16-column blocks w, w + 4, .. of the chunk, every 16-row tile that holds dead rows; W (double in LDS) is the A
       // operand in the matrix precision -- the second round sees W = I + O(first round's error), which restores full accuracy
-      T wreg[2][8];
-      if constexpr (V2) {   // (once per chunk: 16 LDS reads for the chunk's 16 column blocks)
-#pragma unroll
-        for (int iu = 0; iu < 2; ++iu)
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const int it = (first >> 4) + iu, kk = 4 * (lane >> 4) + (m & 3) + 16 * (m >> 2);
-            wreg[iu][m] = (it < nt && m < 4 * nt) ? (T)S[(size_t)(16 * it + (lane & 15)) * ls + kk] : T(0);
-          }
-      }
       for (int cb = wv; cb < kOfCW / 16; cb += 4)
       for (int it = first >> 4; it < nt; ++it) {
         typename Mfma<T>::Acc acc = Mfma<T>::zero();
-        if constexpr (V2) {
-          const int iu = it - (first >> 4);
-          const T* __restrict__ bcol = tile + 4 * (lane >> 4) * kOfLd + 16 * cb + (lane & 15);
-          T bv[8];
-#pragma unroll
-          for (int m = 0; m < 8; ++m) bv[m] = m < 4 * nt ? bcol[((m & 3) + 16 * (m >> 2)) * kOfLd] : T(0);
-#pragma unroll
-          for (int m = 0; m < 8; ++m)
-            if (m < 4 * nt) acc = Mfma<T>::mma(iu == 0 ? wreg[0][m] : wreg[1][m], bv[m], acc);
-        } else {
         const double* __restrict__ wrow = S + (size_t)(16 * it + (lane & 15)) * ls + (lane >> 4);   // (the dead rows of S hold W_D now)
         const T* __restrict__ bcol = tile + (lane >> 4) * kOfLd + 16 * cb + (lane & 15);
         for (int k0 = 0; k0 < 16 * nt; k0 += 4) acc = Mfma<T>::mma((T)wrow[k0], bcol[k0 * kOfLd], acc);
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int d = 16 * it + Mfma<T>::row(lane, u), c = 16 * cb + (lane & 15);
@@ -708,6 +702,7 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
     // round 4: on the decaying-spectrum batch every item needs it -- the dead rows are mostly leakage of the live ones.  Starting
     // the dead rows from hashed vectors instead, one round: 11.3 -> 6.7 ms per step, but the approximation error of that batch
     // rose from 8.6e-6 to 2.4e-5 -- the dead rows do carry part of the tail; not taken.)
+    ostamp();
     if (!any_regen[0] && (round >= 1 || !any_regen[1])) break;
     __syncthreads();
   }
@@ -801,6 +796,8 @@ extern int g_qr_dbg_bx, g_qr_dbg_by;
 extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
 extern int g_qr_pack;
+extern int g_qr_interleave;
+extern int g_sweep_stagger;
 extern int g_rank_noise_c;
 extern int g_jacobi_live_wave;
 extern int g_eigh_small;
@@ -1332,7 +1329,8 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
       auto kern = orth_fixup_block_kernel<T_, CW_, V2_>;                                                                          \
       if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, n, (T_*)X, vec_stride, elem_stride, strideX, \
-                         (const T_*)sigma, stride_sigma, dead_rel, rank_dev, g_orth_rounds, work_census_on() ? g_work_dev : nullptr); \
+                         (const T_*)sigma, stride_sigma, dead_rel, rank_dev, g_orth_rounds, work_census_on() ? g_work_dev : nullptr, \
+                         g_qr_dbg_bx == -1 ? g_qr_dbg : nullptr);                                                                  \
     } while (0)
     if (dtype == TTR_F32) {
       if (cw == 256 && g_orth_v2) TTR_OF_LAUNCH(float, 256, true);
@@ -1395,6 +1393,14 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_EIGH_SMALL:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
       g_eigh_small = value;
+      return TTR_OK;
+    case TTR_KNOB_SWEEP_STAGGER:
+      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: stagger mode %d outside [0, 2]", value);
+      g_sweep_stagger = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_INTERLEAVE:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: interleave switch %d outside [0, 1]", value);
+      g_qr_interleave = value;
       return TTR_OK;
     case TTR_KNOB_ORTH_V2:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: orth_fixup variant %d outside [0, 1]", value);

@@ -106,6 +106,29 @@ __device__ __forceinline__ void block_rows(int64_t m, int nb, int b, int64_t& ro
 // publishes the pair (v0, v1, tau0, tau1, v0^T v1); the waves to its right apply BOTH reflectors with ONE 4-value
 // reduction,  c <- c - a0 v0 - a1 v1,  a0 = tau0 v0^T c,  a1 = tau1 (v1^T c - (v0^T v1) a0);  the reflectors go to the
 // workspace after the panel (all threads, coalesced) instead of from the owner's sequential chain.
+
+// (item, block) of a workgroup.  grid_swap 0: grid (nb, batch).  1: grid (batch, nb), block-major -- all items' block 0, then all
+// items' block 1, ...: the working blocks of packed items (b < nb / 2) are dispatched before the absorbed ones.  2 (round 5): the
+// same two halves, but INSIDE a half the blocks of an item follow each other (item 0's blocks 0 .. nb/2-1, item 1's, ...).  Why:
+// what a level-0 block of the fused push reads (core[:, i, :], i = 8 b .. 8 b + 7: 256-byte pieces 16 KB apart) and what the
+// apply writes (rows kk I + i: 128-byte pieces 8 KB apart) has its address bits 11 .. 13 fixed by b and every item is aligned
+// alike -- with mode 1 all resident workgroups share b and camp on an eighth of the HBM channels (the same effect measured on
+// ttr_orth_fixup, profiles/r05_orth_stamps.txt).
+__device__ __forceinline__ void block_of(int grid_swap, int nb, int& b, int64_t& bt) {
+  if (grid_swap == 2) {
+    const int half = nb >> 1;
+    const int64_t id = (int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y;   // launch order (x fastest); gridDim.x = batch
+    const int64_t nwork = (int64_t)gridDim.x * half;
+    const int64_t r = id < nwork ? id : id - nwork;
+    bt = r / half;
+    b = (int)(r - bt * half) + (id < nwork ? 0 : half);
+  } else if (grid_swap) {
+    b = blockIdx.y; bt = blockIdx.x;
+  } else {
+    b = blockIdx.x; bt = blockIdx.y;
+  }
+}
+
 template <typename T, int NT, bool PUSHED, int NW, bool PAIR>
 __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_kernel(QrLevel<T> p) {
   using M = Mfma<T>;
@@ -137,8 +160,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   const int cl = lane & 15, g = lane >> 4;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform
   // grid (nb, batch), or -- grid_swap, experiment -- (batch, nb): block-major launch order
-  const int b = p.grid_swap ? blockIdx.y : blockIdx.x;
-  const int64_t bt = p.grid_swap ? blockIdx.x : blockIdx.y;
+  int b;
+  int64_t bt;
+  block_of(p.grid_swap, p.nb, b, bt);
   int64_t row0;
   int rows;
   block_rows(p.m, p.nb, b, row0, rows);
@@ -1014,8 +1038,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = lane & 15, g = lane >> 4;
-  const int b = p.grid_swap ? blockIdx.y : blockIdx.x;
-  const int64_t bt = p.grid_swap ? blockIdx.x : blockIdx.y;
+  int b;
+  int64_t bt;
+  block_of(p.grid_swap, p.nb, b, bt);
   int64_t row0;
   int rows;
   block_rows(p.m, p.nb, b, row0, rows);
@@ -1353,6 +1378,7 @@ int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_
 // what an unpacked block costs and there are half as many); block-major: 1.1 ms, the metric step 20.9 -> 17.5 ms
 // (tools/probes/qr_pack_stamps.py, profiles/r04_qr_pack_ab.txt).  0 = never pack.
 int g_qr_pack = 3;
+int g_qr_interleave = 1;   // ttr_debug_set_knob(TTR_KNOB_QR_INTERLEAVE): see block_of (0 = round 4's block-major order, A/B)
 int g_rank_skip_c = 8;   // ttr_debug_set_knob(TTR_KNOB_QR_RANK_SKIP, c): threshold factor of the rank-revealing early exit (0 = off)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
 
@@ -1395,7 +1421,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     const bool pushed = (l == 0 && pu.Rm);
     {
       ProfScope prof(TTR_PROF_QR_FACTOR, stream);
-      p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? 1 : 0;
+      p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? ((g_qr_interleave && (pl.nb[l] & 1) == 0) ? 2 : 1) : 0;
       const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
       if (pl.nw[l] == 8 && g_qr_variant != 0) {
         if (pushed) hipLaunchKernelGGL((qr_factor_kernel<T, NT, true, 8, true>), grid, dim3(512), 0, stream, p);
@@ -1450,7 +1476,7 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     {
       ProfScope prof(TTR_PROF_QR_APPLY, stream);
-      p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? 1 : 0;
+      p.grid_swap = (g_qr_pack == 3 && p.pack_flag) ? ((g_qr_interleave && (pl.nb[l] & 1) == 0) ? 2 : 1) : 0;
       const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
       if (pl.nw[l] == 8) hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 8>), grid, dim3(512), 0, stream, p);
       else hipLaunchKernelGGL((qr_apply_kernel<T, NT, NTC, 4>), grid, dim3(256), 0, stream, p);

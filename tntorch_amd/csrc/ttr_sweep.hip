@@ -45,6 +45,7 @@ struct SweepArgs {
   int64_t ldr, strideR;
   T* left;          // R x ro (nullable)
   int64_t ldl, strideL;
+  int stagger;      // TTR_KNOB_SWEEP_STAGGER: 0 = columns in order, 1 = project staggered per item, 2 = the Gram kernels as well
 };
 
 __host__ __device__ inline void split_range(int64_t chunks, int nsplit, int split, int64_t& c0, int64_t& c1) {
@@ -135,12 +136,15 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
         for (int r = 0; r < 4; ++r) mw[t][r] = x.v[r];
       }
     };
+    // (step order: see project_kernel; the Gram sums are accumulated in an item-dependent order when staggered, knob value 2)
+    const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
+    const int64_t rot = (p.stagger >= 2 && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
+    auto step_c = [&](int64_t sidx) { int64_t sq = sidx + rot; if (sq >= nsteps) sq -= nsteps; return cb + wave + 4 * sq; };
     Acc cur[4], nxt[4];
-    int64_t c = cb + wave;
-    if (c < ce) load_slab(c, cur);
-    for (; c < ce; c += 4) {
-      const bool more = c + 4 < ce;
-      if (more) load_slab(c + 4, nxt);
+    if (nsteps > 0) load_slab(step_c(0), cur);
+    for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
+      const bool more = sidx + 1 < nsteps;
+      if (more) load_slab(step_c(sidx + 1), nxt);
       gram_update(cur);
       if (more) {
 #pragma unroll
@@ -161,12 +165,14 @@ __global__ __launch_bounds__(kThreads) void rotgram_kernel(SweepArgs<T> p) {
         a[ks] = (k < Rl && c0 + cl < p.n) ? Mp[(int64_t)k * p.ldm + c0 + cl] : T(0);
       }
     };
+    const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
+    const int64_t rot = (p.stagger >= 2 && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
+    auto step_c = [&](int64_t sidx) { int64_t sq = sidx + rot; if (sq >= nsteps) sq -= nsteps; return cb + wave + 4 * sq; };
     T a[16], an[16];
-    int64_t c = cb + wave;
-    if (c < ce) load_cols(c, a);
-    for (; c < ce; c += 4) {
-      const bool more = c + 4 < ce;
-      if (more) load_cols(c + 4, an);  // in flight under this step's 104 MFMAs (two waves per SIMD do not cover an HBM round trip)
+    if (nsteps > 0) load_cols(step_c(0), a);
+    for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
+      const bool more = sidx + 1 < nsteps;
+      if (more) load_cols(step_c(sidx + 1), an);  // in flight under this step's 104 MFMAs (two waves per SIMD do not cover an HBM round trip)
       Acc mw[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -294,7 +300,16 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
   int64_t cb, ce;
   split_range((p.n + 31) / 32, p.nsplit, split, cb, ce);
   const int Rl = (p.rows32 && p.rows32[b] != 0 && R > 32) ? 32 : R;   // (see rotgram_kernel: zero rows are not loaded)
-  for (int64_t c = cb + wave; c < ce; c += 4) {
+  // Step order: every item's rows lie ldm elements apart (8 KB at the metric's bonds) and every item is aligned alike, so
+  // workgroups that walk their columns in step would keep hitting the same HBM channels (address bits 8 .. 12 are the column's;
+  // measured on ttr_orth_fixup, profiles/r05_orth_stamps.txt).  Item b starts at step b mod nsteps and wraps around; the columns
+  // are independent of each other, so the result is bit-identical in any order.  (TTR_KNOB_SWEEP_STAGGER = 0: in order.)
+  const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
+  const int64_t rot = (p.stagger && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
+  for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
+    int64_t sq = sidx + rot;
+    if (sq >= nsteps) sq -= nsteps;
+    const int64_t c = cb + wave + 4 * sq;
     const int64_t col = c * 32 + 2 * cl;
     T bm[2][16];
 #pragma unroll
@@ -712,6 +727,8 @@ int colproject_dispatch(int dtype, int64_t rows, int64_t n, int64_t ro, int64_t 
                                   stride_sigma, left_ortho, left, ldl, strideL, right, ldr, strideR, stream);
 }
 
+int g_sweep_stagger = 1;   // ttr_debug_set_knob(TTR_KNOB_SWEEP_STAGGER)
+
 static int pick_split(int64_t n, int64_t batch) {
   const int64_t chunks = (n + 31) / 32;        // (the projection walks 32 columns per step and wave)
   int64_t want = (2048 + batch - 1) / batch;  // aim at >= 2048 workgroups on the 256 CUs ...
@@ -734,6 +751,7 @@ static int gram_typed(int64_t R, int64_t n, int64_t batch, const void* Mx, int64
   p.R = (int)R; p.n = n; p.M = (const T*)Mx; p.ldm = ldm; p.strideM = strideM;
   p.V1 = (const T*)V1; p.ldv1 = ldv1; p.strideV1 = strideV1;
   p.G = (T*)G; p.nsplit = (int)nsplit;
+  p.stagger = g_sweep_stagger;
   if (work_census_on()) {
     // executed work per item: rows32 items load / multiply 32 of the R rows; pass-through items (skip) of the rotated pass do
     // nothing.  Gram: 10 of the 16 tiles (symmetry); rotation V1^T M: R x Reff x n.
@@ -784,6 +802,7 @@ static int project_typed(int64_t R, int64_t n, int64_t ro, int64_t batch, const 
   p.right = (T*)right; p.ldr = ldr; p.strideR = strideR;
   p.left = (T*)left; p.ldl = ldl; p.strideL = strideL;
   p.nsplit = pick_split(n, batch);
+  p.stagger = g_sweep_stagger;
   if (work_census_on()) {   // right = U^T M: ro x Reff x n; reads Reff rows, writes ro rows
     const double s = (double)sizeof(T), Re = R > 32 ? 32.0 : (double)R;
     const double fl[4] = {2.0 * R * (double)ro * (double)n, 2.0 * Re * (double)ro * (double)n, 0.0, 0.0};
