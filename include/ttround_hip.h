@@ -265,7 +265,12 @@ int ttr_eigh_top(int dtype, int64_t n, int64_t batch,
                  const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
                  void* V, int64_t ldv, int64_t strideV,
                  void* sigma, int64_t stride_sigma,
-                 int32_t* info, int64_t r, double thr, int32_t* flat, void* stream);
+                 int32_t* info, int64_t r, double thr, int32_t* flat, int need_all, void* stream);
+/* `need_all` != 0 (ABI 10; the first pass of an eps-mode bond, whose rank rule needs every singular value): the top-r path only
+ * takes items of which it computes EVERY eigenpair -- r >= the item's live size, i.e. the zero-tail (32 x 32) problems of a packed
+ * bond under a cap r >= 32; all other items get the full QL decomposition of the same launch.  sigma / V are then complete for
+ * every item (structural zeros / unit vectors beyond a shrunk block), exactly as ttr_eigh_trunc(TTR_EIG_RAW, TTR_SOLVER_TRIDIAG)
+ * returns them, and `flat` is not meaningful (the caller runs ttr_spectrum_flat with use_delta). */
 
 /*
  * Selected eigenpairs of symmetric matrices with 64 < n <= ttr_eigsel_max_n() (1024): the k <= 64 LARGEST eigenvalues and their

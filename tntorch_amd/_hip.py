@@ -108,7 +108,7 @@ _SIGNATURES = {
     "ttr_eigh_top": (
         c_int,
         [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-         c_void_p, c_int64, c_double, c_void_p, c_void_p],
+         c_void_p, c_int64, c_double, c_void_p, c_int, c_void_p],
     ),
     "ttr_eigsel_max_n": (c_int, []),
     "ttr_eigsel_scratch_bytes": (c_int64, [c_int, c_int64, c_int64]),
@@ -590,11 +590,12 @@ def eigh_top_ok(n: int, r: int) -> bool:
 
 
 @_on_device
-def eigh_top(G: torch.Tensor, r: int, thr: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+def eigh_top(G: torch.Tensor, r: int, thr: float, need_all: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Pass 1 of a batch-mode bond: symmetric [batch, n, n] (or split partials [batch, parts, n, n]), 40 <= n <= 64, rank cap
     r <= 32 (ttr_eigh_top).  Returns (V, sigma, info, flat): items with flat[b] = 1 carry their r largest eigenpairs (V[b][:, :r],
     sigma[b][:r], zeros beyond), the others the full decomposition of ``eigh_trunc(G, EIG_RAW, ..., abs_floor=SOLVER_TRIDIAG)``
-    (flat[b] = 2 when its kept sigma pass ``spectrum_flat``'s batch-mode test, else 0)."""
+    (flat[b] = 2 when its kept sigma pass ``spectrum_flat``'s batch-mode test, else 0).  ``need_all``: eps mode -- the top-r path only
+    takes items whose every eigenpair it computes (zero-tail items under a cap >= 32); sigma / V are complete for every item."""
     L = lib()
     dt = dtype_code(G.dtype)
     gparts, sGp = 1, 0
@@ -611,7 +612,7 @@ def eigh_top(G: torch.Tensor, r: int, thr: float) -> Tuple[torch.Tensor, torch.T
     flat = torch.empty((batch,), dtype=torch.int32, device=G.device)
     if batch:
         _check(L.ttr_eigh_top(dt, n, batch, G.data_ptr(), ldg, sG, gparts, sGp, V.data_ptr(), n, n * n, sigma.data_ptr(), n,
-                              info.data_ptr(), int(r), float(thr), flat.data_ptr(), _stream()), "ttr_eigh_top")
+                              info.data_ptr(), int(r), float(thr), flat.data_ptr(), int(bool(need_all)), _stream()), "ttr_eigh_top")
     return V, sigma, info, flat
 
 

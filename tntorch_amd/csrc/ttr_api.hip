@@ -746,7 +746,7 @@ int eigh_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ld
                   const void* sigma_in = nullptr, int64_t stride_sigma_in = 0);
 int eigh_top_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                       int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info,
-                      int64_t r, double thr, int32_t* flat, hipStream_t stream);
+                      int64_t r, double thr, int32_t* flat, hipStream_t stream, int need_all);
 int eigh_pairs_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, const void* G, int64_t ldg, int64_t strideG,
                         const int32_t* pair_tab, void* W, void* scratch, const int32_t* skip_flag, int32_t* rot_count,
                         hipStream_t stream);
@@ -979,7 +979,7 @@ int ttr_eigh_top_ok(int64_t n, int64_t r) { return n >= 40 && n <= 64 && r >= 1 
 
 int ttr_eigh_top(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                  int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info,
-                 int64_t r, double thr, int32_t* flat, void* stream) {
+                 int64_t r, double thr, int32_t* flat, int need_all, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_eigh_top: bad dtype %d", dtype);
   TTR_REQUIRE(batch >= 0 && gparts >= 1 && thr > 0.0 && thr <= 1.0, TTR_E_INVALID, "ttr_eigh_top: bad arguments");
   TTR_REQUIRE(ttr_eigh_top_ok(n, r), TTR_E_UNSUPPORTED, "ttr_eigh_top: n = %lld, r = %lld outside 40 <= n <= 64, r <= 32, r < n",
@@ -987,7 +987,7 @@ int ttr_eigh_top(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg
   if (batch == 0) return TTR_OK;
   TTR_REQUIRE(G && V && sigma && info, TTR_E_INVALID, "ttr_eigh_top: null pointer");
   return eigh_top_dispatch(dtype, n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr,
-                           flat, (hipStream_t)stream);
+                           flat, (hipStream_t)stream, need_all);
 }
 
 int64_t ttr_bj_scratch_bytes(int dtype, int64_t b, int64_t npairs, int64_t items) {

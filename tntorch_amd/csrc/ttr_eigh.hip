@@ -70,6 +70,7 @@ struct EighArgs {
   int32_t* top_flat;
   double top_thr;
   int top_r;
+  int top_need_all;          // != 0: the top-r path only serves items of which it computes EVERY eigenpair (top_r >= the live size)
   const int32_t* skip_flag;  // != 0 on the device: the driver has converged, the launch returns at once
   int32_t* rot_count;        // incremented once per problem that rotated anything (the driver's "a whole sweep found nothing")
 };
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) 
     for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off, 64));
     const T l0 = lamv[0], lr = lamv[rsel - 1];
     const T thr = (T)p.top_thr;
-    return l0 > T(0) && lr >= thr * thr * l0 && (rsel == 1 || gmin >= T(512) * eps * l0);
+    return l0 > T(0) && lr >= thr * thr * l0 && (rsel == 1 || gmin >= T(512) * eps * l0) && (!p.top_need_all || rsel == n);
   };
   T* const invn = wsh;   // [<= 32] 1 / ||x_j|| of the twisted vectors (the tridiagonalisation's second broadcast array is free by then)
 
@@ -1685,8 +1686,9 @@ extern "C" void ttr_debug_set_eigh_stamps(void* p) { g_eigh_stamps = p; }
 template <typename T>
 static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts, int64_t stride_gpart,
                           void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info, int64_t r, double thr,
-                          int32_t* flat, hipStream_t stream) {
+                          int32_t* flat, hipStream_t stream, int need_all) {
   EighArgs<T> p{};
+  p.top_need_all = need_all;
   p.n = (int)n;
   p.G = (const T*)G; p.ldg = ldg; p.strideG = strideG; p.gparts = (int)gparts; p.stride_gpart = stride_gpart;
   p.V = (T*)V; p.ldv = ldv; p.strideV = strideV;
@@ -1708,10 +1710,10 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
 }
 int eigh_top_dispatch(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                       int64_t stride_gpart, void* V, int64_t ldv, int64_t strideV, void* sigma, int64_t stride_sigma, int32_t* info,
-                      int64_t r, double thr, int32_t* flat, hipStream_t stream) {
+                      int64_t r, double thr, int32_t* flat, hipStream_t stream, int need_all) {
   if (dtype == TTR_F32)
-    return eigh_top_typed<float>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream);
-  return eigh_top_typed<double>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream);
+    return eigh_top_typed<float>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream, need_all);
+  return eigh_top_typed<double>(n, batch, G, ldg, strideG, gparts, stride_gpart, V, ldv, strideV, sigma, stride_sigma, info, r, thr, flat, stream, need_all);
 }
 
 int g_bj_inner_sweeps = 1;  // ttr_debug_set_knob(TTR_KNOB_BJ_INNER_SWEEPS); measured on C3's share: 1 -> 72 ms, 2 -> 82, 3 -> 90, until converged -> 97

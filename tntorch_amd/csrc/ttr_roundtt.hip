@@ -307,8 +307,13 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
     const void* V1p = nullptr;
     if (svd) {
       const int32_t* flat = nullptr;
-      if (!eps_mode && use_eigh_top && flat_thr > 0.0 && rcap_mu < kNoCap && ttr_eigh_top_ok(R, cap)) {
-        TTR_TRY(ttr_eigh_top(dt, R, B, G, R, parts * R * R, parts, R * R, V1, R, R * R, sig1, R, info1, cap, flat_thr, flatb, st));
+      if (use_eigh_top && flat_thr > 0.0 && rcap_mu < kNoCap && ttr_eigh_top_ok(R, cap)) {
+        // (eps mode: need_all -- the top-r path only where it computes every eigenpair; the certified flat test follows)
+        TTR_TRY(ttr_eigh_top(dt, R, B, G, R, parts * R * R, parts, R * R, V1, R, R * R, sig1, R, info1, cap, flat_thr, flatb,
+                             eps_mode ? 1 : 0, st));
+        if (eps_mode) {
+          TTR_TRY(ttr_spectrum_flat(dt, R, B, sig1, R, cap, flat_thr, 1, 0.0, d2dev, flatb, r32, st));
+        }
         flat = flatb;
       } else {
         TTR_TRY(ttr_eigh_trunc(dt, R, B, G, R, parts * R * R, parts, R * R, V1, R, R * R, sig1, R, info1, TTR_EIG_RAW, 0, 0.0, nullptr,

@@ -24,6 +24,12 @@ def kind_of(name):
         return "qr_factor"
     if "qr_apply_kernel" in name:
         return "qr_apply"
+    if "colgram_kernel" in name:
+        return "colgram"
+    if "colproject_kernel" in name:
+        return "colproject"
+    if "krp_contract" in name:
+        return "krp_contract"
     if "rotgram_kernel" in name:
         return "rowgram" if re.search(r"rotgram_kernel<\w+, true>", name) else "rotgram"
     if "project_kernel" in name and "colproject" not in name:
