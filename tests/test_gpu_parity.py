@@ -1359,6 +1359,28 @@ def test_whole_sweep_entry_eps_mode_vs_host_loop_and_oracle(dt, eps, alg, monkey
     assert _hipops.SWEEP_C_CALLS == n0 + 1
 
 
+@pytest.mark.parametrize("call", ["rmax32", "eps1e-4", "eps1e-4_rmax40"])
+def test_reference_call_signature_on_the_metric_shape(call, monkeypatch):
+    """The reference's own NON-batch calls on one 64^8 rank-64 train t = g + g (`t.round_tt(rmax=32)`, `t.round_tt(eps=1e-4)`):
+    the deferred eps-mode sweep -- first pass through ttr_eigh_top with `need_all` (the packed bonds' 32 x 32 problems by the
+    top-r path, complete spectra), certified flat test on the `rows32` items, ranks read back once -- through ttr_round_tt and
+    through the host loop bit for bit, and against the oracle: ranks, bond singular values, train (SURVEY 8c bounds)."""
+    it = [c[0] for c in _metric_input(1, seed=31)]
+    kw = {"rmax32": dict(rmax=32), "eps1e-4": dict(eps=1e-4), "eps1e-4_rmax40": dict(eps=1e-4, rmax=40)}[call]
+    monkeypatch.setenv("TTR_EPS_DEFERRED", "1")
+    a, b, used = _sweep_both_ways(monkeypatch, lambda: gpu_tensor(it), lambda t: t.round_tt(**kw))
+    assert used == 1 and all(torch.equal(x, y) for x, y in zip(a, b))
+    monkeypatch.setenv("TTR_EPS_DEFERRED", "0")          # the bond-by-bond sweep (one rank readback per bond): same train
+    t = gpu_tensor(it); t.round_tt(**kw)
+    assert ranks(to_list(t.cores)) == ranks(to_list(a)) and tt_rel_err(to_list(t.cores), to_list(a)) <= 1e-5
+    ref = oracle.round_tt([c.clone() for c in it], algorithm="svd", **kw)
+    ours = to_list(a)
+    assert ranks(ours) == ranks(ref) == [1] + [32] * 7 + [1]
+    assert tt_rel_err(ours, ref) <= 1e-5 and tt_rel_err(ours, it) <= 1e-5 and _right_orth_err(ours) <= 5e-5
+    so, sr = oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)
+    assert all(((x - y).abs().max() / y.max()).item() <= 1e-5 for x, y in zip(so, sr))
+
+
 def test_whole_sweep_entry_declines_what_it_does_not_cover(monkeypatch):
     """Outside ttr_round_tt's envelope (TT ranks above a TSQR panel, bonds with more rows than columns) the planner returns
     TTR_E_UNSUPPORTED and the host loop runs -- same results as ever; zero batches keep the batch-mode zero guard."""
@@ -1436,7 +1458,7 @@ def test_top_r_first_pass_on_the_metric_shape(monkeypatch):
     monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (spies on the host loop's per-kernel calls)
     calls = []
     orig = _hip.eigh_top
-    monkeypatch.setattr(_hip, "eigh_top", lambda *a: calls.append(orig(*a)) or calls[-1])
+    monkeypatch.setattr(_hip, "eigh_top", lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1])
     res = {}
     for on in (True, False):
         monkeypatch.setattr(_hipops, "EIGH_TOP_ENABLED", on)

@@ -589,8 +589,10 @@ def truncate(
         if algorithm == "eig":
             st.lap("Time (gram):")
         if algorithm == "svd":
-            if ((batch or delta2_dev is not None) and EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0 and rmax is not None
-                    and _hip.eigh_top_ok(k, _rank_cap(rmax, k))):
+            # r of the top-r launch: the rank cap in batch mode; in eps mode (any non-batch call) min(cap, 32) -- with `need_all`
+            # the top-r path then only serves the 32 x 32 zero-tail problems of packed bonds, whose whole spectrum that is
+            r_top = _rank_cap(rmax, k) if batch else min(_rank_cap(rmax, k), 32)
+            if ((rmax is not None or not batch) and EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0 and _hip.eigh_top_ok(k, r_top)):
                 # only the rmax largest eigenpairs matter when the kept spectrum is flat: multisection + twisted factorisations
                 # instead of the QL iteration over the whole spectrum, decided per item inside the launch (flat kept spectrum
                 # without close pairs; the others fall through to the QL phase).  Such items carry zeros beyond column / entry
@@ -598,7 +600,7 @@ def truncate(
                 # (the deferred eps-mode sweep, round 5: its rank rule needs EVERY sigma, so the top-r path only takes the items of
                 # which it computes every eigenpair -- the 32 x 32 zero-tail problems of a packed bond under a cap >= 32: 47 instead
                 # of ~100 us per bond of one 64^8 train; its flags are not the pass-through flags there)
-                V1, sig1, _, top_flat = _hip.eigh_top(G, _rank_cap(rmax, k), FLAT_SPECTRUM_THR, need_all=not batch)
+                V1, sig1, _, top_flat = _hip.eigh_top(G, r_top, FLAT_SPECTRUM_THR, need_all=not batch)
                 if not batch:
                     top_flat = None
             else:

@@ -307,9 +307,11 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
     const void* V1p = nullptr;
     if (svd) {
       const int32_t* flat = nullptr;
-      if (use_eigh_top && flat_thr > 0.0 && rcap_mu < kNoCap && ttr_eigh_top_ok(R, cap)) {
+      // r of the top-r launch: the cap in batch mode (only with a cap), min(cap, 32) in eps mode (see _hipops.truncate)
+      const int64_t r_top = eps_mode ? (cap < 32 ? cap : 32) : cap;
+      if (use_eigh_top && flat_thr > 0.0 && (eps_mode || rcap_mu < kNoCap) && ttr_eigh_top_ok(R, r_top)) {
         // (eps mode: need_all -- the top-r path only where it computes every eigenpair; the certified flat test follows)
-        TTR_TRY(ttr_eigh_top(dt, R, B, G, R, parts * R * R, parts, R * R, V1, R, R * R, sig1, R, info1, cap, flat_thr, flatb,
+        TTR_TRY(ttr_eigh_top(dt, R, B, G, R, parts * R * R, parts, R * R, V1, R, R * R, sig1, R, info1, r_top, flat_thr, flatb,
                              eps_mode ? 1 : 0, st));
         if (eps_mode) {
           TTR_TRY(ttr_spectrum_flat(dt, R, B, sig1, R, cap, flat_thr, 1, 0.0, d2dev, flatb, r32, st));
