@@ -758,6 +758,9 @@ def main():
                 # parity check's LAPACK threads winding down -- moved the figure by 50 % between otherwise identical runs)
                 el = min(timed_steps(sstep, lambda: None, torch.cuda.synchronize, 3, st)[0] for _ in range(3))
                 extras[label] = {"tensors_per_step": Bx, "ms_per_step": el / st * 1e3, "cores_per_s": Bx * N_CORES * st / el}
+            # (nothing of the small-batch runs may stay alive: a 1 MB core of `small` pins the multi-GB segment the caching allocator
+            # carved it from, and config C1 at 64^6 needs all but 5 GiB of the device -- round 5's first B = 4096 run fell back to 48 x 64^5)
+            small = sstep = None
             for Bo in (2048,):
                 # other resident batches: what rounds 1-4 reported (2048: the launches' tails weigh more)
                 if Bo == B or B != 4096:
