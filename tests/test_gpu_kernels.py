@@ -736,14 +736,60 @@ def test_orth_fixup(dt, columns):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [1024, 1500])
+def test_orth_fixup_split_rounds_special_vectors(dt, n):
+    """The three-launch rounds of ttr_orth_fixup (large batches; forced here with TTR_KNOB_ORTH_SPLIT = 1): an untouched item, noisy
+    dead vectors, a dead vector inside the span of the others, a zero one, one with NaN entries, a scaled one -- orthonormal
+    results, live vectors bit-identical, the same vectors as the single-launch kernel where the remainders are genuine."""
+    h = _hip()
+    g = torch.Generator().manual_seed(31 + n)
+    B, r = 5, 12
+    Q = torch.linalg.qr(torch.randn(B, n, r, generator=g, dtype=torch.float64))[0].transpose(1, 2).contiguous()
+    sig = torch.ones(B, r, dtype=torch.float64) * torch.linspace(1, 0.5, r, dtype=torch.float64)
+    X = Q.clone()
+    sig[1, 9:] = 1e-12
+    X[1, 9:] = X[1, 9:] * 3.0 + 0.3 * X[1, :3] + 0.2 * torch.randn(3, n, generator=g, dtype=torch.float64)
+    sig[2, 8:] = 0.0
+    X[2, 8] = X[2, 0] - 2 * X[2, 3]
+    X[2, 9] = 0
+    X[2, 10] = float("nan")
+    X[2, 11] = 5 * X[2, 11]
+    sig[3, 11] = 1e-9
+    sig[4, 4:] = 1e-10                                   # most vectors dead, mostly leakage of the live ones: needs the second round
+    X[4, 4:] = 0.1 * X[4, 4:] + X[4, :4].sum(dim=0, keepdim=True)
+    Xd = X.to(dt).cuda()
+    before = Xd.clone()
+    sg = sig.to(dt).cuda()
+    assert h.lib().ttr_orth_fixup_workspace_bytes(h.dtype_code(dt), r, n, B, 1) == 0            # default threshold: single launch
+    mono = before.clone()
+    h.orth_fixup(mono, sg, r, 1e-6)
+    h.set_knob(h.KNOB_ORTH_SPLIT, 1)
+    assert h.lib().ttr_orth_fixup_workspace_bytes(h.dtype_code(dt), r, n, B, 1) > 0
+    h.orth_fixup(Xd, sg, r, 1e-6)
+    out = Xd.cpu().double()
+    eye = torch.eye(r, dtype=torch.float64)
+    t = tol(dt, 2e-6, 1e-13)
+    for b in range(B):
+        assert torch.isfinite(out[b]).all() and (out[b] @ out[b].T - eye).abs().max() < t, b
+    assert torch.equal(Xd[0], before[0]) and torch.equal(Xd[1, :9], before[1, :9]) and torch.equal(Xd[4, :4], before[4, :4])
+    for b in (1, 3, 4):                                  # genuine remainders: the same vectors as the single-launch kernel
+        assert (Xd[b] - mono[b]).abs().max().item() < tol(dt, 2e-5, 1e-11), b
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("r,n,first", [(32, 2048, 17), (64, 4096, 1), (30, 777, 29), (7, 50, 0), (70, 500, 40), (32, 1000, 5), (20, 300, 0),
                                        (16, 4096, 9)])
-def test_orth_fixup_many_dead(dt, r, n, first):
+def test_orth_fixup_many_dead(dt, r, n, first, split):
     """Most of the kept vectors below the resolution (a rank-64 bond with sigma_j ~ 2^-j: SURVEY 8d's decaying variant of the
     metric): the block kernel (r <= 64; Gram matrix + Gram-Schmidt in coefficient space) and the sequential one (r = 70) leave
     every vector orthonormal, the live ones bit-identical, and the dead ones inside span(their own old value, earlier vectors)
     where that remainder was genuine."""
     h = _hip()
+    if split:   # the three-launch rounds (large batches), forced on this small one; shapes it does not cover keep the single launch
+        if r > 64 or n < 512:
+            pytest.skip("outside the split path's envelope")
+        h.set_knob(h.KNOB_ORTH_SPLIT, 1)
     g = torch.Generator().manual_seed(r * 1000 + n)
     B = 3
     Q = torch.linalg.qr(torch.randn(B, n, r, generator=g, dtype=torch.float64))[0].transpose(1, 2).contiguous()  # [B, r, n]
@@ -767,7 +813,7 @@ def test_orth_fixup_many_dead(dt, r, n, first):
     rem = old - prev.T @ (prev @ old)
     rem = rem / rem.norm()
     assert (out[0, first] - rem).abs().max() < tol(dt, 5e-6, 1e-12)
-    if r <= 32 and dt == torch.float32:
+    if r <= 32 and dt == torch.float32 and not split:
         # round 5's inner loops (TTR_KNOB_ORTH_V2, the default) against round 4's on the same input: another summation order of the
         # same sums -- the same vectors to rounding
         h.set_knob(h.KNOB_ORTH_V2, 0)

@@ -151,9 +151,11 @@ _SIGNATURES = {
         c_int,
         [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     ),
+    "ttr_orth_fixup_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "ttr_orth_fixup": (
         c_int,
-        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p, c_void_p],
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p,
+         c_void_p, c_int64, c_void_p],
     ),
     "ttr_norm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "ttr_scale_cols": (
@@ -982,8 +984,11 @@ def orth_fixup(X: torch.Tensor, sigma: torch.Tensor, r: int, dead_rel: float, co
         assert X.shape[1] == r
     if batch == 0 or r == 0 or n == 0:
         return
+    wsb = int(L.ttr_orth_fixup_workspace_bytes(dt, r, n, batch, es))   # > 0: a large batch, three launches per round
+    ws = torch.empty(wsb, dtype=torch.uint8, device=X.device) if wsb > 0 else None
     _check(L.ttr_orth_fixup(dt, r, n, batch, X.data_ptr(), vs, es, X.shape[1] * X.shape[2], sigma.data_ptr(),
-                            sigma.shape[-1], float(dead_rel), rank_dev.data_ptr() if rank_dev is not None else None, _stream()),
+                            sigma.shape[-1], float(dead_rel), rank_dev.data_ptr() if rank_dev is not None else None,
+                            ws.data_ptr() if ws is not None else None, wsb, _stream()),
            "ttr_orth_fixup")
 
 
@@ -1042,6 +1047,7 @@ KNOB_JACOBI_LIVE_WAVE = 11
 KNOB_ORTH_V2 = 12
 KNOB_QR_INTERLEAVE = 13
 KNOB_SWEEP_STAGGER = 14
+KNOB_ORTH_SPLIT = 15
 
 
 ALG_SVD, ALG_EIG = 0, 1

@@ -708,6 +708,249 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ttr_orth_fixup for LARGE batches (round 5): the same rounds -- Gram matrix, coefficients, X_dead <- W X -- as three launches per
+// round instead of one workgroup per item.  Why: the single-workgroup kernel above keeps one 32 KB chunk in flight per workgroup
+// and walks an item's 256 KB four times; even with the staggered chunk order a pass costs 8 us per chunk (cycle stamps,
+// profiles/r05_orth_stamps.txt), i.e. ~2 TB/s chip-wide.  The Gram pass IS ttr_rowgram on the r x n matrix of vectors (split-K
+// partials, 16-byte loads, two slabs in flight per wave: 4 TB/s class), and the apply pass is a streaming kernel of the same
+// build (below).  Per-item control flow lives in flag arrays: skip[round][b] != 0 = item b takes no part in that round.
+// Small batches keep the single launch (three launches per round and bond would add ~40 dependent launches to a B = 1 call).
+struct OrthSplitWs {
+  int64_t off_g, off_w, off_regen, off_skip, total;
+  int parts;
+};
+static OrthSplitWs orth_split_layout(int64_t r, int64_t n, int64_t batch, int64_t es, int max_rounds) {
+  OrthSplitWs w{};
+  const int64_t r4 = (r + 15) & ~15LL;
+  w.parts = n >= 2048 ? 4 : (n >= 1024 ? 2 : 1);   // short fp32 accumulation chains: the partials are summed in double
+  int64_t off = 0;
+  w.off_g = off; off += align_up(batch * w.parts * r * r * es, 256);
+  w.off_w = off; off += align_up(batch * r4 * r4 * es, 256);
+  w.off_regen = off; off += align_up(batch * 8, 256);                       // one 64-bit mask per item
+  w.off_skip = off; off += align_up((int64_t)(max_rounds + 1) * batch * 4, 256);
+  w.total = off;
+  return w;
+}
+
+template <typename T>
+__global__ void orth_init_kernel(int r, int64_t batch, const T* __restrict__ sigma, int64_t stride_sigma, double dead_rel,
+                                 const int32_t* __restrict__ rank_dev, int32_t* __restrict__ skip0) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  if (rank_dev) r = rank_dev[b] < r ? rank_dev[b] : r;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const double s0 = (double)sg[0];
+  int first = r;
+  for (int i = 0; i < r; ++i)
+    if (!((double)sg[i] > dead_rel * s0)) { first = i; break; }
+  skip0[b] = first >= r ? 1 : 0;
+}
+
+// Coefficients of one round (the middle section of orth_fixup_block_kernel, verbatim): S = sum of the Gram partials (double),
+// Cholesky of the dead rows' Schur complement, W_D = L^-1 [-S_DL, I].  Writes W (matrix precision), the regeneration mask and
+// the next round's skip flag.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void orth_coef_kernel(int r, const T* __restrict__ Gp, int parts, T* __restrict__ Wg,
+                                                             unsigned long long* __restrict__ regen_mask, const int32_t* __restrict__ skip_now,
+                                                             int32_t* __restrict__ skip_next, const T* __restrict__ sigma,
+                                                             int64_t stride_sigma, double dead_rel, const int32_t* __restrict__ rank_dev,
+                                                             int round, double* __restrict__ census) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char oc_smem[];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (skip_now[b] != 0) { if (tid == 0) skip_next[b] = 1; return; }
+  const int r_launch = r;
+  if (rank_dev) r = rank_dev[b] < r ? rank_dev[b] : r;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const double s0 = (double)sg[0];
+  int first = r;
+  for (int i = 0; i < r; ++i)
+    if (!((double)sg[i] > dead_rel * s0)) { first = i; break; }
+  const int r4 = (r_launch + 15) & ~15;
+  const int ls = r4 + 1;
+  double* S = reinterpret_cast<double*>(oc_smem);   // [r4][ls]
+  double* W = S + (size_t)r4 * ls;
+  int* regen = reinterpret_cast<int*>(W + (size_t)r4 * ls);   // [64]
+  int* any_regen = regen + 64;
+  if (census && tid == 0) {
+    if (round == 0) atomicAdd(census + TTR_PROF_NKINDS + TTR_PROF_MISC, 1.0);
+    atomicAdd(census + TTR_PROF_MISC, 1.0);
+  }
+  const T* __restrict__ G = Gp + b * (int64_t)parts * r_launch * r_launch;
+  for (int idx = tid; idx < r4 * r4; idx += kThreads) {
+    const int i = idx / r4, j = idx - i * r4;
+    double v = 0.0;
+    if (i < r_launch && j < r_launch)
+      for (int pt = 0; pt < parts; ++pt) v += (double)G[(int64_t)pt * r_launch * r_launch + i * r_launch + j];
+    S[i * ls + j] = v;
+  }
+  if (tid < 64) regen[tid] = 0;
+  if (tid == 0) { any_regen[0] = 0; any_regen[1] = 0; }
+  __syncthreads();
+  // a dead vector with a non-finite entry has a non-finite diagonal: it counts as the zero vector (replaced below); its row and
+  // column must not poison the others (the single-launch kernel zeroes such entries when it stages the vectors)
+  for (int d = first; d < r; ++d) {
+    const double sdd = S[d * ls + d];
+    if (!(sdd - sdd == 0.0)) {
+      __syncthreads();
+      for (int k = tid; k < r4; k += kThreads) { S[d * ls + k] = 0.0; S[k * ls + d] = 0.0; }
+      __syncthreads();
+    }
+  }
+  for (int idx = tid; idx < (r - first) * r4; idx += kThreads) {   // (other non-finite entries of dead rows: treated as zero)
+    const int d = first + idx / r4, k = idx % r4;
+    const double v = S[d * ls + k];
+    if (!(v - v == 0.0)) { S[d * ls + k] = 0.0; S[k * ls + d] = 0.0; }
+  }
+  __syncthreads();
+  const int nd = r - first;
+  double* Cm = W;
+  for (int idx = tid; idx < nd * nd; idx += kThreads) {
+    const int ia = idx / nd, ib = idx - ia * nd;
+    const double* __restrict__ sa = S + (size_t)(first + ia) * ls;
+    const double* __restrict__ sb = S + (size_t)(first + ib) * ls;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+    int k = 0;
+    for (; k + 3 < first; k += 4) { c0 += sa[k] * sb[k]; c1 += sa[k + 1] * sb[k + 1]; c2 += sa[k + 2] * sb[k + 2]; c3 += sa[k + 3] * sb[k + 3]; }
+    for (; k < first; ++k) c0 += sa[k] * sb[k];
+    Cm[ia * ls + ib] = sa[first + ib] - ((c0 + c1) + (c2 + c3));
+  }
+  __syncthreads();
+  for (int a = 0; a < nd; ++a) {
+    const double piv = Cm[a * ls + a], saa = S[(first + a) * ls + first + a];
+    const bool bad = !(saa > 0.0) || !(saa < 1e300) || !(piv > 1e-4 * saa);
+    const double dinv = bad ? 0.0 : 1.0 / sqrt(piv);
+    __syncthreads();
+    if (tid > a && tid < nd) Cm[tid * ls + a] *= dinv;
+    if (tid == a) Cm[a * ls + a] = bad ? 1.0 : piv * dinv;
+    if (tid == 0 && bad) { regen[first + a] = 1; any_regen[0] = 1; }
+    if (tid == 0 && !(piv > 0.5 * saa)) any_regen[1] = 1;
+    __syncthreads();
+    if (!bad) {
+      const int rem = nd - a - 1;
+      for (int idx = tid; idx < rem * rem; idx += kThreads) {
+        const int i = a + 1 + idx / rem, j = a + 1 + idx % rem;
+        if (j <= i) Cm[i * ls + j] -= Cm[i * ls + a] * Cm[j * ls + a];
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nd * r4; idx += kThreads) {
+    const int ia = idx / r4, k = idx - ia * r4;
+    double* __restrict__ zr = S + (size_t)(first + ia) * ls;
+    zr[k] = k < first ? -zr[k] : (k == first + ia ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int a = 0; a < nd; ++a) {
+    if (tid < r4) {
+      double* __restrict__ za = S + (size_t)(first + a) * ls;
+      double w = 0.0;
+      if (!regen[first + a]) {
+        double w0 = za[tid], w1 = 0.0, w2 = 0.0, w3 = 0.0;
+        const double* __restrict__ la = Cm + (size_t)a * ls;
+        int bq = 0;
+        for (; bq + 3 < a; bq += 4) {
+          w0 -= la[bq] * S[(size_t)(first + bq) * ls + tid];
+          w1 -= la[bq + 1] * S[(size_t)(first + bq + 1) * ls + tid];
+          w2 -= la[bq + 2] * S[(size_t)(first + bq + 2) * ls + tid];
+          w3 -= la[bq + 3] * S[(size_t)(first + bq + 3) * ls + tid];
+        }
+        for (; bq < a; ++bq) w0 -= la[bq] * S[(size_t)(first + bq) * ls + tid];
+        w = ((w0 + w1) + (w2 + w3)) / la[a];
+      }
+      za[tid] = w;
+    }
+    __syncthreads();
+  }
+  // W_D in the matrix precision (rows below `first` are never applied: zero), mask, next round's flag
+  T* __restrict__ Wb = Wg + b * (int64_t)r4 * r4;
+  for (int idx = tid; idx < r4 * r4; idx += kThreads) {
+    const int i = idx / r4, k = idx - i * r4;
+    Wb[idx] = (i >= first && i < r) ? (T)S[(size_t)i * ls + k] : T(0);
+  }
+  if (tid == 0) {
+    unsigned long long m = 0ull;
+    for (int d = first; d < r; ++d) if (regen[d]) m |= 1ull << d;
+    regen_mask[b] = m;
+    skip_next[b] = (any_regen[0] || (round == 0 && any_regen[1])) ? 0 : 1;
+  }
+}
+
+// X_dead <- W X, streamed: grid (column splits, items); a wave walks 16-column slabs (every item starts at another slab: the
+// columns are independent), the vectors of a slab are the B operand straight from global memory (four 64-byte row segments per
+// load, the next slab's loads in flight under this slab's products), W is the A operand from an LDS image.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void orth_apply_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t strideX,
+                                                              const T* __restrict__ Wg, const unsigned long long* __restrict__ regen_mask,
+                                                              const int32_t* __restrict__ skip_now, const T* __restrict__ sigma,
+                                                              int64_t stride_sigma, double dead_rel, const int32_t* __restrict__ rank_dev,
+                                                              int round, int nsplit) {
+  using M = Mfma<T>;
+  __shared__ T Wl[64 * 65];
+  const int64_t b = blockIdx.y;
+  if (skip_now[b] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
+  const int r_launch = r;
+  if (rank_dev) r = rank_dev[b] < r ? rank_dev[b] : r;
+  const T* __restrict__ sg = sigma + b * stride_sigma;
+  const double s0 = (double)sg[0];
+  int first = r;
+  for (int i = 0; i < r; ++i)
+    if (!((double)sg[i] > dead_rel * s0)) { first = i; break; }
+  const int r4 = (r_launch + 15) & ~15;
+  const int nt = (r + 15) >> 4, it0 = first >> 4;
+  const T* __restrict__ Wb = Wg + b * (int64_t)r4 * r4;
+  for (int idx = tid; idx < r4 * r4; idx += kThreads) Wl[(idx / r4) * 65 + idx % r4] = Wb[idx];
+  const unsigned long long rm = regen_mask[b];
+  __syncthreads();
+  T* __restrict__ Xb = X + b * strideX;
+  const int64_t slabs = (n + 15) / 16, per = (slabs + nsplit - 1) / nsplit;
+  const int64_t cb = (int64_t)blockIdx.x * per, ce = cb + per < slabs ? cb + per : slabs;
+  const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
+  const int64_t rot = nsteps > 1 ? (int64_t)(b % nsteps) : 0;
+  auto step_c = [&](int64_t sidx) { int64_t sq = sidx + rot; if (sq >= nsteps) sq -= nsteps; return cb + wave + 4 * sq; };
+  const int nks = r4 >> 2;
+  auto load_cols = [&](int64_t c, T (&a)[16]) {
+    const int64_t col = c * 16 + cl;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + g;
+      T v = (ks < nks && k < r_launch && col < n) ? Xb[(int64_t)k * vs + col] : T(0);
+      a[ks] = (v - v == T(0)) ? v : T(0);   // (non-finite entries of a dead vector count as zero)
+    }
+  };
+  T a[16], an[16];
+  if (nsteps > 0) load_cols(step_c(0), a);
+  for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
+    const int64_t c = step_c(sidx);
+    if (sidx + 1 < nsteps) load_cols(step_c(sidx + 1), an);
+    for (int it = it0; it < nt; ++it) {
+      typename M::Acc acc = M::zero();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        if (ks < nks) acc = M::mma(Wl[(16 * it + cl) * 65 + 4 * ks + g], a[ks], acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d = 16 * it + M::row(lane, u);
+        const int64_t col = c * 16 + cl;
+        if (d < first || d >= r || col >= n) continue;
+        T out = acc[u];
+        if ((rm >> d) & 1ull) {
+          uint32_t h = (uint32_t)(col * 2654435761u) ^ (uint32_t)((d + 1) * 40503u) ^ (uint32_t)((round + 1) * 97u);
+          h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+          out = (T)((double)(h >> 8) * (1.0 / 8388608.0) - 1.0);
+        }
+        Xb[(int64_t)d * vs + col] = out;
+      }
+    }
+    if (sidx + 1 < nsteps) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) a[ks] = an[ks];
+    }
+  }
+}
+
 // implemented in the other translation units
 int gemm_dispatch(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   int64_t strideA, const void* B, int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC,
@@ -807,6 +1050,54 @@ static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 }  // namespace ttr
 
 using namespace ttr;
+
+static int g_orth_rounds = 4;   // ttr_debug_set_knob(TTR_KNOB_ORTH_ROUNDS): rounds of the block orthonormal completion (diagnostics)
+static int g_orth_v2 = 1;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2, 0): round 4's inner loops (A/B)
+static int g_orth_split = 256;   // ttr_debug_set_knob(TTR_KNOB_ORTH_SPLIT): batches from this size take the three-launch rounds (0 = never)
+
+// (vectors as rows of a row-major matrix, at most 64 of them, at least 512 elements each, a batch that fills the chip)
+static bool orth_split_ok(int64_t r, int64_t n, int64_t batch, int64_t elem_stride) {
+  return g_orth_split > 0 && batch >= g_orth_split && batch <= 65535 && elem_stride == 1 && r >= 2 && r <= 64 && n >= 512;
+}
+
+template <typename T>
+static int orth_split_run(int64_t r, int64_t n, int64_t batch, T* X, int64_t vs, int64_t strideX, const T* sigma, int64_t stride_sigma,
+                          double dead_rel, const int32_t* rank_dev, char* ws, hipStream_t s) {
+  const int dtype = sizeof(T) == 4 ? TTR_F32 : TTR_F64;
+  const OrthSplitWs L = orth_split_layout(r, n, batch, sizeof(T), g_orth_rounds);
+  T* G = (T*)(ws + L.off_g);
+  T* Wg = (T*)(ws + L.off_w);
+  unsigned long long* regen = (unsigned long long*)(ws + L.off_regen);
+  int32_t* skip = (int32_t*)(ws + L.off_skip);
+  double* census = work_census_on() ? g_work_dev : nullptr;
+  {
+    ProfScope prof(TTR_PROF_MISC, s);
+    hipLaunchKernelGGL(orth_init_kernel<T>, dim3((unsigned)ceil_div(batch, kThreads)), dim3(kThreads), 0, s, (int)r, batch, sigma, stride_sigma,
+                       dead_rel, rank_dev, skip);
+  }
+  const int r4 = ((int)r + 15) & ~15;
+  const size_t lds = 2 * (size_t)r4 * (r4 + 1) * 8 + 64 * 4 + 16;
+  int nsplit = (int)ceil_div(2048, batch);   // aim at >= 2048 workgroups, >= 8 slabs per wave
+  const int64_t slabs = (n + 15) / 16;
+  if (nsplit > slabs / 32) nsplit = (int)(slabs / 32);
+  if (nsplit < 1) nsplit = 1;
+  for (int round = 0; round < g_orth_rounds; ++round) {
+    const int32_t* sk = skip + (int64_t)round * batch;
+    TTR_HIP_CHECK(hipGetLastError());
+    const int rc = sweep_gram_dispatch(dtype, r, n, batch, X, vs, strideX, nullptr, 0, 0, G, L.parts, s, sk, nullptr);
+    if (rc != TTR_OK) return rc;
+    ProfScope prof(TTR_PROF_MISC, s);
+    auto kern = orth_coef_kernel<T>;
+    if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, (const T*)G, L.parts, Wg, regen, sk,
+                       skip + (int64_t)(round + 1) * batch, sigma, stride_sigma, dead_rel, rank_dev, round, census);
+    hipLaunchKernelGGL(orth_apply_kernel<T>, dim3((unsigned)nsplit, (unsigned)batch), dim3(kThreads), 0, s, (int)r, n, X, vs, strideX,
+                       (const T*)Wg, (const unsigned long long*)regen, sk, sigma, stride_sigma, dead_rel, rank_dev, round, nsplit);
+  }
+  TTR_HIP_CHECK(hipGetLastError());
+  return TTR_OK;
+}
+
 
 extern "C" {
 
@@ -1309,17 +1600,28 @@ int ttr_scale_batch(int dtype, int64_t count, int64_t batch, const void* x, int6
   return TTR_OK;
 }
 
-static int g_orth_v2 = 1;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2, 0): round 4's inner loops (A/B)
-static int g_orth_rounds = 4;   // ttr_debug_set_knob(TTR_KNOB_ORTH_ROUNDS): rounds of the block orthonormal completion (diagnostics)
+
+int64_t ttr_orth_fixup_workspace_bytes(int dtype, int64_t r, int64_t n, int64_t batch, int64_t elem_stride) {
+  if (!dtype_ok(dtype) || !orth_split_ok(r, n, batch, elem_stride)) return 0;
+  return orth_split_layout(r, n, batch, dtype == TTR_F32 ? 4 : 8, g_orth_rounds).total;
+}
 
 int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int64_t vec_stride, int64_t elem_stride,
                    int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
-                   void* stream) {
+                   void* workspace, int64_t workspace_bytes, void* stream) {
   TTR_REQUIRE(dtype_ok(dtype), TTR_E_INVALID, "ttr_orth_fixup: bad dtype %d", dtype);
   TTR_REQUIRE(r >= 0 && n >= 0 && batch >= 0 && r <= 2147483647LL, TTR_E_INVALID, "ttr_orth_fixup: bad sizes");
   if (batch == 0 || r == 0 || n == 0) return TTR_OK;
   TTR_REQUIRE(X && sigma, TTR_E_INVALID, "ttr_orth_fixup: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (workspace && orth_split_ok(r, n, batch, elem_stride) &&
+      workspace_bytes >= orth_split_layout(r, n, batch, dtype == TTR_F32 ? 4 : 8, g_orth_rounds).total) {
+    if (dtype == TTR_F32)
+      return orth_split_run<float>(r, n, batch, (float*)X, vec_stride, strideX, (const float*)sigma, stride_sigma, dead_rel, rank_dev,
+                                   (char*)workspace, s);
+    return orth_split_run<double>(r, n, batch, (double*)X, vec_stride, strideX, (const double*)sigma, stride_sigma, dead_rel, rank_dev,
+                                  (char*)workspace, s);
+  }
   ProfScope prof(TTR_PROF_MISC, s);
   if (r <= 64) {  // the block variant (Gram matrix + coefficient-space Gram-Schmidt + one small product per round)
     const int cw = r <= 32 ? 256 : 128;
@@ -1393,6 +1695,10 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_EIGH_SMALL:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
       g_eigh_small = value;
+      return TTR_OK;
+    case TTR_KNOB_ORTH_SPLIT:
+      TTR_REQUIRE(value >= 0 && value <= 65535, TTR_E_INVALID, "ttr_debug_set_knob: orth split threshold %d outside [0, 65535]", value);
+      g_orth_split = value;
       return TTR_OK;
     case TTR_KNOB_SWEEP_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: stagger mode %d outside [0, 2]", value);

@@ -36,7 +36,7 @@ struct SweepPlan {
   int64_t off_carry = 0, off_carryn = 0, off_expo = 0, off_escr = 0, off_r32 = 0;
   int64_t off_G = 0, off_G2 = 0, off_V1 = 0, off_V = 0, off_sig1 = 0, off_sig = 0, off_info1 = 0, off_info = 0, off_flat = 0;
   int64_t off_eigws = 0, eig_wsb = 0, off_gemmws = 0, gemm_wsb = 0;
-  int64_t off_M = 0, off_left[3] = {0, 0, 0}, off_d2 = 0, off_nrm = 0;
+  int64_t off_M = 0, off_left[3] = {0, 0, 0}, off_d2 = 0, off_nrm = 0, off_orth = 0, orth_wsb = 0;
   int64_t total = 0;
 };
 
@@ -105,6 +105,8 @@ int make_sweep_plan(int dtype, int64_t N, const int64_t* shapes, const int64_t* 
     if (batch * R * cap > maxleft) maxleft = batch * R * cap;
     const int64_t ew = ttr_eigh_workspace_bytes(dtype, R, batch);
     if (ew > p.eig_wsb) p.eig_wsb = ew;
+    const int64_t ow = ttr_orth_fixup_workspace_bytes(dtype, cap, n, batch, 1);
+    if (ow > p.orth_wsb) p.orth_wsb = ow;
     rq = cap;
   }
   // the carry M = R_{N-2} x (last core)
@@ -128,6 +130,7 @@ int make_sweep_plan(int dtype, int64_t N, const int64_t* shapes, const int64_t* 
   p.off_eigws = take(off, p.eig_wsb);
   p.off_M = take(off, maxM * p.es);
   for (int i = 0; i < 3; ++i) p.off_left[i] = take(off, maxleft * p.es);
+  p.off_orth = take(off, p.orth_wsb);
   p.off_d2 = take(off, 8);
   p.off_nrm = take(off, 4096 * 8);
   p.total = off;
@@ -343,7 +346,8 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
     TTR_TRY(ttr_project(dt, R, n, cap, B, M, n, R * n, V1p, R, R * R, V, R, R * R, sig, R, 1, cores_out[mu], n, cap * n, lnew, cap,
                         R * cap, r32, st));
     if (svd)
-      TTR_TRY(ttr_orth_fixup(dt, cap, n, B, cores_out[mu], n, 1, cap * n, sig, R, (double)R * epsT, eps_mode ? info : nullptr, st));
+      TTR_TRY(ttr_orth_fixup(dt, cap, n, B, cores_out[mu], n, 1, cap * n, sig, R, (double)R * epsT, eps_mode ? info : nullptr,
+                             p.orth_wsb > 0 ? (void*)(ws + p.off_orth) : nullptr, p.orth_wsb, st));
     if (eps_mode) TTR_TRY(ttr_mask_cols(dt, R, cap, B, lnew, cap, R * cap, info, st));
     left = lnew;
   }

@@ -19,10 +19,11 @@ inputs = {"g+g": bench.make_input(B, dev, seed=1234), "decay 1.0": bench.make_de
 for name, inp in inputs.items():
     def step():
         t = tn.Tensor(inp, batch=True); t.round_tt(rmax=32); return t
-    for il, ov, sg in ((1, 1, 1), (1, 1, 0), (1, 1, 2), (0, 0, 0)):
+    for il, ov, sg, sp in ((1, 1, 1, 256), (1, 1, 1, 0), (0, 0, 0, 0)):
         _hip.set_knob(_hip.KNOB_QR_INTERLEAVE, il)
         _hip.set_knob(_hip.KNOB_ORTH_V2, ov)
         _hip.set_knob(_hip.KNOB_SWEEP_STAGGER, sg)
+        _hip.set_knob(_hip.KNOB_ORTH_SPLIT, sp)
         _hipops.STREAM_CHUNKS_ENABLED = True
         for _ in range(3):
             step()
@@ -40,6 +41,6 @@ for name, inp in inputs.items():
         torch.cuda.synchronize()
         p = _hip.prof_collect()
         _hip.prof_enable(False)
-        print(f"{name} B={B} interleave={il} orth_v2={ov} stagger={sg}: step {wall:.2f} ms (two streams) = {B * 8 / wall * 1e3:.0f} cores/s; per kind ms/step: " +
+        print(f"{name} B={B} interleave={il} orth_v2={ov} stagger={sg} orth_split={sp}: step {wall:.2f} ms (two streams) = {B * 8 / wall * 1e3:.0f} cores/s; per kind ms/step: " +
               ", ".join(f"{k} {v['ms'] / 3:.2f}" for k, v in p.items() if v["launches"]))
-_hip.set_knob(_hip.KNOB_QR_INTERLEAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 1); _hip.set_knob(_hip.KNOB_SWEEP_STAGGER, 1)
+_hip.set_knob(_hip.KNOB_QR_INTERLEAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 1); _hip.set_knob(_hip.KNOB_SWEEP_STAGGER, 1); _hip.set_knob(_hip.KNOB_ORTH_SPLIT, 256)
