@@ -760,7 +760,7 @@ def test_orth_fixup_split_rounds_special_vectors(dt, n):
     Xd = X.to(dt).cuda()
     before = Xd.clone()
     sg = sig.to(dt).cuda()
-    assert h.lib().ttr_orth_fixup_workspace_bytes(h.dtype_code(dt), r, n, B, 1) == 0            # default threshold: single launch
+    assert h.lib().ttr_orth_fixup_workspace_bytes(h.dtype_code(dt), r, n, B, 1) == 0            # default: always the single launch
     mono = before.clone()
     h.orth_fixup(mono, sg, r, 1e-6)
     h.set_knob(h.KNOB_ORTH_SPLIT, 1)
