@@ -219,6 +219,8 @@ int ttr_qr_apply_pushed_gram(int dtype, int64_t k, int64_t I, int64_t n, int64_t
  * TTR_EIG_RAW / TTR_EIG_REF clamp negative eigenvalues: G is taken to be positive semi-definite up to rounding (a Gram matrix).  The
  * tridiagonal solver uses that for a 64 x 64 matrix whose diagonal is exactly zero from index 32 on (zero rows / columns: the
  * carry of a bond whose QR packed its rows): it is solved as its leading 32 x 32 block, V[b] = blockdiag(V11, I), sigma[b][32:] = 0.
+ * PRECONDITION of RAW / REF therefore: G is a Gram matrix (PSD up to rounding: G_ii = 0 implies a zero row).  A general symmetric
+ * matrix -- e.g. [[0, 1], [1, 0]] padded to 64 x 64 -- must be passed with TTR_EIG_MATCH_DIAG, which neither clamps nor shrinks.
  * The input may be given as `gparts` partial matrices (split-K partials of a Gram kernel, `stride_gpart` elements
  * apart): G[b] = sum_p G[b * strideG + p * stride_gpart + ...]; gparts = 1 for a plain matrix.
  */
