@@ -110,7 +110,7 @@ def decaying_parity(inp, out, item):
 def kernel_model():
     """Algorithmic work of every kernel kind PER TENSOR of the metric workload (float32): `flops` = the arithmetic the
     kernel's algorithm performs, `bytes` = what it must move given its interface (operands read once, results written
-    once, including the reflectors / T factors / R a factorisation leaves behind).  DESIGN.md section 6 derives them."""
+    once, including the reflectors / T factors / R a factorisation leaves behind).  DESIGN.md section 3 lists them."""
     s = 4
     n, I, Rr, ro = R_IN, MODE, R_IN, R_OUT
     mid = N_CORES - 2                                  # cores 1..6: pushed 4096 x 64 factorisations
@@ -533,7 +533,7 @@ def main():
     ap.add_argument("--gather", default=os.environ.get("TTR_BENCH_GATHER", "end"), choices=["end", "step", "none"],
                     help="N > 1: `end` (default; north_star: 'a single RCCL gather over xGMI at the end') = ONE gather of the last "
                          "step's rounded cores after the last timed step, inside the timed region; `step` = every step's result is "
-                         "gathered on rank 0 (asynchronously, under the next step's compute: link-bound at 8 GPUs, DESIGN section 6); "
+                         "gathered on rank 0 (asynchronously, under the next step's compute: link-bound at 8 GPUs, DESIGN section 9); "
                          "`none` = no gather (compute-only scaling)")
     ap.add_argument("--single-stream", action="store_true",
                     help="issue the timed region on one stream too (for rocprofv3 kernel traces: with sub-batch "

@@ -762,7 +762,7 @@ def test_rank_cap_above_the_numerical_rank_of_a_packed_train(batch):
     else:
         # round.py:147-158 with delta = 0 cuts singular values that are EXACTLY zero.  The oracle's LAPACK returns 1e-7-level
         # noise for the 16 null directions and keeps them (rank 48); here they are exact zeros (zero-tail Gram matrix) and
-        # the same rule cuts them: the numerical rank, never more than the reference's (DESIGN section 6)
+        # the same rule cuts them: the numerical rank, never more than the reference's (DESIGN section 7 (viii))
         assert all(32 <= r <= 48 for r in ranks(ref)[1:-1]) and ranks(ours) == [1] + [32] * (N - 1) + [1]   # (oracle: 48 where LAPACK's noise is nonzero)
     assert tt_rel_err(ours, it) <= 2e-5
     assert _right_orth_err(ours) <= 5e-5
