@@ -811,18 +811,6 @@ def main():
                     ent["dominant"] = {"kernel": dk, "ms": pkr[dk]["ms_per_step"], "bound": pkr[dk].get("bound"), "frac": pkr[dk].get("frac")}
                     ent["oracle_check"] = decaying_parity(dinp, dout, 0)
                     extras[f"decaying_spectrum_{decay}"] = ent
-                    if decay == 1.0:
-                        # the opt-in three-launch rounds of ttr_orth_fixup (TTR_ORTH_SPLIT: faster where most kept directions lie
-                        # below the resolution -- this input --, slower where none does -- the headline): same input, same checks
-                        _hip.set_knob(_hip.KNOB_ORTH_SPLIT, 256)
-                        try:
-                            el2, dout2, _ = timed_steps(dstep, lambda: None, torch.cuda.synchronize, 2, 5)
-                            extras["decaying_spectrum_1.0_orth_split"] = {
-                                "tensors_per_step": B, "knob": "TTR_ORTH_SPLIT=256 (opt-in)", "ms_per_step": el2 / 5 * 1e3,
-                                "cores_per_s": B * N_CORES * 5 / el2, "oracle_check": decaying_parity(dinp, dout2, 0)}
-                            del dout2
-                        finally:
-                            _hip.set_knob(_hip.KNOB_ORTH_SPLIT, int(os.environ.get("TTR_ORTH_SPLIT", "0") or 0))
                     del dinp, dout, dstep   # (the closure's default argument holds the input too)
                 except Exception as e:  # noqa: BLE001
                     extras[f"decaying_spectrum_{decay}"] = {"error": repr(e)[:300]}

@@ -486,7 +486,7 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
                    int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
                    void* workspace, int64_t workspace_bytes, void* stream);
 /* `workspace` (ABI 10; may be NULL): with ttr_orth_fixup_workspace_bytes(...) > 0 bytes of it, a LARGE batch (>=
- * TTR_KNOB_ORTH_SPLIT items, opt-in; vectors as rows, <= 64 of them) runs every round as three launches -- the Gram matrix by
+ * TTR_KNOB_ORTH_SPLIT items, default 2048; vectors as rows, <= 64 of them) runs every round as three launches -- the Gram matrix by
  * ttr_rowgram's kernel (split-K partials summed in double), the coefficients, the streamed product X_dead <- W X -- instead of
  * one workgroup per item: same rounds, same semantics (a vector with non-finite entries counts as the zero vector), ~2x the HBM
  * rate.  Without it (or below the threshold) the single-launch kernel runs. */
@@ -605,9 +605,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      (independent columns: bit-identical results); 2 = ttr_rowgram / ttr_rotgram as well (their sums are then
  *                      accumulated in an item-dependent order); 0 = in order (A/B). */
 #define TTR_KNOB_SWEEP_STAGGER 14
-/*   TTR_KNOB_ORTH_SPLIT  batch size from which ttr_orth_fixup (given a workspace) runs its rounds as three launches; 0 (default) =
- *                      always the single-launch kernel.  Opt-in: 2.4 ms per 2048-train step faster where most kept directions lie
- *                      below the resolution (sigma ~ 2^-j), 0.27 ms slower where none does (13 launches per bond exit at once). */
+/*   TTR_KNOB_ORTH_SPLIT  batch size (per launch) from which ttr_orth_fixup, given a workspace, runs its rounds as three launches
+ *                      (default 2048; 0 = always the single-launch kernel): 13 % on a 4096-train step whose kept directions mostly
+ *                      lie below the resolution (sigma ~ 2^-j), nothing measurable on one without dead directions at that size
+ *                      (the launches that exit at once cost 0.3 - 2 % at 1024 items: hence the threshold). */
 #define TTR_KNOB_ORTH_SPLIT 15
 /*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed

@@ -932,7 +932,7 @@ def test_decaying_spectrum_eps(dt, eps, decay):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
-@pytest.mark.parametrize("decay", [0.5, 1.0])
+@pytest.mark.parametrize("decay", [0.5, 1.0, -1.0])
 def test_decaying_spectrum_metric_shape(dt, decay):
     """The decaying-spectrum variant at (a slice of) the metric's shape: cores [64, 64, 64], 64^5, rank 64 -> 32,
     sigma_j ~ 2^(-j/2) (sigma_31 / sigma_0 = 2e-5, sigma_63 / sigma_0 = 3e-10), batch of 2, vs the float64 oracle.
@@ -941,9 +941,24 @@ def test_decaying_spectrum_metric_shape(dt, decay):
     (round 4: NaN, then rank-1 zeros by the zero guard; now H = I for sub-columns below 2^-50 of their block), and 15 of the 32
     kept directions of every bond lie below the resolution of the input (orthonormal completion)."""
     f32 = dt == torch.float32
-    inp = _decaying_tt([64] * 5, 64, decay, dt, seed=5, batch=2)
-    t = gpu_tensor(inp, batch=True)
-    t.round_tt(rmax=32)
+    if decay < 0:
+        # decay -1 = decay 1 with ttr_orth_fixup's three-launch rounds (what batches from TTR_KNOB_ORTH_SPLIT = 2048 items per
+        # stream take by default), forced on this batch of 2: the same bounds; through ttr_round_tt and through the host loop
+        from tntorch_amd import _hip, _hipops
+        decay = 1.0
+        _hip.set_knob(_hip.KNOB_ORTH_SPLIT, 1)
+        inp = _decaying_tt([64] * 5, 64, decay, dt, seed=5, batch=2)
+        _hipops.SWEEP_C_ENABLED = False
+        th = gpu_tensor(inp, batch=True)
+        th.round_tt(rmax=32)
+        _hipops.SWEEP_C_ENABLED = True
+        t = gpu_tensor(inp, batch=True)
+        t.round_tt(rmax=32)
+        assert all(torch.equal(a, b) for a, b in zip(t.cores, th.cores))
+    else:
+        inp = _decaying_tt([64] * 5, 64, decay, dt, seed=5, batch=2)
+        t = gpu_tensor(inp, batch=True)
+        t.round_tt(rmax=32)
     for i in range(2):
         one = [c[i] for c in inp]
         ref = oracle.round_tt([c.double() for c in one], rmax=32, algorithm="svd")

@@ -216,7 +216,7 @@ def lib():
         if os.environ.get("TTR_STRICT_RANKS", "0") == "1":
             L.ttr_debug_set_knob(9, 1)
         # TTR_ORTH_SPLIT=<batch size>: ttr_orth_fixup's three-launch rounds from that batch size on (header: TTR_KNOB_ORTH_SPLIT)
-        if os.environ.get("TTR_ORTH_SPLIT", "0") not in ("", "0"):
+        if os.environ.get("TTR_ORTH_SPLIT", "") != "":
             L.ttr_debug_set_knob(15, int(os.environ["TTR_ORTH_SPLIT"]))
         _lib = L
     return _lib

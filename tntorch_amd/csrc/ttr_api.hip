@@ -1053,12 +1053,13 @@ using namespace ttr;
 
 static int g_orth_rounds = 4;   // ttr_debug_set_knob(TTR_KNOB_ORTH_ROUNDS): rounds of the block orthonormal completion (diagnostics)
 static int g_orth_v2 = 1;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2, 0): round 4's inner loops (A/B)
-// ttr_debug_set_knob(TTR_KNOB_ORTH_SPLIT): batches from this size take the three-launch rounds; 0 (default) = never.  OPT-IN: on a
-// batch whose spectra decay fast (15 of 32 kept directions of every item below the resolution) the rounds cost 6.0 instead of 8.4
-// ms/step at B = 2048 (step 26.6 -> 24.0 ms), but a batch WITHOUT dead directions pays for 13 launches per bond that exit at once
-// instead of one: the headline step 13.61 -> 13.88 ms (profiles/r05_orth_split_ab.txt).  Nothing on the host knows which case it
-// is without a readback, so the caller decides (tntorch_amd: TTR_ORTH_SPLIT=256).
-static int g_orth_split = 0;
+// ttr_debug_set_knob(TTR_KNOB_ORTH_SPLIT): batches from this size (per launch, i.e. per sub-batch stream) take the three-launch
+// rounds; 0 = never.  Where most kept directions lie below the resolution (sigma ~ 2^-j) the rounds cost 6.0 instead of 8.4 ms per
+// 2048-train step (B = 4096: step 50.4 -> 44.5 ms, 650 k -> 736 k cores/s); a batch WITHOUT dead directions pays for 13 launches
+// per bond that exit at once instead of one: nothing measurable from 2048 items per launch (headline at B = 4096, four
+// alternations: 25.515 vs 25.524 ms), 0.3 - 2 % at 1024 (profiles/r05_orth_split_ab.txt, r05_orth_split_headline_ab.txt) --
+// hence the threshold.
+static int g_orth_split = 2048;
 
 // (vectors as rows of a row-major matrix, at most 64 of them, at least 512 elements each, a batch that fills the chip)
 static bool orth_split_ok(int64_t r, int64_t n, int64_t batch, int64_t elem_stride) {
