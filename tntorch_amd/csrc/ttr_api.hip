@@ -430,8 +430,12 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
                                                                     int64_t strideX, const T* __restrict__ sigma,
                                                                     int64_t stride_sigma, double dead_rel,
                                                                     const int32_t* __restrict__ rank_dev, int max_rounds,
-                                                                    double* __restrict__ census, long long* __restrict__ dbg) {
+                                                                    double* __restrict__ census, long long* __restrict__ dbg,
+                                                                    const int32_t* __restrict__ skip_items, int round0) {
   constexpr int kOfLd = kOfCW + 4;
+  // (`skip_items` / `round0`: this launch finishes what the three-launch rounds left over -- items flagged done return at once, the
+  // others continue with round number round0, which only enters the hashed replacement vectors)
+  if (skip_items && skip_items[blockIdx.x] != 0) return;
   // (diagnostics, ttr_debug_set_qr_stamps with TTR_KNOB_QR_STAMP_BX = -1: item 0 stamps its phases -- start, then per round: Gram
   // pass done, coefficients done, apply pass done)
   int dbgi = 0;
@@ -501,8 +505,9 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
   const int nch = (int)((n + kOfCW - 1) / kOfCW);
   const int rot = V2 ? (int)(b % nch) : 0;
   auto chunk_c0 = [&](int tq) { int c = tq + rot; if (c >= nch) c -= nch; return (int64_t)c * kOfCW; };
-  if (census && tid == 0) atomicAdd(census + TTR_PROF_NKINDS + TTR_PROF_MISC, 1.0);   // census: items with dead rows ...
-  for (int round = 0; round < max_rounds; ++round) {
+  if (census && round0 == 0 && tid == 0) atomicAdd(census + TTR_PROF_NKINDS + TTR_PROF_MISC, 1.0);   // census: items with dead rows ...
+  if (round0 > 0) census = nullptr;   // (the item and its first rounds were counted by the three-launch rounds)
+  for (int round = round0; round < max_rounds; ++round) {
     if (census && tid == 0) atomicAdd(census + TTR_PROF_MISC, 1.0);                   // ... and the rounds they took
     // ---- S = X X^T on the matrix cores: wave w owns the 16-row tile w of S (all column tiles); fp32 accumulators are
     // flushed into double sums after every chunk (64 products per entry), fp64 accumulates in place
@@ -716,6 +721,7 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
 // partials, 16-byte loads, two slabs in flight per wave: 4 TB/s class), and the apply pass is a streaming kernel of the same
 // build (below).  Per-item control flow lives in flag arrays: skip[round][b] != 0 = item b takes no part in that round.
 // Small batches keep the single launch (three launches per round and bond would add ~40 dependent launches to a B = 1 call).
+constexpr int kOrthSplitRounds = 2;
 struct OrthSplitWs {
   int64_t off_g, off_w, off_regen, off_skip, total;
   int parts;
@@ -1087,7 +1093,11 @@ static int orth_split_run(int64_t r, int64_t n, int64_t batch, T* X, int64_t vs,
   const int64_t slabs = (n + 15) / 16;
   if (nsplit > slabs / 32) nsplit = (int)(slabs / 32);
   if (nsplit < 1) nsplit = 1;
-  for (int round = 0; round < g_orth_rounds; ++round) {
+  // Two rounds ("twice is enough"); what is left after them -- items whose remainders collapsed and were replaced by hashed
+  // vectors: rare -- is finished by the single-launch kernel (one launch that exits at once where nothing is left, instead of
+  // six more launches per bond that do).
+  const int nrounds = g_orth_rounds < kOrthSplitRounds ? g_orth_rounds : kOrthSplitRounds;
+  for (int round = 0; round < nrounds; ++round) {
     const int32_t* sk = skip + (int64_t)round * batch;
     TTR_HIP_CHECK(hipGetLastError());
     const int rc = sweep_gram_dispatch(dtype, r, n, batch, X, vs, strideX, nullptr, 0, 0, G, L.parts, s, sk, nullptr);
@@ -1620,13 +1630,20 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
   if (batch == 0 || r == 0 || n == 0) return TTR_OK;
   TTR_REQUIRE(X && sigma, TTR_E_INVALID, "ttr_orth_fixup: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  const int32_t* of_skip = nullptr;   // (set when the three-launch rounds ran first: what they left over goes to the single launch)
+  int of_round0 = 0;
   if (workspace && orth_split_ok(r, n, batch, elem_stride) &&
       workspace_bytes >= orth_split_layout(r, n, batch, dtype == TTR_F32 ? 4 : 8, g_orth_rounds).total) {
-    if (dtype == TTR_F32)
-      return orth_split_run<float>(r, n, batch, (float*)X, vec_stride, strideX, (const float*)sigma, stride_sigma, dead_rel, rank_dev,
-                                   (char*)workspace, s);
-    return orth_split_run<double>(r, n, batch, (double*)X, vec_stride, strideX, (const double*)sigma, stride_sigma, dead_rel, rank_dev,
-                                  (char*)workspace, s);
+    const int rc = dtype == TTR_F32
+                       ? orth_split_run<float>(r, n, batch, (float*)X, vec_stride, strideX, (const float*)sigma, stride_sigma, dead_rel,
+                                               rank_dev, (char*)workspace, s)
+                       : orth_split_run<double>(r, n, batch, (double*)X, vec_stride, strideX, (const double*)sigma, stride_sigma, dead_rel,
+                                                rank_dev, (char*)workspace, s);
+    if (rc != TTR_OK) return rc;
+    of_round0 = g_orth_rounds < kOrthSplitRounds ? g_orth_rounds : kOrthSplitRounds;
+    if (of_round0 >= g_orth_rounds) return TTR_OK;
+    of_skip = (const int32_t*)((char*)workspace + orth_split_layout(r, n, batch, dtype == TTR_F32 ? 4 : 8, g_orth_rounds).off_skip) +
+              (int64_t)of_round0 * batch;
   }
   ProfScope prof(TTR_PROF_MISC, s);
   if (r <= 64) {  // the block variant (Gram matrix + coefficient-space Gram-Schmidt + one small product per round)
@@ -1638,7 +1655,7 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
       if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, n, (T_*)X, vec_stride, elem_stride, strideX, \
                          (const T_*)sigma, stride_sigma, dead_rel, rank_dev, g_orth_rounds, work_census_on() ? g_work_dev : nullptr, \
-                         g_qr_dbg_bx == -1 ? g_qr_dbg : nullptr);                                                                  \
+                         g_qr_dbg_bx == -1 ? g_qr_dbg : nullptr, of_skip, of_round0);                                             \
     } while (0)
     if (dtype == TTR_F32) {
       if (cw == 256 && g_orth_v2) TTR_OF_LAUNCH(float, 256, true);
