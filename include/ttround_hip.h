@@ -486,10 +486,11 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
                    int64_t strideX, const void* sigma, int64_t stride_sigma, double dead_rel, const int32_t* rank_dev,
                    void* workspace, int64_t workspace_bytes, void* stream);
 /* `workspace` (ABI 10; may be NULL): with ttr_orth_fixup_workspace_bytes(...) > 0 bytes of it, a LARGE batch (>=
- * TTR_KNOB_ORTH_SPLIT items, default 2048; vectors as rows, <= 64 of them) runs every round as three launches -- the Gram matrix by
- * ttr_rowgram's kernel (split-K partials summed in double), the coefficients, the streamed product X_dead <- W X -- instead of
- * one workgroup per item: same rounds, same semantics (a vector with non-finite entries counts as the zero vector), ~2x the HBM
- * rate.  Without it (or below the threshold) the single-launch kernel runs. */
+ * TTR_KNOB_ORTH_SPLIT items, default 2048; vectors as rows, <= 64 of them) runs its first two rounds as three launches each -- the
+ * Gram matrix by ttr_rowgram's kernel (split-K partials summed in double), the coefficients, the streamed product X_dead <- W X --
+ * instead of one workgroup per item, and ONE launch of the single-workgroup kernel finishes the items that need more (remainders
+ * that collapsed and were replaced: rare).  Same rounds, same semantics (a vector with non-finite entries counts as the zero
+ * vector), ~2x the HBM rate.  Without a workspace (or below the threshold) the single-launch kernel does everything. */
 /* `rank_dev` (optional, device int32 [batch]): only the first min(r, rank_dev[b]) vectors of item b are looked at -- a sweep
  * that computes its factors at the rank cap and cuts them to the selected rank later does not complete vectors it drops. */
 
