@@ -1396,6 +1396,20 @@ def test_reference_call_signature_on_the_metric_shape(call, monkeypatch):
     assert all(((x - y).abs().max() / y.max()).item() <= 1e-5 for x, y in zip(so, sr))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_whole_sweep_entry_eps_mode_long_last_core(dt, monkeypatch):
+    """eps mode forms delta from ||last core|| on the device; a carry of 2^20 elements takes the chunked two-stage norm
+    (`_hip.norm` / norm_one in ttr_roundtt.hip): ttr_round_tt and the host loop agree bit for bit, ranks as the oracle's."""
+    torch.manual_seed(17)
+    it = [torch.randn(1, 64, 64, dtype=dt), (torch.randn(64, 6, dtype=dt) @ torch.randn(6, 16384, dtype=dt)).reshape(64, 16384, 1)]
+    monkeypatch.setenv("TTR_EPS_DEFERRED", "1")
+    a, b, used = _sweep_both_ways(monkeypatch, lambda: gpu_tensor(it), lambda t: t.round_tt(eps=1e-3, rmax=16))
+    assert used == 1 and all(torch.equal(x, y) for x, y in zip(a, b))
+    ref = oracle.round_tt([c.clone() for c in it], eps=1e-3, rmax=16, algorithm="svd")
+    assert ranks(to_list(a)) == ranks(ref) == [1, 6, 1]
+    assert rel_diff(dense(to_list(a)), dense(ref)) <= (2e-5 if dt == torch.float32 else 1e-10)
+
+
 def test_whole_sweep_entry_declines_what_it_does_not_cover(monkeypatch):
     """Outside ttr_round_tt's envelope (TT ranks above a TSQR panel, bonds with more rows than columns) the planner returns
     TTR_E_UNSUPPORTED and the host loop runs -- same results as ever; zero batches keep the batch-mode zero guard."""

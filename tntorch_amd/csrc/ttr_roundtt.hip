@@ -132,7 +132,7 @@ int make_sweep_plan(int dtype, int64_t N, const int64_t* shapes, const int64_t* 
   for (int i = 0; i < 3; ++i) p.off_left[i] = take(off, maxleft * p.es);
   p.off_orth = take(off, p.orth_wsb);
   p.off_d2 = take(off, 8);
-  p.off_nrm = take(off, 4096 * 8);
+  p.off_nrm = take(off, 64 + 4096 * 8);   // [0, 64): the norm; behind it: up to 4096 chunk norms (norm_one)
   p.total = off;
   return TTR_OK;
 }
