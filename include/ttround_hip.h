@@ -487,7 +487,8 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
                    void* workspace, int64_t workspace_bytes, void* stream);
 /* `workspace` (ABI 10; may be NULL): with ttr_orth_fixup_workspace_bytes(...) > 0 bytes of it, a LARGE batch (>=
  * TTR_KNOB_ORTH_SPLIT items, default 2048; vectors as rows, <= 64 of them) runs its first two rounds as three launches each -- the
- * Gram matrix by ttr_rowgram's kernel (split-K partials summed in double), the coefficients, the streamed product X_dead <- W X --
+ * Gram matrix by ttr_rowgram's kernel (split-K partials summed in double), the coefficients, the streamed product X_dead <- W X
+ * (which, for <= 32 vectors, also leaves the second round's Gram matrix: that round has two launches) --
  * instead of one workgroup per item, and ONE launch of the single-workgroup kernel finishes the items that need more (remainders
  * that collapsed and were replaced: rare).  Same rounds, same semantics (a vector with non-finite entries counts as the zero
  * vector), ~2x the HBM rate.  Without a workspace (or below the threshold) the single-launch kernel does everything. */
@@ -592,8 +593,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      barrier in the round loop): measured SLOWER (1.25 vs 0.80 ms per launch of 2048 matrices, round 5);
  *                      0 (default) = the four-wave kernel. */
 #define TTR_KNOB_JACOBI_LIVE_WAVE 11
-/*   TTR_KNOB_ORTH_V2  1 (default) = ttr_orth_fixup's block variant for <= 32 vectors runs the round-5 inner loops (wide LDS operand
- *                      reads with a permuted K order, dead tile rows only, chunk columns split over the four waves); 0 = round 4's (A/B). */
+/*   TTR_KNOB_ORTH_V2  1 = ttr_orth_fixup's block variant for <= 32 vectors runs the round-5 inner loops (wide LDS operand
+ *                      reads with a permuted K order, dead tile rows only, chunk columns split over the four waves); 0 = round 4's (A/B);
+ *                      2 (default) = 1 + the three-launch rounds of a large batch with <= 32 vectors skip the second round's Gram launch:
+ *                      the first round's product launch leaves the Gram matrix of the vectors as it wrote them (A/B against 1). */
 #define TTR_KNOB_ORTH_V2 12
 /*   TTR_KNOB_QR_INTERLEAVE  1 (default) = the block-major launches of TTR_KNOB_QR_PACK = 3 (ttr_qr_factor_pushed level 0,
  *                      ttr_qr_apply_pushed level 0) order the workgroups of each half item by item (an item's working blocks follow

@@ -821,8 +821,21 @@ def test_orth_fixup_many_dead(dt, r, n, first, split):
             X1 = before.clone()
             h.orth_fixup(X1, sig.to(dt).cuda(), r, 1e-6)
         finally:
-            h.set_knob(h.KNOB_ORTH_V2, 1)
+            h.set_knob(h.KNOB_ORTH_V2, 2)
         assert torch.equal(X1[:, :first], Xd[:, :first]) and (X1 - Xd).abs().max().item() < 2e-5
+    if split and r <= 32:
+        # the second round's Gram matrix left by the first round's apply launch (TTR_KNOB_ORTH_V2 = 2, the default) against a
+        # Gram launch of its own (1): the same sums in another order -- the same vectors to rounding
+        h.set_knob(h.KNOB_ORTH_V2, 1)
+        try:
+            X1 = before.clone()
+            h.orth_fixup(X1, sig.to(dt).cuda(), r, 1e-6)
+        finally:
+            h.set_knob(h.KNOB_ORTH_V2, 2)
+        o1 = X1.cpu().double()
+        for b in range(B):
+            assert (o1[b] @ o1[b].T - eye).abs().max() < tol(dt, 2e-6, 1e-13), b
+        assert torch.equal(X1[:, :first], Xd[:, :first]) and (X1 - Xd).abs().max().item() < tol(dt, 2e-5, 1e-11)
 
 
 @pytest.mark.parametrize("dt", DT)

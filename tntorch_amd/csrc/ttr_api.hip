@@ -724,14 +724,21 @@ __global__ __launch_bounds__(kThreads, V2 ? 2 : 1) void orth_fixup_block_kernel(
 constexpr int kOrthSplitRounds = 2;
 struct OrthSplitWs {
   int64_t off_g, off_w, off_regen, off_skip, total;
-  int parts;
+  int parts;    // Gram partials of a ttr_rowgram launch
+  int nsplit;   // column splits of the apply launch (grid x)
+  int fparts;   // Gram partials written by a FUSED apply launch (one per wave and column split)
 };
 static OrthSplitWs orth_split_layout(int64_t r, int64_t n, int64_t batch, int64_t es, int max_rounds) {
   OrthSplitWs w{};
   const int64_t r4 = (r + 15) & ~15LL;
   w.parts = n >= 2048 ? 4 : (n >= 1024 ? 2 : 1);   // short fp32 accumulation chains: the partials are summed in double
+  w.nsplit = (int)ceil_div(2048, batch);           // aim at >= 2048 workgroups, >= 8 slabs per wave
+  const int64_t slabs = (n + 15) / 16;
+  if (w.nsplit > slabs / 32) w.nsplit = (int)(slabs / 32);
+  if (w.nsplit < 1) w.nsplit = 1;
+  w.fparts = 4 * w.nsplit;
   int64_t off = 0;
-  w.off_g = off; off += align_up(batch * w.parts * r * r * es, 256);
+  w.off_g = off; off += align_up(batch * (w.parts > w.fparts ? w.parts : w.fparts) * r * r * es, 256);
   w.off_w = off; off += align_up(batch * r4 * r4 * es, 256);
   w.off_regen = off; off += align_up(batch * 8, 256);                       // one 64-bit mask per item
   w.off_skip = off; off += align_up((int64_t)(max_rounds + 1) * batch * 4, 256);
@@ -886,14 +893,24 @@ __global__ __launch_bounds__(kThreads) void orth_coef_kernel(int r, const T* __r
 // X_dead <- W X, streamed: grid (column splits, items); a wave walks 16-column slabs (every item starts at another slab: the
 // columns are independent), the vectors of a slab are the B operand straight from global memory (four 64-byte row segments per
 // load, the next slab's loads in flight under this slab's products), W is the A operand from an LDS image.
-template <typename T>
+//
+// GRAM (at most 32 vectors): the launch also leaves the Gram matrix of the vectors AS IT WROTE THEM -- what the next round's
+// coefficients are computed from -- so that the next round does not read the item again for it (ttr_rowgram on 32 x 2048 items:
+// 0.35 ms per launch at B = 4096, a quarter of the round).  The MFMA products of the apply pass have the columns on the lanes'
+// N index; the Gram product contracts over the columns, so a slab's 32 x 16 tile (live rows as loaded, dead rows as computed)
+// goes through a per-wave LDS tile and comes back with the columns on K.  Only the dead row tiles' rows of the Gram matrix are
+// formed (orth_coef_kernel reads nothing else); every wave writes its own partial: Gnext[b][4 split + wave][r][r], the others
+// zero.
+constexpr int kOrthXtLd = 17;
+template <typename T, bool GRAM>
 __global__ __launch_bounds__(kThreads) void orth_apply_kernel(int r, int64_t n, T* __restrict__ X, int64_t vs, int64_t strideX,
                                                               const T* __restrict__ Wg, const unsigned long long* __restrict__ regen_mask,
                                                               const int32_t* __restrict__ skip_now, const T* __restrict__ sigma,
                                                               int64_t stride_sigma, double dead_rel, const int32_t* __restrict__ rank_dev,
-                                                              int round, int nsplit) {
+                                                              int round, int nsplit, T* __restrict__ Gnext) {
   using M = Mfma<T>;
   __shared__ T Wl[64 * 65];
+  __shared__ T Xt[GRAM ? 4 * 32 * kOrthXtLd : 1];
   const int64_t b = blockIdx.y;
   if (skip_now[b] != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 15, g = lane >> 4;
@@ -917,24 +934,32 @@ __global__ __launch_bounds__(kThreads) void orth_apply_kernel(int r, int64_t n, 
   const int64_t rot = nsteps > 1 ? (int64_t)(b % nsteps) : 0;
   auto step_c = [&](int64_t sidx) { int64_t sq = sidx + rot; if (sq >= nsteps) sq -= nsteps; return cb + wave + 4 * sq; };
   const int nks = r4 >> 2;
-  auto load_cols = [&](int64_t c, T (&a)[16]) {
+  constexpr int KS = GRAM ? 8 : 16;   // k-steps of four vectors held per slab (GRAM: at most 32 vectors)
+  auto load_cols = [&](int64_t c, T (&a)[KS]) {
     const int64_t col = c * 16 + cl;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + g;
       T v = (ks < nks && k < r_launch && col < n) ? Xb[(int64_t)k * vs + col] : T(0);
       a[ks] = (v - v == T(0)) ? v : T(0);   // (non-finite entries of a dead vector count as zero)
     }
   };
-  T a[16], an[16];
+  T a[KS], an[KS];
+  T* const xt = Xt + (GRAM ? wave * 32 * kOrthXtLd : 0);
+  typename M::Acc Gacc[2][2] = {{M::zero(), M::zero()}, {M::zero(), M::zero()}};
   if (nsteps > 0) load_cols(step_c(0), a);
   for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
     const int64_t c = step_c(sidx);
     if (sidx + 1 < nsteps) load_cols(step_c(sidx + 1), an);
+    if constexpr (GRAM) {   // the slab as loaded (columns beyond n: zeros); the dead rows are overwritten below
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (ks < nks) xt[(4 * ks + g) * kOrthXtLd + cl] = a[ks];
+    }
     for (int it = it0; it < nt; ++it) {
       typename M::Acc acc = M::zero();
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
         if (ks < nks) acc = M::mma(Wl[(16 * it + cl) * 65 + 4 * ks + g], a[ks], acc);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -948,12 +973,44 @@ __global__ __launch_bounds__(kThreads) void orth_apply_kernel(int r, int64_t n, 
           out = (T)((double)(h >> 8) * (1.0 / 8388608.0) - 1.0);
         }
         Xb[(int64_t)d * vs + col] = out;
+        if constexpr (GRAM) xt[d * kOrthXtLd + cl] = out;
       }
+    }
+    if constexpr (GRAM) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave, in-order LDS: the tile is complete)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (it >= it0 && it < nt) {   // (wave-uniform)
+          T pa[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) pa[s4] = xt[(16 * it + cl) * kOrthXtLd + 4 * s4 + g];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            if (jt < nt) {
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) Gacc[it][jt] = M::mma(pa[s4], xt[(16 * jt + cl) * kOrthXtLd + 4 * s4 + g], Gacc[it][jt]);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads are done before the next slab's tile is written)
     }
     if (sidx + 1 < nsteps) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) a[ks] = an[ks];
+      for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
     }
+  }
+  if constexpr (GRAM) {
+    T* __restrict__ Gp = Gnext + ((b * nsplit + blockIdx.x) * 4 + wave) * (int64_t)r_launch * r_launch;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 16 * it + M::row(lane, u), j = 16 * jt + cl;
+          if (i < r_launch && j < r_launch) Gp[i * r_launch + j] = Gacc[it][jt][u];
+        }
   }
 }
 
@@ -1058,7 +1115,7 @@ static bool dtype_ok(int dtype) { return dtype == TTR_F32 || dtype == TTR_F64; }
 using namespace ttr;
 
 static int g_orth_rounds = 4;   // ttr_debug_set_knob(TTR_KNOB_ORTH_ROUNDS): rounds of the block orthonormal completion (diagnostics)
-static int g_orth_v2 = 1;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2, 0): round 4's inner loops (A/B)
+static int g_orth_v2 = 2;       // ttr_debug_set_knob(TTR_KNOB_ORTH_V2): 0 = round 4's inner loops, 1 = round 5's, 2 = + the three-launch rounds' fused Gram (A/B)
 // ttr_debug_set_knob(TTR_KNOB_ORTH_SPLIT): batches from this size (per launch, i.e. per sub-batch stream) take the three-launch
 // rounds; 0 = never.  Where most kept directions lie below the resolution (sigma ~ 2^-j) the rounds cost 6.0 instead of 8.4 ms per
 // 2048-train step (B = 4096: step 50.4 -> 44.5 ms, 650 k -> 736 k cores/s); a batch WITHOUT dead directions pays for 13 launches
@@ -1089,10 +1146,9 @@ static int orth_split_run(int64_t r, int64_t n, int64_t batch, T* X, int64_t vs,
   }
   const int r4 = ((int)r + 15) & ~15;
   const size_t lds = 2 * (size_t)r4 * (r4 + 1) * 8 + 64 * 4 + 16;
-  int nsplit = (int)ceil_div(2048, batch);   // aim at >= 2048 workgroups, >= 8 slabs per wave
-  const int64_t slabs = (n + 15) / 16;
-  if (nsplit > slabs / 32) nsplit = (int)(slabs / 32);
-  if (nsplit < 1) nsplit = 1;
+  const int nsplit = L.nsplit;
+  // at most 32 vectors: round k's apply launch leaves the Gram matrix round k + 1 starts from (orth_apply_kernel<T, true>)
+  const bool fuse = g_orth_v2 >= 2 && r4 <= 32;
   // Two rounds ("twice is enough"); what is left after them -- items whose remainders collapsed and were replaced by hashed
   // vectors: rare -- is finished by the single-launch kernel (one launch that exits at once where nothing is left, instead of
   // six more launches per bond that do).
@@ -1100,15 +1156,24 @@ static int orth_split_run(int64_t r, int64_t n, int64_t batch, T* X, int64_t vs,
   for (int round = 0; round < nrounds; ++round) {
     const int32_t* sk = skip + (int64_t)round * batch;
     TTR_HIP_CHECK(hipGetLastError());
-    const int rc = sweep_gram_dispatch(dtype, r, n, batch, X, vs, strideX, nullptr, 0, 0, G, L.parts, s, sk, nullptr);
-    if (rc != TTR_OK) return rc;
+    const bool have_gram = fuse && round > 0;   // left by the previous round's apply launch
+    if (!have_gram) {
+      const int rc = sweep_gram_dispatch(dtype, r, n, batch, X, vs, strideX, nullptr, 0, 0, G, L.parts, s, sk, nullptr);
+      if (rc != TTR_OK) return rc;
+    }
     ProfScope prof(TTR_PROF_MISC, s);
     auto kern = orth_coef_kernel<T>;
     if (lds > 64 * 1024) TTR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, (const T*)G, L.parts, Wg, regen, sk,
-                       skip + (int64_t)(round + 1) * batch, sigma, stride_sigma, dead_rel, rank_dev, round, census);
-    hipLaunchKernelGGL(orth_apply_kernel<T>, dim3((unsigned)nsplit, (unsigned)batch), dim3(kThreads), 0, s, (int)r, n, X, vs, strideX,
-                       (const T*)Wg, (const unsigned long long*)regen, sk, sigma, stride_sigma, dead_rel, rank_dev, round, nsplit);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kThreads), lds, s, (int)r, (const T*)G, have_gram ? L.fparts : L.parts, Wg, regen,
+                       sk, skip + (int64_t)(round + 1) * batch, sigma, stride_sigma, dead_rel, rank_dev, round, census);
+    if (fuse && round + 1 < nrounds)
+      hipLaunchKernelGGL((orth_apply_kernel<T, true>), dim3((unsigned)nsplit, (unsigned)batch), dim3(kThreads), 0, s, (int)r, n, X, vs,
+                         strideX, (const T*)Wg, (const unsigned long long*)regen, sk, sigma, stride_sigma, dead_rel, rank_dev, round,
+                         nsplit, G);
+    else
+      hipLaunchKernelGGL((orth_apply_kernel<T, false>), dim3((unsigned)nsplit, (unsigned)batch), dim3(kThreads), 0, s, (int)r, n, X, vs,
+                         strideX, (const T*)Wg, (const unsigned long long*)regen, sk, sigma, stride_sigma, dead_rel, rank_dev, round,
+                         nsplit, (T*)nullptr);
   }
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
@@ -1732,7 +1797,7 @@ int ttr_debug_set_knob(int knob, int value) {
       g_qr_interleave = value;
       return TTR_OK;
     case TTR_KNOB_ORTH_V2:
-      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: orth_fixup variant %d outside [0, 1]", value);
+      TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: orth_fixup variant %d outside [0, 2]", value);
       g_orth_v2 = value;
       return TTR_OK;
     case TTR_KNOB_JACOBI_LIVE_WAVE:

@@ -41,7 +41,7 @@ for decay in (1.0, 0.5):
               ", ".join(f"{k} {v['ms']:.2f}/{v['launches']}" for k, v in p.items() if v["launches"]) +
               f"; orth_fixup: {w['misc']['bytes']:.0f} items with dead rows, {w['misc']['flops']:.0f} rounds"
               f" ({w['misc']['flops'] / max(w['misc']['bytes'], 1):.2f} per item)")
-    _hip.set_knob(_hip.KNOB_ORTH_ROUNDS, 4); _hip.set_knob(_hip.KNOB_JACOBI_LIVE_WAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 1)
+    _hip.set_knob(_hip.KNOB_ORTH_ROUNDS, 4); _hip.set_knob(_hip.KNOB_JACOBI_LIVE_WAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 2)
     # the pass-2 Jacobi launches alone: capture the arguments of the host loop's calls
     _hipops.SWEEP_C_ENABLED = False
     cap = []

@@ -43,4 +43,4 @@ for name, inp in inputs.items():
         _hip.prof_enable(False)
         print(f"{name} B={B} interleave={il} orth_v2={ov} stagger={sg} orth_split={sp}: step {wall:.2f} ms (two streams) = {B * 8 / wall * 1e3:.0f} cores/s; per kind ms/step: " +
               ", ".join(f"{k} {v['ms'] / 3:.2f}" for k, v in p.items() if v["launches"]))
-_hip.set_knob(_hip.KNOB_QR_INTERLEAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 1); _hip.set_knob(_hip.KNOB_SWEEP_STAGGER, 1); _hip.set_knob(_hip.KNOB_ORTH_SPLIT, 2048)
+_hip.set_knob(_hip.KNOB_QR_INTERLEAVE, 1); _hip.set_knob(_hip.KNOB_ORTH_V2, 2); _hip.set_knob(_hip.KNOB_SWEEP_STAGGER, 1); _hip.set_knob(_hip.KNOB_ORTH_SPLIT, 2048)

@@ -22,7 +22,7 @@ tail -n 30 $OUT/pmc_summary.txt
 head -n 25 $OUT/kernel_stats.txt
 # ---- the inputs / configs furthest from their roofs ("Missing 3"): the decaying-spectrum variant of the metric
 #      (no shortcut fires), BASELINE C3's per-GPU share and C4 -- kernel trace + the same three counter passes each
-for spec in "decay05:2048:decay0.5:2" "c3:64:c3:2" "c4:1:c4:2"; do
+for spec in "decay05:2048:decay0.5:2" "decay10:2048:decay1.0:2" "c3:64:c3:2" "c4:1:c4:2"; do
   IFS=: read name bb kind st <<< "$spec"
   D=$OUT/$name
   mkdir -p $D
