@@ -53,9 +53,9 @@ extern "C" {
 
 /* ABI version of this header: bumped whenever an exported signature changes (round 2 inserted `gparts` / `stride_gpart` into
    ttr_eigh_trunc = 2; round 3 additions = 3 ... 7, the last one ttr_eigh_top; round 4: 8 = rows32 / skip_zero_rows, 9 = ttr_carry_rows32;
-   round 5: 10 = ttr_round_tt, the whole sweep behind one call, + TTR_KNOB_RANK_NOISE_FLOOR).  ttr_version() returns the value the library was built with; the Python
+   round 5: 10 = ttr_round_tt, the whole sweep behind one call, + TTR_KNOB_RANK_NOISE_FLOOR; 11 = ttr_qr_factor_expo / ttr_qr_factor_pushed_expo).  ttr_version() returns the value the library was built with; the Python
    binding refuses to use a library whose version differs (a stale .so would take misaligned arguments silently). */
-#define TTR_ABI_VERSION 10
+#define TTR_ABI_VERSION 11
 int ttr_version(void);
 const char* ttr_last_error(void);
 
@@ -142,6 +142,20 @@ int ttr_qr_apply(int dtype, int64_t m, int64_t n, int64_t batch,
                  void* workspace, int64_t workspace_bytes,
                  const void* C, int64_t ldc, int64_t strideC, int64_t kcols,
                  void* Out, int64_t ldo, int64_t strideO, void* stream);
+/*
+ * ttr_qr_factor with the sweep's power-of-two normalisation folded in (ABI 11; fp32 only): R comes back as R 2^-e, e the binary
+ * exponent of the largest entry of the TOP block of the TSQR tree (max |entry| of what is returned times 2^e lies within a factor
+ * sqrt(rows) of 1: O(1), exact scaling), and e is ADDED to expo_acc[item] (device int32 [batch]).  The left-to-right loop of a
+ * rounding (tensor.py:1905-1906) multiplies the norms of all cores into the last R: 64^8 randn cores reach 2^72 in fp32, sums and
+ * products more; the sweep therefore keeps every R at O(1) and gives the exponents back to the first core at the end (exact).
+ * Rounds 1 - 4 did that with one ttr_pow2_normalize launch per core; the factor kernel already scales its block by a power of two
+ * (its fp32 range guard) and here simply does not scale R back.  Reflectors and T factors are scale invariant: ttr_qr_apply on
+ * the same workspace is unchanged.  ttr_qr_factor_pushed_expo: the same for the fused push.
+ */
+int ttr_qr_factor_expo(int dtype, int64_t m, int64_t n, int64_t batch,
+                       const void* A, int64_t lda, int64_t strideA,
+                       void* R, int64_t ldr, int64_t strideR,
+                       void* workspace, int64_t workspace_bytes, int32_t* expo_acc, void* stream);
 
 /*
  * Fused "push right + QR" of the left-to-right sweep (tensor.py:1823-1832 followed by tensor.py:1816 of the next
@@ -157,6 +171,11 @@ int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n
                          const void* core, int64_t stride_core,
                          void* R, int64_t ldr, int64_t strideR,
                          void* workspace, int64_t workspace_bytes, void* stream);
+int ttr_qr_factor_pushed_expo(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch,
+                              const void* Rm, int64_t ldrm, int64_t strideRm,
+                              const void* core, int64_t stride_core,
+                              void* R, int64_t ldr, int64_t strideR,
+                              void* workspace, int64_t workspace_bytes, int32_t* expo_acc, void* stream);
 /*
  * The same fused push + factorisation for the middle core of a TT SUM a + b (tensor.py:445-668): the next core is the
  * block-diagonal blockdiag(a_core [ra][I][ca], b_core [rb][I][cb]) of tensor.py's `__add__`, which is never

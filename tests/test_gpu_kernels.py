@@ -172,6 +172,55 @@ def test_qr_pushed(dt, k, Rin, I, n, qr_variant):
     assert (out - Q @ C.double()).abs().max() < tol(dt, 3e-5, 1e-12)
 
 
+@pytest.mark.parametrize("shape", [(4096, 64), (64, 64), (33, 5), (700, 20), (9000, 48)])
+def test_qr_factor_expo_is_the_plain_factorisation_at_another_exponent(shape):
+    """ttr_qr_factor_expo (ABI 11): R comes back as R 2^-e with the exponent added to expo_acc -- the SAME bits as ttr_qr_factor's R
+    once scaled back (exact powers of two), the same reflectors (ttr_qr_apply unchanged), e such that what is returned is O(1);
+    items at 1e-20 and 1e+15, a zero item."""
+    h = _hip()
+    m, n = shape
+    g = torch.Generator().manual_seed(m + n)
+    A = torch.randn(4, m, n, generator=g, dtype=torch.float32)
+    A[1] *= 1e-20
+    A[2] *= 1e15
+    A[3] = 0
+    Ad = A.cuda()
+    plain = h.qr_factor(Ad)
+    expo = torch.tensor([0, 5, -3, 7], dtype=torch.int32, device="cuda")
+    f = h.qr_factor(Ad, expo_acc=expo)
+    e = (expo.cpu() - torch.tensor([0, 5, -3, 7], dtype=torch.int32)).double()
+    assert int(e[3]) == 0 and torch.equal(f.R[3], plain.R[3])
+    back = torch.ldexp(f.R.cpu().double(), e[:, None, None].expand_as(f.R).to(torch.int32))
+    assert torch.equal(back.to(torch.float32), plain.R.cpu())
+    mx = f.R[:3].abs().amax(dim=(1, 2)).cpu()
+    assert (mx > 2.0 ** -12).all() and (mx < 2.0 ** 12).all()
+    assert torch.equal(h.qr_apply(f), h.qr_apply(plain))
+
+
+@pytest.mark.parametrize("k,Rin,I,n", [(64, 64, 64, 64), (64, 64, 8, 64), (64, 64, 4, 33), (10, 7, 9, 12), (33, 64, 130, 64)])
+def test_qr_factor_pushed_expo_is_the_plain_factorisation_at_another_exponent(k, Rin, I, n):
+    """ttr_qr_factor_pushed_expo: as above for the fused push -- TSQR trees with a top level of their own (the kernel keeps the
+    exponent) and single-level ones (I <= 8: a normalisation launch inside the entry)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(k * 1000 + Rin * 100 + I * 10 + n)
+    B = 3
+    Rm = torch.randn(B, k, Rin, generator=g, dtype=torch.float32)
+    core = torch.randn(B, Rin, I, n, generator=g, dtype=torch.float32)
+    Rm[1] *= 1e-18
+    core[2] *= 1e12
+    plain = h.qr_factor_pushed(Rm.cuda(), core.cuda())
+    expo = torch.tensor([1, 0, -2], dtype=torch.int32, device="cuda")
+    f = h.qr_factor_pushed(Rm.cuda(), core.cuda(), expo_acc=expo)
+    e = (expo.cpu() - torch.tensor([1, 0, -2], dtype=torch.int32)).double()
+    back = torch.ldexp(f.R.cpu().double(), e[:, None, None].expand_as(f.R).to(torch.int32))
+    assert torch.equal(back.to(torch.float32), plain.R.cpu())
+    mx = f.R.abs().amax(dim=(1, 2)).cpu()
+    assert (mx > 2.0 ** -12).all() and (mx < 2.0 ** 12).all()
+    assert torch.equal(h.qr_apply(f), h.qr_apply(plain))
+    if plain.rows32 is not None:
+        assert torch.equal(f.rows32, plain.rows32)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("pack", [0, 1, 2, 3])
 @pytest.mark.parametrize("I,mixed", [(64, False), (128, False), (64, True), (24, False)])

@@ -1339,6 +1339,37 @@ def test_whole_sweep_entry_is_bit_identical_to_the_host_loop_batch(case, alg, mo
     assert all(torch.isfinite(x).all() for x in a)
 
 
+@pytest.mark.parametrize("case", ["metric3", "scaled", "two_cores"])
+def test_r_factors_normalised_by_the_factor_kernel_give_the_same_bits(case, monkeypatch):
+    """The fp32 sweep keeps every R factor at O(1) by an exact power of two per item.  ABI 11: the factor kernel leaves R at the
+    exponent it factored at (ttr_qr_factor_expo / ttr_qr_factor_pushed_expo) instead of one ttr_pow2_normalize launch per core:
+    the rounded cores are BIT-identical to the separate launches' (host loop, TTR_FUSE_QR_NORM=0), on the metric's shape, on a
+    train whose cores are scaled by 1e-9 and 1e+7 (norms far outside fp32's squares without the normalisation) and on two cores."""
+    from tntorch_amd import _hipops
+    if case == "metric3":
+        inp, rmax = _metric_input(3, seed=21), 32
+    elif case == "scaled":
+        inp = _metric_input(2, seed=22)
+        inp = [c * (1e-9 if i % 2 == 0 else 1e7) for i, c in enumerate(inp)]
+        rmax = 32
+    else:
+        torch.manual_seed(3)
+        inp, rmax = [torch.randn(4, 1, 40, 24), torch.randn(4, 24, 48, 1)], 7
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(_hipops, "FUSE_QR_NORM", fused)
+        t = gpu_tensor(inp, batch=True)
+        t.round_tt(rmax=rmax)
+        out[fused] = [c.clone() for c in t.cores]
+    monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", True)
+    t = gpu_tensor(inp, batch=True)
+    t.round_tt(rmax=rmax)
+    assert all(torch.equal(x, y) for x, y in zip(out[True], out[False]))
+    assert all(torch.equal(x, y) for x, y in zip(out[True], t.cores))
+    assert all(torch.isfinite(x).all() for x in out[True])
+
+
 @pytest.mark.parametrize("dt,eps", [(torch.float32, 1e-3), (torch.float64, 1e-6), (torch.float64, 1e-14)])
 @pytest.mark.parametrize("alg", ["svd", "eig"])
 def test_whole_sweep_entry_eps_mode_vs_host_loop_and_oracle(dt, eps, alg, monkeypatch):

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTR_LIB_PATH") or os.path.join(_HERE, "libttround_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 10  # include/ttround_hip.h: TTR_ABI_VERSION
+ABI_VERSION = 11  # include/ttround_hip.h: TTR_ABI_VERSION
 SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
 EIG_RAW, EIG_REF, EIG_MATCH_DIAG = 0, 1, 2
 SOLVER_JACOBI_REL, SOLVER_JACOBI_ABS, SOLVER_TRIDIAG, SOLVER_JACOBI_LIVE = 0, 1, 2, 3  # `abs_floor` argument of ttr_eigh_trunc
@@ -67,6 +67,12 @@ _SIGNATURES = {
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_void_p],
     ),
+    "ttr_qr_factor_expo": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p, c_void_p],
+    ),
     "ttr_qr_apply": (
         c_int,
         [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64,
@@ -78,6 +84,12 @@ _SIGNATURES = {
         [c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_int64, c_void_p],
+    ),
+    "ttr_qr_factor_pushed_expo": (
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
+         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "ttr_qr_factor_pushed_sum": (
         c_int,
@@ -432,8 +444,11 @@ class QrFactors:
 
 
 @_on_device
-def qr_factor(A: torch.Tensor) -> QrFactors:
-    """Factor [batch, m, n]; returns a handle holding R [batch, k, n] and the implicit Q."""
+def qr_factor(A: torch.Tensor, expo_acc: Optional[torch.Tensor] = None) -> QrFactors:
+    """Factor [batch, m, n]; returns a handle holding R [batch, k, n] and the implicit Q.
+
+    ``expo_acc`` (fp32; device int32 [batch]): R comes back as R 2^-e, e the exponent of the top block's largest entry, and e is
+    added to expo_acc[b] -- the sweep's per-core power-of-two normalisation without a launch of its own (ttr_qr_factor_expo)."""
     L = lib()
     dt = dtype_code(A.dtype)
     A, lda, sA = _mat(A)
@@ -442,7 +457,12 @@ def qr_factor(A: torch.Tensor) -> QrFactors:
     R = torch.empty((batch, k, n), dtype=A.dtype, device=A.device)
     wsb = L.ttr_qr_workspace_bytes(dt, m, n, max(batch, 1))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=A.device)
-    if batch > 0:
+    if batch > 0 and expo_acc is not None:
+        assert expo_acc.dtype == torch.int32 and expo_acc.numel() == batch and expo_acc.is_contiguous()
+        code = L.ttr_qr_factor_expo(dt, m, n, batch, A.data_ptr(), lda, sA, R.data_ptr(), n, k * n, ws.data_ptr(), wsb,
+                                    expo_acc.data_ptr(), _stream())
+        _check(code, "ttr_qr_factor_expo")
+    elif batch > 0:
         code = L.ttr_qr_factor(dt, m, n, batch, A.data_ptr(), lda, sA, R.data_ptr(), n, k * n, ws.data_ptr(), wsb, _stream())
         _check(code, "ttr_qr_factor")
     return QrFactors(ws, wsb, m, n, batch, A.dtype, R)
@@ -453,8 +473,9 @@ def pushed_supported(k: int, Rin: int, I: int, n: int, dt: torch.dtype) -> bool:
 
 
 @_on_device
-def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
-    """Factor the left unfolding of ``Rm @ core`` (Rm [batch, k, Rin], core [batch, Rin, I, n]) without forming it."""
+def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor, expo_acc: Optional[torch.Tensor] = None) -> QrFactors:
+    """Factor the left unfolding of ``Rm @ core`` (Rm [batch, k, Rin], core [batch, Rin, I, n]) without forming it.
+    ``expo_acc``: as for ``qr_factor`` (ttr_qr_factor_pushed_expo)."""
     L = lib()
     dt = dtype_code(core4.dtype)
     Rm, ldrm, sRm = _mat(Rm)
@@ -466,7 +487,12 @@ def qr_factor_pushed(Rm: torch.Tensor, core4: torch.Tensor) -> QrFactors:
     R = torch.empty((batch, kq, n), dtype=core4.dtype, device=core4.device)
     wsb = L.ttr_qr_pushed_workspace_bytes(dt, I, n, max(batch, 1))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=core4.device)
-    if batch > 0:
+    if batch > 0 and expo_acc is not None:
+        assert expo_acc.dtype == torch.int32 and expo_acc.numel() == batch and expo_acc.is_contiguous()
+        code = L.ttr_qr_factor_pushed_expo(dt, k, Rin, I, n, batch, Rm.data_ptr(), ldrm, sRm, core4.data_ptr(), Rin * I * n,
+                                           R.data_ptr(), n, kq * n, ws.data_ptr(), wsb, expo_acc.data_ptr(), _stream())
+        _check(code, "ttr_qr_factor_pushed_expo")
+    elif batch > 0:
         code = L.ttr_qr_factor_pushed(dt, k, Rin, I, n, batch, Rm.data_ptr(), ldrm, sRm, core4.data_ptr(), Rin * I * n,
                                       R.data_ptr(), n, kq * n, ws.data_ptr(), wsb, _stream())
         _check(code, "ttr_qr_factor_pushed")

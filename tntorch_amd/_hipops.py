@@ -1179,6 +1179,10 @@ def round_tt(
 # the ~80 launches of a train are enqueued from C++ instead of one ctypes call each (the host cost of a call: 1.2 ms -> what the
 # device needs).  TTR_SWEEP_C=0: always the Python loop below (A/B; tests cross-check the two).
 SWEEP_C_ENABLED = os.environ.get("TTR_SWEEP_C", "1") != "0"
+# The host loop's fp32 factorisations normalise their R factors themselves (ttr_qr_factor_expo / ttr_qr_factor_pushed_expo, ABI 11)
+# instead of one ttr_pow2_normalize launch per core; TTR_FUSE_QR_NORM=0: the separate launches (A/B; the results are bit-identical
+# either way -- the scalings are exact powers of two -- and the one-call entry always uses the fused form).
+FUSE_QR_NORM = os.environ.get("TTR_FUSE_QR_NORM", "1") != "0"
 SWEEP_C_CALLS = 0   # (tests: how many sweeps went through ttr_round_tt)
 
 
@@ -1267,27 +1271,31 @@ def _round_tt_sweep(c, eps, rmax, algorithm, batch, arena, chunk, zflags=None) -
                 c[mu] = None
                 continue
             c[mu] = c[mu].dense()  # ranks above the fused kernel's 64 columns: the padded core after all
+        # fp32: ||R_mu|| is the norm of the partially contracted tensor and grows like (I r)^(mu/2): the squared
+        # column norms / Gram entries of a high-order train overflow fp32 (LAPACK rescales internally).  Every R
+        # is therefore brought back to O(1) by an exact power of two per batch item -- by the factor kernel itself
+        # (``expo_acc``: ttr_qr_factor_expo; rounds 1 - 4 and the explicit-Q path: one ttr_pow2_normalize launch) -- ; the
+        # exponents are summed on the device and returned to core 0 at the end, so the result is bit-identical whenever
+        # nothing overflowed.
+        f32 = c[mu].dtype == torch.float32
+        if f32 and expo is None:
+            expo = torch.zeros(Bt, dtype=torch.int32, device=c[mu].device)
+        ex = expo if (f32 and FUSE_QR_NORM) else None
         if r1 > _hip.max_qr_cols(c[mu].dtype):
             # more columns than a TSQR panel holds (TT rank > 64): explicit Q from the blocked QR
             A = c[mu] if Rprev is None else _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1))
             f = _ExplicitQ(*qr(A.reshape(Bt, rows_k * I, r1)))
+            ex = None
         elif Rprev is None:
-            f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1))
+            f = _hip.qr_factor(c[mu].reshape(Bt, r0 * I, r1), expo_acc=ex)
         elif _hip.pushed_supported(Rprev.shape[1], r0, I, r1, c[mu].dtype):
-            f = _hip.qr_factor_pushed(Rprev, c[mu])  # QR of (Rprev @ core) without materialising it
+            f = _hip.qr_factor_pushed(Rprev, c[mu], expo_acc=ex)  # QR of (Rprev @ core) without materialising it
         else:
             pushed = _hip.gemm(Rprev, c[mu].reshape(Bt, r0, I * r1)).reshape(Bt, Rprev.shape[1], I, r1)
-            f = _hip.qr_factor(pushed.reshape(Bt, Rprev.shape[1] * I, r1))
+            f = _hip.qr_factor(pushed.reshape(Bt, Rprev.shape[1] * I, r1), expo_acc=ex)
         facs.append((f, rows_k, I))
         Rprev = f.R
-        if Rprev.dtype == torch.float32:
-            # ||R_mu|| is the norm of the partially contracted tensor and grows like (I r)^(mu/2): the squared
-            # column norms / Gram entries of a high-order train overflow fp32 (LAPACK rescales internally).  Every R
-            # is therefore brought back to O(1) by an exact power of two per batch item (one ttr_pow2_normalize
-            # launch); the exponents are summed on the device and returned to core 0 at the end, so the result is
-            # bit-identical whenever nothing overflowed.
-            if expo is None:
-                expo = torch.zeros(Bt, dtype=torch.int32, device=Rprev.device)
+        if f32 and ex is None:
             Rprev, _ = _hip.pow2_normalize(Rprev, expo_acc=expo)
         c[mu] = None
     last = c[N - 1]

@@ -1027,7 +1027,8 @@ int hadamard_dispatch(int dtype, int64_t count, const void* a, const void* b, vo
 int core_kron_dispatch(int dtype, int64_t B, int64_t R1, int64_t S1, int64_t I, int64_t R2, int64_t S2, const void* a,
                        const void* c, void* out, hipStream_t stream);
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
-                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs = 1);
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs = 1,
+                       int32_t* expo_acc = nullptr);
 int qr_apply_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws_bytes, const void* C,
                       int64_t ldc, int64_t strideC, int64_t kc, void* Out, int64_t ldo, int64_t strideO,
                       hipStream_t stream, int64_t o_cs = 1);
@@ -1035,7 +1036,7 @@ int64_t qr_workspace_bytes(int dtype, int64_t m, int64_t n, int64_t batch);
 int64_t qr_pushed_workspace_bytes(int dtype, int64_t I, int64_t n, int64_t batch);
 int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
                               int64_t ldrm, int64_t strideRm, const void* Cn, int64_t strideCn, void* R, int64_t ldr,
-                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream);
+                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int32_t* expo_acc = nullptr);
 int qr_factor_pushed_sum_dispatch(int dtype, int64_t k, int64_t I, int64_t batch, const void* Rm, int64_t ldrm,
                                   int64_t strideRm, const void* Ca, int64_t ra, int64_t ca, int64_t strideCa,
                                   const void* Cb, int64_t rb, int64_t cb, int64_t strideCb, void* R, int64_t ldr,
@@ -1236,6 +1237,17 @@ int ttr_qr_factor(int dtype, int64_t m, int64_t n, int64_t batch, const void* A,
                             (hipStream_t)stream);
 }
 
+int ttr_qr_factor_expo(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA, void* R,
+                       int64_t ldr, int64_t strideR, void* workspace, int64_t workspace_bytes, int32_t* expo_acc, void* stream) {
+  TTR_REQUIRE(dtype == TTR_F32, TTR_E_UNSUPPORTED, "ttr_qr_factor_expo: fp32 only (dtype %d)", dtype);
+  TTR_REQUIRE(m >= 1 && n >= 1 && batch >= 0, TTR_E_INVALID, "ttr_qr_factor_expo: bad shape %lld x %lld", (long long)m,
+              (long long)n);
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(A && R && workspace && expo_acc, TTR_E_INVALID, "ttr_qr_factor_expo: null pointer");
+  return qr_factor_dispatch(dtype, m, n, batch, A, lda, strideA, R, ldr, strideR, workspace, workspace_bytes,
+                            (hipStream_t)stream, 1, expo_acc);
+}
+
 int ttr_qr_apply(int dtype, int64_t m, int64_t n, int64_t batch, void* workspace, int64_t workspace_bytes,
                  const void* C, int64_t ldc, int64_t strideC, int64_t kcols, void* Out, int64_t ldo, int64_t strideO,
                  void* stream) {
@@ -1286,6 +1298,17 @@ int ttr_qr_factor_pushed(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n
   TTR_REQUIRE(Rm && core && R && workspace, TTR_E_INVALID, "ttr_qr_factor_pushed: null pointer");
   return qr_factor_pushed_dispatch(dtype, k, Rin, I, n, batch, Rm, ldrm, strideRm, core, stride_core, R, ldr, strideR,
                                    workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttr_qr_factor_pushed_expo(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
+                              int64_t ldrm, int64_t strideRm, const void* core, int64_t stride_core, void* R, int64_t ldr,
+                              int64_t strideR, void* workspace, int64_t workspace_bytes, int32_t* expo_acc, void* stream) {
+  TTR_REQUIRE(dtype == TTR_F32, TTR_E_UNSUPPORTED, "ttr_qr_factor_pushed_expo: fp32 only (dtype %d)", dtype);
+  TTR_REQUIRE(batch >= 0, TTR_E_INVALID, "ttr_qr_factor_pushed_expo: negative batch");
+  if (batch == 0) return TTR_OK;
+  TTR_REQUIRE(Rm && core && R && workspace && expo_acc, TTR_E_INVALID, "ttr_qr_factor_pushed_expo: null pointer");
+  return qr_factor_pushed_dispatch(dtype, k, Rin, I, n, batch, Rm, ldrm, strideRm, core, stride_core, R, ldr, strideR,
+                                   workspace, workspace_bytes, (hipStream_t)stream, expo_acc);
 }
 
 int ttr_qr_factor_pushed_sum(int dtype, int64_t k, int64_t I, int64_t batch, const void* Rm, int64_t ldrm,

@@ -79,6 +79,10 @@ struct QrLevel {
   int sumRa, sumCa;
   long long* dbg;      // optional: cycle stamps of block (dbg_bx, dbg_by) at phase boundaries (diagnostics)
   int dbg_bx, dbg_by;
+  // TOP level, fp32 (optional): the user's R is left at the exponent the block was factored at -- R 2^-e with e the exponent of
+  // the top block's largest entry, always taken -- and e is ADDED to expo_acc[item]: the per-core power-of-two normalisation of a
+  // rounding sweep (ttr_pow2_normalize after every factorisation: 8 launches per 64^8 train) without a launch of its own.
+  int32_t* expo_acc;
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -424,7 +428,12 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     lds_barrier();  // Ss is reused by the panels
     if (bm > T(0) && bm < T(3e38)) {
       (void)frexpf((float)bm, &bexp);
-      if (bexp > -8 && bexp < 8) bexp = 0;  // already O(1): leave the data alone
+      if (!(!PUSHED && p.top && p.expo_acc) && bexp > -8 && bexp < 8) bexp = 0;  // already O(1): leave the data alone
+    }
+    // (QrLevel::expo_acc; not in the PUSHED instances -- the metric's level-0 kernel sits at its register cap, and a pushed
+    // factorisation that is its own top level is a small one: factor_run normalises its R with a launch of its own)
+    if constexpr (!PUSHED) {
+      if (p.top && p.expo_acc && tid == 0) p.expo_acc[bt] += bexp;   // (one block per item at the top; R keeps the exponent, see below)
     }
     if (bexp != 0) {
 #pragma unroll
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           T rv;
           if constexpr (PAIR) rv = (lane <= c && lane < kb) ? (cc == 0 ? pcv[0][0].x : pcv[1][0].x) : T(0);
           else rv = (lane <= c && lane < kb) ? pc[cc][0] : T(0);
-          if constexpr (sizeof(T) == 4) { if (bexp != 0) rv = ldexpf((float)rv, bexp); }
+          if constexpr (sizeof(T) == 4) { if (bexp != 0 && !(!PUSHED && p.top && p.expo_acc)) rv = ldexpf((float)rv, bexp); }
           Ro[(int64_t)lane * p.ldr + c] = rv;
         }
       }
@@ -1391,7 +1400,33 @@ struct Pushed {  // level-0 operands of a fused push (nullptr Rm: plain factoris
   int64_t strideCn2 = 0;
   int sumRa = 0, sumCa = 0;
   int k = 0, Rin = 0, I = 0;
+  int32_t* expo_acc = nullptr;  // QrLevel::expo_acc of the top level (plain factorisations too)
 };
+
+// R <- R 2^-e in place, e = exponent of the item's largest entry, expo_acc[item] += e: the top level of a PUSHED factorisation
+// that has a single level (a handful of mode indices: never the hot path) -- see QrLevel::expo_acc
+template <typename T>
+__global__ __launch_bounds__(256) void r_expo_kernel(T* __restrict__ R, int rows, int n, int64_t ldr, int64_t strideR,
+                                                     int32_t* __restrict__ expo_acc) {
+  __shared__ float red[4];
+  const int64_t bt = blockIdx.x;
+  T* __restrict__ Rb = R + bt * strideR;
+  float mx = 0.f;
+  for (int idx = threadIdx.x; idx < rows * n; idx += 256) mx = fmaxf(mx, fabsf((float)Rb[(int64_t)(idx / n) * ldr + idx % n]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int e = 0;
+  if (mx > 0.f && mx < 3e38f) (void)frexpf(mx, &e);
+  if (e != 0)
+    for (int idx = threadIdx.x; idx < rows * n; idx += 256) {
+      T* q = Rb + (int64_t)(idx / n) * ldr + idx % n;
+      *q = (T)ldexpf((float)*q, -e);
+    }
+  if (threadIdx.x == 0) expo_acc[bt] += e;
+}
 
 template <typename T, int NT>
 static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* R, int64_t ldr,
@@ -1416,6 +1451,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.tau = ws + pl.off_tau[l];
     p.Tg = ws + pl.off_tg[l];
     p.top = (l == L - 1);
+    p.expo_acc = (p.top && !(l == 0 && pu.Rm)) ? pu.expo_acc : nullptr;
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     const bool pushed = (l == 0 && pu.Rm);
@@ -1447,6 +1483,14 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
         const double by[4] = {rd, rd, 0.0, 0.0};
         work_items(TTR_PROF_QR_FACTOR, p.pack_flag, nullptr, batch, fl, by, stream);
       }
+    }
+  }
+  if (pu.expo_acc && pu.Rm && L == 1) {   // (the pushed kernel was its own top level)
+    if constexpr (sizeof(T) == 4) {
+      const int64_t mt = (int64_t)pu.k * pu.I;
+      ProfScope prof(TTR_PROF_QR_FACTOR, stream);
+      hipLaunchKernelGGL(r_expo_kernel<T>, dim3((unsigned)batch), dim3(256), 0, stream, R, (int)(mt < n ? mt : n), n, ldr, strideR,
+                         pu.expo_acc);
     }
   }
   TTR_HIP_CHECK(hipGetLastError());
@@ -1503,6 +1547,7 @@ static int factor_typed(int64_t m, int64_t n, int64_t batch, const void* A, int6
       if (ps.Rm) ps.Rm = (const T*)ps.Rm + b0 * ps.strideRm;
       if (ps.Cn) ps.Cn = (const T*)ps.Cn + b0 * ps.strideCn;
       if (ps.Cn2) ps.Cn2 = (const T*)ps.Cn2 + b0 * ps.strideCn2;
+      if (ps.expo_acc) ps.expo_acc += b0;
       const int rc = factor_typed<T>(m, n, nb, A ? (const void*)((const T*)A + b0 * strideA) : nullptr, lda, strideA,
                                      (T*)R + b0 * strideR, ldr, strideR, wsp, wsb, ps, stream, a_cs);
       if (rc != TTR_OK) return rc;
@@ -1562,10 +1607,13 @@ static int apply_typed(int64_t m, int64_t n, int64_t batch, void* ws, int64_t ws
 int qr_max_cols(int) { return 64; }
 
 int qr_factor_dispatch(int dtype, int64_t m, int64_t n, int64_t batch, const void* A, int64_t lda, int64_t strideA,
-                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs) {
+                       void* R, int64_t ldr, int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t a_cs,
+                       int32_t* expo_acc) {
   TTR_REQUIRE(n <= qr_max_cols(dtype), TTR_E_UNSUPPORTED, "ttr_qr: n = %lld exceeds the %d-column panel kernel",
               (long long)n, qr_max_cols(dtype));
-  const Pushed none;
+  TTR_REQUIRE(!expo_acc || dtype == TTR_F32, TTR_E_UNSUPPORTED, "ttr_qr_factor: expo_acc is an fp32 facility");
+  Pushed none;
+  none.expo_acc = expo_acc;
   if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream, a_cs);
   return factor_typed<double>(m, n, batch, A, lda, strideA, R, ldr, strideR, ws, ws_bytes, none, stream, a_cs);
 }
@@ -1610,12 +1658,14 @@ static int pushed_ok(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n) {
 
 int qr_factor_pushed_dispatch(int dtype, int64_t k, int64_t Rin, int64_t I, int64_t n, int64_t batch, const void* Rm,
                               int64_t ldrm, int64_t strideRm, const void* Cn, int64_t strideCn, void* R, int64_t ldr,
-                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                              int64_t strideR, void* ws, int64_t ws_bytes, hipStream_t stream, int32_t* expo_acc) {
   const int rc = pushed_ok(dtype, k, Rin, I, n);
   if (rc != TTR_OK) return rc;
+  TTR_REQUIRE(!expo_acc || dtype == TTR_F32, TTR_E_UNSUPPORTED, "ttr_qr_factor_pushed: expo_acc is an fp32 facility");
   Pushed pu;
   pu.Rm = Rm; pu.ldrm = ldrm; pu.strideRm = strideRm; pu.Cn = Cn; pu.strideCn = strideCn;
   pu.k = (int)k; pu.Rin = (int)Rin; pu.I = (int)I;
+  pu.expo_acc = expo_acc;
   const int64_t m = pushed_rows(I, dtype);
   if (dtype == TTR_F32) return factor_typed<float>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);
   return factor_typed<double>(m, n, batch, nullptr, 0, 0, R, ldr, strideR, ws, ws_bytes, pu, stream);

@@ -82,7 +82,7 @@ int make_sweep_plan(int dtype, int64_t N, const int64_t* shapes, const int64_t* 
     p.kq[mu] = m < n ? m : n;
     p.off_qr[mu] = take(off, p.qr_wsb[mu]);
     p.off_R[mu] = take(off, batch * p.kq[mu] * n * p.es);
-    p.off_Rn[mu] = dtype == TTR_F32 ? take(off, batch * p.kq[mu] * n * p.es) : p.off_R[mu];
+    p.off_Rn[mu] = p.off_R[mu];   // (rounds 1 - 4: a second buffer for the normalised R; the factor kernel normalises in place now)
     k = p.kq[mu];
   }
   p.rows_k[N - 1] = k;
@@ -231,20 +231,20 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
     const int64_t n = p.r1[mu], k = p.rows_k[mu], kq = p.kq[mu];
     void* R = ws + p.off_R[mu];
     void* qws = ws + p.off_qr[mu];
+    // fp32: every R back to O(1) by an exact power of two per item, exponents summed on the device (_round_tt_sweep) -- by the
+    // factor kernel itself (ABI 11: no ttr_pow2_normalize launch per core)
     if (mu == 0) {
       const int64_t m = k * p.I[0];
-      TTR_TRY(ttr_qr_factor(dt, m, n, B, cores_in[0], n, m * n, R, n, kq * n, qws, p.qr_wsb[0], st));
+      if (f32) TTR_TRY(ttr_qr_factor_expo(dt, m, n, B, cores_in[0], n, m * n, R, n, kq * n, qws, p.qr_wsb[0], expo, st));
+      else TTR_TRY(ttr_qr_factor(dt, m, n, B, cores_in[0], n, m * n, R, n, kq * n, qws, p.qr_wsb[0], st));
+    } else if (f32) {
+      TTR_TRY(ttr_qr_factor_pushed_expo(dt, k, p.r0[mu], p.I[mu], n, B, Rprev, p.r0[mu], k * p.r0[mu], cores_in[mu],
+                                        p.r0[mu] * p.I[mu] * n, R, n, kq * n, qws, p.qr_wsb[mu], expo, st));
     } else {
       TTR_TRY(ttr_qr_factor_pushed(dt, k, p.r0[mu], p.I[mu], n, B, Rprev, p.r0[mu], k * p.r0[mu], cores_in[mu],
                                    p.r0[mu] * p.I[mu] * n, R, n, kq * n, qws, p.qr_wsb[mu], st));
     }
-    if (f32) {  // every R back to O(1) by an exact power of two per item, exponents summed on the device (_round_tt_sweep)
-      void* Rn = ws + p.off_Rn[mu];
-      TTR_TRY(ttr_pow2_normalize(dt, kq * n, B, R, kq * n, Rn, kq * n, escr, expo, st));
-      Rprev = Rn;
-    } else {
-      Rprev = R;
-    }
+    Rprev = R;
   }
   // the first truncation's carry M = R x (last core)
   const int64_t cM = p.rows_k[N - 1], cK = p.r0[N - 1], cN = p.I[N - 1] * p.r1[N - 1];
