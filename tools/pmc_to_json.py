@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kind_of(name):
-    if "qr_factor_kernel" in name:
+    if "qr_factor_kernel" in name or "r_expo_kernel" in name:   # (r_expo: the normalisation of a single-level pushed factorisation, timed as qr_factor)
         return "qr_factor"
     if "qr_apply_kernel" in name:
         return "qr_apply"
