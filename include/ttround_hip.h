@@ -633,10 +633,12 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      lie below the resolution (sigma ~ 2^-j), nothing measurable on one without dead directions at that size
  *                      (the launches that exit at once cost 0.3 - 2 % at 1024 items: hence the threshold). */
 #define TTR_KNOB_ORTH_SPLIT 15
-/*   TTR_KNOB_EIGH_SMALL  1 (default) = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
+/*   TTR_KNOB_EIGH_SMALL  1 = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items
- *                      itself (A/B). */
+ *                      itself (A/B); 2 (default) = 1, and fp32 ttr_eigh_top launches of >= 1024 matrices use a build of the 32-row
+ *                      instance capped at 168 VGPRs (three waves per SIMD, 44 spilled registers; 3: 128 VGPRs, four waves) --
+ *                      same results bit for bit, 17 % less eigensolver time at B = 4096. */
 #define TTR_KNOB_EIGH_SMALL 8
 int ttr_debug_set_knob(int knob, int value);
 int ttr_prof_enable(int on);   /* 0 = off, 1 = per-kind device times, 2 = times + executed-work census (ttr_prof_collect_work) */

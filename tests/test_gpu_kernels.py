@@ -1136,6 +1136,31 @@ def test_eigh_top_zero_tail_is_solved_as_the_leading_block(dt, r, parts):
     assert float(Vc[b, 40, :k].abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("r", [32, 20])
+def test_eigh_top_large_launches_use_a_build_at_higher_occupancy_with_the_same_bits(r):
+    """fp32 ttr_eigh_top launches of >= 1024 matrices run the 32-row instance from a build capped at 168 VGPRs (three waves per SIMD,
+    spilled registers; TTR_KNOB_EIGH_SMALL = 2, the default; 3: 128 VGPRs): flat, declined (graded) and full-size items come out
+    BIT-identical to the spill-free build (1) -- eigenvectors, singular values, ranks and flags."""
+    h = _hip()
+    B, n = 1100, 64
+    g = torch.Generator().manual_seed(500 + r)
+    rows = torch.zeros(B, n, 96, dtype=torch.float64)
+    rows[:, :32] = torch.randn(B, 32, 96, generator=g, dtype=torch.float64)
+    rows[::7, :32] *= (2.0 ** (-0.5 * torch.arange(32, dtype=torch.float64)))[None, :, None]     # graded: declined
+    rows[5::11, 40] = 0.5 * torch.randn(len(range(5, B, 11)), 96, generator=g, dtype=torch.float64)   # full-size items
+    G = (rows @ rows.transpose(1, 2)).to(torch.float32).cuda()
+    out = {}
+    try:
+        for v in (1, 2, 3):
+            h.set_knob(h.KNOB_EIGH_SMALL, v)
+            out[v] = [x.clone() for x in h.eigh_top(G, r, 0.125)]
+    finally:
+        h.set_knob(h.KNOB_EIGH_SMALL, 2)
+    assert 0 < int((out[1][3] == 1).sum()) < B
+    for v in (2, 3):
+        assert all(torch.equal(a, b) for a, b in zip(out[1], out[v])), v
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_eigh_top_declines_what_it_cannot_certify(dt):
     """Graded kept spectra, exactly and nearly multiple eigenvalues, identity, zero: flag 0 and the QL phase of the same launch

@@ -1804,7 +1804,7 @@ int ttr_debug_set_knob(int knob, int value) {
       g_qr_dbg_by = value;
       return TTR_OK;
     case TTR_KNOB_EIGH_SMALL:
-      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 1]", value);
+      TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: small-eigensolver switch %d outside [0, 3]", value);
       g_eigh_small = value;
       return TTR_OK;
     case TTR_KNOB_ORTH_SPLIT:

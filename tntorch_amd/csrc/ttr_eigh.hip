@@ -582,8 +582,8 @@ using IC2 = std::integral_constant<int, I>;
 // It runs first (top-r launches and plain QL launches on Gram matrices alike); items without a zero tail get info[b] = -1 and are
 // solved by the NMAX = 64 launch that follows, which skips everything else (items the top-r path declines fall through to the QL phase of their own launch, as ever: handing them to the
 // second launch made it as long as its slowest block -- 171 us per launch at B = 2048 for ~1 % of the items, measured).
-template <typename T, bool TOP = false, int NMAX = 64>
-__global__ __launch_bounds__(2 * kWave, (sizeof(T) == 4 && NMAX == 64 ? 4 : 2)) void eigh_tridiag_kernel(EighArgs<T> p) {
+template <typename T, bool TOP = false, int NMAX = 64, int MINW = 0>
+__global__ __launch_bounds__(2 * kWave, (MINW > 0 ? MINW : (sizeof(T) == 4 && NMAX == 64 ? 4 : 2))) void eigh_tridiag_kernel(EighArgs<T> p) {
   static_assert(NMAX == 64 || NMAX == 32, "64-row kernel and its 32-row instance");
   constexpr int NT = NMAX / 16;   // 16-row tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1594,7 +1594,8 @@ int g_rank_noise_c = 0;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): se
 // per step), 0.38 instead of 0.26 ms at n_live = 18 -- a round of the parallel-order Jacobi is ~7000 scattered LDS accesses, not
 // synchronisation: a quarter of the lanes take longer over them than the barriers of four waves cost.  Kept for the A/B.
 int g_jacobi_live_wave = 0;
-int g_eigh_small = 1;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL, 0): no separate 32-row launch (A/B)
+int g_eigh_small = 2;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL): 0 = no separate 32-row launch, 1 = the 32-row instance, 2 (default) / 3 = and its
+                        // large fp32 top-r launches at three / four waves per SIMD (A/B)
 template <typename T>
 static int eigh_typed(int dtype, int64_t n, int64_t batch, const void* G, int64_t ldg, int64_t strideG, int64_t gparts,
                       int64_t stride_gpart, void* V,
@@ -1700,7 +1701,17 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
 #endif
   ProfScope prof(TTR_PROF_EIGH, stream);
   if (n == 64 && g_eigh_small) {   // zero-tail items first, in the 32-row instance (see the kernel)
-    hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
+    // Large fp32 launches go through a build capped at 168 VGPRs (TTR_KNOB_EIGH_SMALL = 2, the default; 3: 128): the instance needs
+    // 210 registers, i.e. two waves per SIMD = FOUR matrices per CU at a time, each of them latency-bound -- three waves per SIMD
+    // with 44 spilled registers (four: 124) is the faster trade from 1024 matrices per launch on (B = 4096: eigh 3.75 -> 3.13 ms
+    // per step of event time, the step 24.91 -> 24.77 ms, bit-identical results: profiles/r05_eigh_occ_ab.txt); a single matrix
+    // keeps the spill-free build.
+    if (sizeof(T) == 4 && g_eigh_small == 2 && batch >= 1024)
+      hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32, 3>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
+    else if (sizeof(T) == 4 && g_eigh_small == 3 && batch >= 1024)
+      hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32, 4>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
+    else
+      hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 32>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), 32), stream, p);
     TTR_HIP_CHECK(hipGetLastError());
     p.top_pre = 1;
   }
@@ -1759,3 +1770,4 @@ int eigh_pairs_dispatch(int dtype, int64_t b, int64_t npairs, int64_t items, con
 }
 
 }  // namespace ttr
+
