@@ -16,6 +16,7 @@ gathers the rounded cores on rank 0 with a single RCCL gather.
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definition of every field).
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -590,6 +591,14 @@ def main():
 
     sizes = [B] * world
     sched = GatherSchedule(args.gather if dist_on else "none", sizes=sizes, dst=0, local_shortcut=not dist_on)
+    # N > 1: the steps are issued from a stream of their own instead of the default stream.  Measured on one GPU
+    # (tools/probes/dist_overhead_probe.py, profiles/r05_dist_overhead.txt): with a live RCCL communicator the same step costs
+    # 27.3 - 27.4 ms instead of 24.8 - 25.0 when it is enqueued from the default stream (destroying the process group restores
+    # it; gloo and a lazily initialised nccl group cost nothing), and 24.95 ms from a (high-priority) stream of its own.
+    work_stream = torch.cuda.Stream(device=dev, priority=-1) if (dist_on and os.environ.get("TTR_BENCH_WORK_STREAM", "1") != "0") else None
+
+    def on_work_stream():
+        return torch.cuda.stream(work_stream) if work_stream is not None else contextlib.nullcontext()
     inflight = []  # completion events of the steps enqueued so far
     step_events = []  # all of them, for the per-step device times reported in the JSON line
     host_ms = []      # host time spent enqueuing each step
@@ -603,19 +612,21 @@ def main():
         if len(inflight) >= int(os.environ.get("TTR_BENCH_RUNAHEAD", "2")):
             inflight.pop(0).synchronize()
         h0 = time.perf_counter()
-        t = tn.Tensor(inp, batch=True)
-        t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
-        host_ms.append(round((time.perf_counter() - h0) * 1e3, 2))
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        inflight.append(ev)
-        step_events.append(ev)
-        sched.after_step(t)   # `step`: start this step's gather (after the previous one completed); `end` / `none`: nothing moves
+        with on_work_stream():
+            t = tn.Tensor(inp, batch=True)
+            t.round_tt(rmax=R_OUT, algorithm=args.algorithm)
+            host_ms.append(round((time.perf_counter() - h0) * 1e3, 2))
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            inflight.append(ev)
+            step_events.append(ev)
+            sched.after_step(t)   # `step`: start this step's gather (after the previous one completed); `end` / `none`: nothing moves
         return t
 
     def drain():
         """Everything the root is owed has arrived when this returns (called inside the timed region): `end` = THE gather."""
-        return sched.drain()
+        with on_work_stream():   # (the collective orders itself behind the stream that produced the cores)
+            return sched.drain()
 
     def fence():
         torch.cuda.synchronize()
@@ -641,7 +652,8 @@ def main():
         per_peer = sum(c.numel() * c.element_size() for c in out.cores)
         fence()
         g0 = time.perf_counter()
-        gather_batch(out, dst=0, sizes=sizes, async_op=False, local_shortcut=False).wait()
+        with on_work_stream():
+            gather_batch(out, dst=0, sizes=sizes, async_op=False, local_shortcut=False).wait()
         fence()
         g_ms = (time.perf_counter() - g0) * 1e3
         # ... and the steps ALONE (no gather at all), same fences: with `end` the timed region is steps * compute_only + one gather
@@ -658,6 +670,7 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info()
         gather_info = {"mode": args.gather, "collectives_in_timed_region": sched.gathers_timed, "bytes_per_peer_per_step": per_peer,
                        "peers": world - 1, "alone_ms": g_ms, "compute_only_ms_per_step": c_ms,
+                       "steps_on_own_stream": work_stream is not None,
                        # `step`: the gather of step k has to hide under the compute of step k + 1 -- if it does not, the job is link-bound
                        "hidden_under_compute": bool(g_ms < c_ms) if args.gather == "step" else None,
                        "root_inbound_GBs": per_peer * max(world - 1, 1) / g_ms / 1e6, "per_link_GBs": per_peer / g_ms / 1e6,
