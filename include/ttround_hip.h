@@ -413,9 +413,14 @@ int ttr_rowgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, i
 int64_t ttr_qr_pushed_flag_offset(int dtype, int64_t I, int64_t n, int64_t batch);
 /* The same flags for a carry that no fused push follows -- the LAST core of the left-to-right sweep, tensor.py:2053-2056's first
  * truncation: flag[b] = 1 when rows 32.. of the 64 x cols matrix R[b] hold at most (c eps)^2 of ||R[b]||_F^2 (c =
- * TTR_KNOB_QR_RANK_SKIP; the packing test of ttr_qr_factor_pushed).  The caller then hands `flag` to ttr_rowgram / ttr_rotgram /
- * ttr_project as `rows32` for M = R x (last core): rows 32.. of M are below c eps ||M|| and are treated as zero, exactly as the
- * packed push treats them at every other bond (ABI 9). */
+ * TTR_KNOB_QR_RANK_SKIP; the packing test of ttr_qr_factor_pushed).  Since round 5 the sweep (tntorch_amd/_hipops.py, ttr_round_tt)
+ * calls it ON THE CARRY ITSELF, M = R_{N-2} x (last core) as a 64 x (I r) matrix, not on the R factor: what ttr_rowgram /
+ * ttr_rotgram / ttr_project then treat as zero (`rows32`) is below c eps ||M||_F whatever the last core's condition number is --
+ * but it is DROPPED energy, not a structural zero: rows 32.. of M are non-zero in memory.  The eps-mode rank rule accounts for it
+ * through the noise floor (TTR_KNOB_RANK_NOISE_FLOOR, default 1: sigma[32..] count as eps sigma_0 and ttr_spectrum_flat tests the
+ * whole spectrum with its robustness margin E = 64 n eps sigma_0^2 >= (c eps)^2 ||M||^2); with the floor switched off the 32
+ * trailing values are exact zeros to the rule and a tolerance below c eps (fp64, eps < 2e-15) may select fewer directions than
+ * LAPACK's (ABI 9). */
 int ttr_carry_rows32(int dtype, int64_t cols, int64_t batch, const void* R, int64_t ldr, int64_t strideR, int32_t* flag,
                      void* stream);
 int ttr_rotgram(int dtype, int64_t R, int64_t n, int64_t batch, const void* M, int64_t ldm, int64_t strideM,
@@ -596,13 +601,13 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      workgroups); 0 = never (required for ttr_qr_apply_pushed_gram, whose epilogue assumes the unpacked map). */
 #define TTR_KNOB_QR_PACK 7
 /*   (8 = TTR_KNOB_EIGH_SMALL, below)
- *   TTR_KNOB_RANK_NOISE_FLOOR  c (default 0 = off): the rank rule of round.py:147-158 (eps mode: ttr_eigh_trunc with use_delta,
- *                      ttr_spectrum_flat) sees every singular value at no less than c eps sigma_0.  Background: the zero-tail
- *                      eigenproblems of a rank-deficient bond (t = g + g) return EXACT zeros for the null directions, which the
- *                      rule cuts at any delta >= 0; LAPACK's gesdd -- the reference -- returns rounding noise of order eps sigma_0
- *                      there, so `round_tt(rmax=48)` (eps = 1e-14 by default) on a numerically rank-32 fp32 train keeps 32..48
- *                      directions depending on that noise.  c = 1 reproduces the reference's usual outcome (fp32: the cap;
- *                      fp64: eps^2 < 1e-28, still cut); tntorch_amd sets it from TTR_STRICT_RANKS=1. */
+ *   TTR_KNOB_RANK_NOISE_FLOOR  c (default 1 since round 6; 0 = off): the rank rule of round.py:147-158 (eps mode: ttr_eigh_trunc
+ *                      with use_delta, ttr_spectrum_flat) sees every singular value at no less than c eps sigma_0.  Background: the
+ *                      zero-tail eigenproblems of a rank-deficient bond (t = g + g) return EXACT zeros for the null directions, which
+ *                      the rule would cut at any delta >= 0; LAPACK's gesdd -- the reference -- returns rounding noise of order
+ *                      eps sigma_0 there, so `round_tt(rmax=48)` (eps = 1e-14 by default) on a numerically rank-32 fp32 train keeps
+ *                      the cap.  c = 1 reproduces the reference's outcome (fp32: the cap; fp64: eps^2 < 1e-28, still cut);
+ *                      TTR_STRICT_RANKS=0 in the environment of tntorch_amd sets 0. */
 #define TTR_KNOB_RANK_NOISE_FLOOR 9
 /*   TTR_KNOB_ORTH_ROUNDS  (default 4) upper bound on the rounds of ttr_orth_fixup's block variant (diagnostics: what a round costs;
  *                      fewer than the data needs leaves the completed directions short of orthonormal).  In census mode
@@ -633,6 +638,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      lie below the resolution (sigma ~ 2^-j), nothing measurable on one without dead directions at that size
  *                      (the launches that exit at once cost 0.3 - 2 % at 1024 items: hence the threshold). */
 #define TTR_KNOB_ORTH_SPLIT 15
+/*   TTR_KNOB_QR_STAGGER  k (default 0 = off; round 6, A/B): workgroups 256 .. 511 of a fused push + factor launch (the second
+ *                      resident block of every CU under round-robin dispatch) start k x 1024 cycles late, so that a CU's two blocks
+ *                      alternate their HBM phase (the push) and their panel chain instead of running them side by side. */
+#define TTR_KNOB_QR_STAGGER 16
 /*   TTR_KNOB_EIGH_SMALL  1 = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

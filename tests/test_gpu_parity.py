@@ -708,35 +708,42 @@ def test_mixed_rank_batch_vs_oracle():
         assert all(((x - y).abs().max() / y.max()).item() <= 2e-5 for x, y in zip(so, sr)), i
 
 
-def test_strict_ranks_switch_restores_the_reference_ranks_of_null_directions():
-    """TTR_STRICT_RANKS=1 (= ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, 1)): the eps-mode rank rule sees the null directions
-    of a rank-deficient bond at LAPACK's noise level eps sigma_0 instead of the exact zeros of the zero-tail eigenproblem, so the
-    NON-batch `round_tt(rmax=48)` (eps = 1e-14, tensor.py:2008-2014) of a numerically rank-32 fp32 train keeps the cap like the
-    reference (round.py:147-158 on gesdd's output) and like batch mode; fp64 still cuts them (eps^2 < 1e-28), as LAPACK's do."""
+def test_reference_ranks_of_null_directions_are_the_default_and_the_switch_turns_them_off():
+    """The eps-mode rank rule sees the null directions of a rank-deficient bond at LAPACK's noise level eps sigma_0
+    (TTR_KNOB_RANK_NOISE_FLOOR = 1, the library's default since round 6) instead of the exact zeros of the zero-tail
+    eigenproblem, so the NON-batch `round_tt(rmax=48)` (eps = 1e-14, tensor.py:2008-2014) of a numerically rank-32 fp32 train keeps
+    the cap like the reference (round.py:147-158 on gesdd's output) and like batch mode; fp64 still cuts them (eps^2 < 1e-28), as
+    LAPACK's do.  TTR_STRICT_RANKS=0 (knob = 0) cuts exact zeros: the numerical rank."""
     from tntorch_amd import _hip
     N, I = 5, 64
     torch.manual_seed(7)
     g = oracle.tt_randn([I] * N, 32, dtype=torch.float32)
     it = [c / c.abs().max() for c in oracle.tt_add(g, g)]
     ref = oracle.round_tt([c.clone() for c in it], rmax=48, algorithm="svd")
-    _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 1)
+    t = gpu_tensor(it)
+    t.round_tt(rmax=48)
+    ours = to_list(t.cores)
+    assert ranks(ours) == [1] + [48] * (N - 1) + [1]
+    assert all(a == b for a, b in zip(ranks(ours), ranks(ref)) if b in (1, 48))   # (the oracle: 48 wherever LAPACK's noise is nonzero)
+    assert all(a >= b for a, b in zip(ranks(ours), ranks(ref)))
+    assert tt_rel_err(ours, it) <= 1e-5 and _right_orth_err(ours) <= 5e-5
+    t64 = gpu_tensor([c.double() for c in it])
+    t64.round_tt(rmax=48)
+    r64 = oracle.round_tt([c.double() for c in it], rmax=48, algorithm="svd")
+    assert ranks(to_list(t64.cores)) == ranks(r64) == [1] + [32] * (N - 1) + [1]
+    # a full-rank train is untouched by the switch
+    h = oracle.tt_randn([I] * 4, 40, dtype=torch.float32)
+    a = gpu_tensor([c.clone() for c in h]); a.round_tt(eps=1e-3)
+    _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 0)
     try:
-        t = gpu_tensor(it)
-        t.round_tt(rmax=48)
-        ours = to_list(t.cores)
-        assert ranks(ours) == [1] + [48] * (N - 1) + [1]
-        assert all(a >= b for a, b in zip(ranks(ours), ranks(ref)))        # (the oracle: 48 wherever LAPACK's noise is nonzero)
-        assert tt_rel_err(ours, it) <= 1e-5 and _right_orth_err(ours) <= 5e-5
-        t64 = gpu_tensor([c.double() for c in it])
-        t64.round_tt(rmax=48)
-        r64 = oracle.round_tt([c.double() for c in it], rmax=48, algorithm="svd")
-        assert ranks(to_list(t64.cores)) == ranks(r64) == [1] + [32] * (N - 1) + [1]
-        # a full-rank train is untouched by the switch
-        h = oracle.tt_randn([I] * 4, 40, dtype=torch.float32)
-        a = gpu_tensor([c.clone() for c in h]); a.round_tt(eps=1e-3)
+        b = gpu_tensor([c.clone() for c in h]); b.round_tt(eps=1e-3)
+        # switched off: exact zeros are cut by the same rule at any delta >= 0 -- the numerical rank, the same tensor
+        z = gpu_tensor(it)
+        z.round_tt(rmax=48)
+        assert ranks(to_list(z.cores)) == [1] + [32] * (N - 1) + [1]
+        assert tt_rel_err(to_list(z.cores), it) <= 2e-5
     finally:
-        _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 0)
-    b = gpu_tensor([c.clone() for c in h]); b.round_tt(eps=1e-3)
+        _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 1)
     assert ranks(to_list(a.cores)) == ranks(to_list(b.cores))
     assert all(torch.equal(x, y) for x, y in zip(a.cores, b.cores))
 
@@ -745,7 +752,8 @@ def test_strict_ranks_switch_restores_the_reference_ranks_of_null_directions():
 def test_rank_cap_above_the_numerical_rank_of_a_packed_train(batch):
     """rmax = 48 on a train of numerical rank 32 in 64 (g + g): every bond packs, its Gram matrix is solved as a 32 x 32 problem
     (V = blockdiag(V11, I), sigma[32:] = 0), and 16 of the 48 directions under the cap are null -- batch mode keeps them
-    (orthonormal completion); the non-batch call applies the reference's rank rule to exact zeros (see below)."""
+    (round.py:149-150), and so does the non-batch call: the rank rule (round.py:147-158) sees them at LAPACK's noise level
+    eps sigma_0, as the reference's gesdd returns them.  Batch and non-batch calls agree with each other and with the oracle."""
     N, I = 5, 64
     torch.manual_seed(7)
     g = oracle.tt_randn([I] * N, 32, dtype=torch.float32)
@@ -757,13 +765,10 @@ def test_rank_cap_above_the_numerical_rank_of_a_packed_train(batch):
     t.round_tt(rmax=48)
     ours = to_list(t.cores, 1) if batch else to_list(t.cores)
     ref = oracle.round_tt([c.clone() for c in it], rmax=48, algorithm="svd")
-    if batch:
-        assert ranks(ours) == [1] + [48] * (N - 1) + [1]     # round.py:149-150: batch mode keeps the cap
-    else:
-        # round.py:147-158 with delta = 0 cuts singular values that are EXACTLY zero.  The oracle's LAPACK returns 1e-7-level
-        # noise for the 16 null directions and keeps them (rank 48); here they are exact zeros (zero-tail Gram matrix) and
-        # the same rule cuts them: the numerical rank, never more than the reference's
-        assert all(32 <= r <= 48 for r in ranks(ref)[1:-1]) and ranks(ours) == [1] + [32] * (N - 1) + [1]   # (oracle: 48 where LAPACK's noise is nonzero)
+    assert ranks(ours) == [1] + [48] * (N - 1) + [1]
+    # the oracle's LAPACK returns 1e-7-level noise for the 16 null directions and keeps them: 48 wherever that noise is nonzero
+    assert all(32 <= r <= 48 for r in ranks(ref)[1:-1])
+    assert all(a == b for a, b in zip(ranks(ours), ranks(ref)) if b in (1, 48))
     assert tt_rel_err(ours, it) <= 2e-5
     assert _right_orth_err(ours) <= 5e-5
 
@@ -1818,6 +1823,19 @@ def test_from_dense_consuming_matches_constructor(kind, monkeypatch):
     assert not torch.equal(Xd.cpu(), X)      # (the input really was consumed)
     with pytest.raises(ValueError):
         tn.Tensor.from_dense_consuming(X, r)  # CPU tensors: the constructor is the way
+
+
+def test_from_dense_consuming_with_a_long_last_mode_completes_with_a_warning():
+    """A last mode above the 64 columns of the fused column-sweep kernels has no in-place carry: the call completes through the
+    constructor's path (as in rounds 1 - 4) and says so, instead of raising."""
+    torch.manual_seed(32)
+    X = torch.randn(16, 16, 96, dtype=torch.float32)
+    ref = tn.Tensor(X.cuda(), ranks_tt=8)
+    with pytest.warns(RuntimeWarning, match="last mode > 64"):
+        t = tn.Tensor.from_dense_consuming(X.cuda(), 8)
+    assert list(t.ranks_tt) == list(ref.ranks_tt)
+    for a, b in zip(t.cores, ref.cores):
+        assert torch.equal(a, b)
 
 
 def test_verbose_prints_the_reference_stage_lines_on_device(capsys):

@@ -223,10 +223,11 @@ def lib():
             k, v = item.split("=")
             if L.ttr_debug_set_knob(int(k), int(v)) != 0:
                 raise ValueError(f"TTR_KNOBS: ttr_debug_set_knob({k}, {v}) rejected: " + L.ttr_last_error().decode(errors="replace"))
-        # TTR_STRICT_RANKS=1: eps-mode rank rule with LAPACK's noise floor for null directions (header: TTR_KNOB_RANK_NOISE_FLOOR;
-        # INTEGRATION.md "Ranks of rank-deficient trains")
-        if os.environ.get("TTR_STRICT_RANKS", "0") == "1":
-            L.ttr_debug_set_knob(9, 1)
+        # The eps-mode rank rule sees null directions at LAPACK's noise floor (header: TTR_KNOB_RANK_NOISE_FLOOR = 1, the library's
+        # default since round 6: the reference's ranks).  TTR_STRICT_RANKS=0 switches the floor off: exact zeros are cut
+        # (INTEGRATION.md "Ranks of rank-deficient trains")
+        if os.environ.get("TTR_STRICT_RANKS", "1") == "0":
+            L.ttr_debug_set_knob(9, 0)
         # TTR_ORTH_SPLIT=<batch size>: ttr_orth_fixup's three-launch rounds from that batch size on (header: TTR_KNOB_ORTH_SPLIT)
         if os.environ.get("TTR_ORTH_SPLIT", "") != "":
             L.ttr_debug_set_knob(15, int(os.environ["TTR_ORTH_SPLIT"]))
@@ -1071,6 +1072,7 @@ KNOB_QR_RANK_SKIP = 6
 KNOB_QR_PACK = 7
 KNOB_EIGH_SMALL = 8
 KNOB_RANK_NOISE_FLOOR = 9
+KNOB_QR_STAGGER = 16
 KNOB_ORTH_ROUNDS = 10
 KNOB_JACOBI_LIVE_WAVE = 11
 KNOB_ORTH_V2 = 12

@@ -1225,8 +1225,13 @@ def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> O
     ranks_dev = torch.empty(N - 1, dtype=torch.int32, device=dev) if eps_mode else None
     zf = torch.empty(1, dtype=torch.int32, device=dev) if (zflags is not None and not eps_mode) else None
     use_top = EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0
-    _hip.round_tt_sweep([x.contiguous() for x in c], rcap, algorithm, eps_mode, eps if eps is not None else 0.0,
-                        max(FLAT_SPECTRUM_THR, 0.0), use_top, outs, ranks_dev, zf, ws)
+    try:
+        _hip.round_tt_sweep([x.contiguous() for x in c], rcap, algorithm, eps_mode, eps if eps is not None else 0.0,
+                            max(FLAT_SPECTRUM_THR, 0.0), use_top, outs, ranks_dev, zf, ws)
+    except NotImplementedError:
+        # a per-kernel limit the planner does not mirror (TTR_E_UNSUPPORTED from inside the sweep): ttr_round_tt never writes its
+        # inputs, so the loop over the per-kernel entries -- which asks every kernel's own predicate -- starts from the same state
+        return None
     SWEEP_C_CALLS += 1
     if zf is not None:
         zflags.append(_deferred_readback(zf))

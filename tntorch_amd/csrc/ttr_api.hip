@@ -1104,6 +1104,7 @@ extern int g_qr_f64_nw4;
 extern int g_rank_skip_c;
 extern int g_qr_pack;
 extern int g_qr_interleave;
+extern int g_qr_stagger;
 extern int g_sweep_stagger;
 extern int g_rank_noise_c;
 extern int g_jacobi_live_wave;
@@ -1814,6 +1815,10 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_SWEEP_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: stagger mode %d outside [0, 2]", value);
       g_sweep_stagger = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_STAGGER:
+      TTR_REQUIRE(value >= 0 && value <= 1024, TTR_E_INVALID, "ttr_debug_set_knob: stagger of %d kilo-cycles outside [0, 1024]", value);
+      g_qr_stagger = value;
       return TTR_OK;
     case TTR_KNOB_QR_INTERLEAVE:
       TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: interleave switch %d outside [0, 1]", value);

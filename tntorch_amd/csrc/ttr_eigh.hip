@@ -1588,7 +1588,7 @@ int64_t eigh_workspace_bytes(int dtype, int64_t n, int64_t batch) {
   return batch * 2 * n * (n + 1) * (dtype == TTR_F64 ? 8 : 4);
 }
 
-int g_rank_noise_c = 0;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): see rank_rule (ttr_common.h)
+int g_rank_noise_c = 1;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): see rank_rule (ttr_common.h); 1 = the reference's ranks (round 6: the default)
 // ttr_debug_set_knob(TTR_KNOB_JACOBI_LIVE_WAVE, 1): pass 2 with ONE wave per matrix.  REFUTED by measurement (round 5,
 // profiles/r05_decay_probe.txt): 1.25 instead of 0.80 ms per launch of 2048 matrices at n_live = 35 (eigh 14.3 instead of 10.0 ms
 // per step), 0.38 instead of 0.26 ms at n_live = 18 -- a round of the parallel-order Jacobi is ~7000 scattered LDS accesses, not

@@ -83,6 +83,10 @@ struct QrLevel {
   // the top block's largest entry, always taken -- and e is ADDED to expo_acc[item]: the per-core power-of-two normalisation of a
   // rounding sweep (ttr_pow2_normalize after every factorisation: 8 launches per 64^8 train) without a launch of its own.
   int32_t* expo_acc;
+  // PUSHED level 0 (round 6, TTR_KNOB_QR_STAGGER, kilo-cycles; 0 = off): workgroups 256 .. 511 of the launch -- the second resident
+  // block of every CU under round-robin dispatch -- start that much later, so that one block's HBM phase (the push) runs under
+  // the other's panel chain instead of beside its push.
+  int stagger_kc;
 };
 
 // beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha)/beta, scale = 1/(alpha - beta)  (LAPACK larfg).
@@ -176,6 +180,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 
   int dbgi = 0;
   auto stamp = [&]() { if (p.dbg && b == p.dbg_bx && bt == p.dbg_by && tid == 0) p.dbg[dbgi++] = (long long)clock64(); };
+  if constexpr (PUSHED && PAIR) {
+    if (p.stagger_kc > 0) {
+      const int64_t lid = (int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y;
+      if (lid >= 256 && lid < 512) {
+        const long long t0 = clock64();
+        while (clock64() - t0 < (long long)p.stagger_kc * 1024) __builtin_amdgcn_s_sleep(16);
+      }
+    }
+  }
   stamp();
   Acc acc[4][NT];
   if constexpr (PUSHED) {
@@ -1387,6 +1400,7 @@ int g_qr_dbg_bx = 0, g_qr_dbg_by = 0;  // which level-0 block stamps (ttr_debug_
 // what an unpacked block costs and there are half as many); block-major: 1.1 ms, the metric step 20.9 -> 17.5 ms
 // (tools/probes/qr_pack_stamps.py, profiles/r04_qr_pack_ab.txt).  0 = never pack.
 int g_qr_pack = 3;
+int g_qr_stagger = 0;      // ttr_debug_set_knob(TTR_KNOB_QR_STAGGER): see QrLevel::stagger_kc
 int g_qr_interleave = 1;   // ttr_debug_set_knob(TTR_KNOB_QR_INTERLEAVE): see block_of (0 = round 4's block-major order, A/B)
 int g_rank_skip_c = 8;   // ttr_debug_set_knob(TTR_KNOB_QR_RANK_SKIP, c): threshold factor of the rank-revealing early exit (0 = off)
 int g_qr_variant = 1;           // ttr_debug_set_knob(TTR_KNOB_QR_PANEL): 1 = pair steps in the 8-wave blocks (default), 0 = one reflector at a time
@@ -1452,6 +1466,7 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     p.Tg = ws + pl.off_tg[l];
     p.top = (l == L - 1);
     p.expo_acc = (p.top && !(l == 0 && pu.Rm)) ? pu.expo_acc : nullptr;
+    p.stagger_kc = g_qr_stagger;
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     const bool pushed = (l == 0 && pu.Rm);

@@ -73,8 +73,10 @@ int make_sweep_plan(int dtype, int64_t N, const int64_t* shapes, const int64_t* 
     if (mu == 0) {
       p.qr_wsb[mu] = ttr_qr_workspace_bytes(dtype, m, n, batch);
     } else {
-      TTR_REQUIRE(k <= 64 && p.r0[mu] <= 64 && m >= n, TTR_E_UNSUPPORTED,
-                  "ttr_round_tt: core %lld outside the fused push (k = %lld, Rin = %lld, k I = %lld < n = %lld)", (long long)mu,
+      // (the fused push's own envelope, pushed_ok in ttr_qr.hip: all three conditions, so that a train outside it is declined HERE --
+      // TTR_E_UNSUPPORTED from the planner, the caller keeps its loop over the per-kernel entries -- and not in the middle of the sweep)
+      TTR_REQUIRE(k <= 64 && p.r0[mu] <= 64 && m >= n && p.r0[mu] * p.I[mu] * n < (int64_t(1) << 31), TTR_E_UNSUPPORTED,
+                  "ttr_round_tt: core %lld outside the fused push (k = %lld, Rin = %lld, k I = %lld < n = %lld, or Rin I n >= 2^31)", (long long)mu,
                   (long long)k, (long long)p.r0[mu], (long long)m, (long long)n);
       p.qr_wsb[mu] = ttr_qr_pushed_workspace_bytes(dtype, p.I[mu], n, batch);
       if (k == 64) p.flag_off[mu] = ttr_qr_pushed_flag_offset(dtype, p.I[mu], n, batch);

@@ -173,10 +173,15 @@ class Tensor(object):
         rmax = list(ranks_tt) if hasattr(ranks_tt, "__len__") else [ranks_tt] * (N - 1)
         assert len(rmax) == N - 1
         if data.shape[-1] > 64:
-            # (the in-place carry exists for the fused tall kernels, <= 64 columns: silently doubling the memory exactly where the
-            # caller said there is none would be the worst outcome)
-            raise NotImplementedError("from_dense_consuming: the last mode must be <= 64 (the in-place first carry needs the fused "
-                                      "column-sweep kernels); use tn.Tensor(data, ranks_tt=...)")
+            # the in-place carry exists for the fused tall kernels (<= 64 columns).  A longer last mode completes through the
+            # ordinary constructor path -- the behaviour of rounds 1 - 4 -- with the first carry NEXT to the input (peak memory
+            # input x (1 + ranks_tt[-1] / I_N)); the caller is told, since memory is what this entry exists for
+            import warnings
+
+            warnings.warn("from_dense_consuming: last mode > 64, the first carry is written next to the input instead of over it "
+                          f"(+ {rmax[-1]} / {data.shape[-1]} of the input's bytes)", RuntimeWarning, stacklevel=2)
+            cores = _hipops.dense_tt_svd(data[None], 1e-14, rmax, algorithm, False)
+            return cls([c[0] for c in cores])
         cores = _hipops.dense_tt_svd(data[None], 1e-14, rmax, algorithm, False, consume_input=True)
         return cls([c[0] for c in cores])
 
