@@ -1566,9 +1566,20 @@ def test_flat_spectrum_shortcut_in_eps_mode(monkeypatch):
     s64[:, :32] = torch.linspace(1.0, 0.6, 32)
     s64[1, 31] = 1e-3                                                        # kept value far below sigma_1: needs the second pass
     fl = torch.tensor([1, 1], dtype=torch.int32).cuda()
+    # (the structural-zero reading belongs to the rank rule WITHOUT the noise floor, TTR_STRICT_RANKS=0: exact zeros are cut)
+    _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 0)
+    try:
+        assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]
+        assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29).tolist() == [0, 0]
+        assert _hip.spectrum_flat(s64.cuda(), 48, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]     # the cap above the live block
+    finally:
+        _hip.set_knob(_hip.KNOB_RANK_NOISE_FLOOR, 1)
+    # the default (round 6): the rule sees the 32 zeros at eps sigma_1 like LAPACK's noise -- 32 x (1.2e-7)^2 >> delta^2, they are
+    # KEPT by the rule and the cap decides, robustly where the keep-th value carries more than E (item 0), with or without the flag;
+    # a cap of 48 keeps 16 of the noise-level values: far below sigma_1 / 8, the second pass (and the completion) runs
     assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]
-    assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29).tolist() == [0, 0]
-    assert _hip.spectrum_flat(s64.cuda(), 48, 0.125, True, 1e-29, rows32=fl).tolist() == [1, 0]     # the cap above the live block
+    assert _hip.spectrum_flat(s64.cuda(), 32, 0.125, True, 1e-29).tolist() == [1, 0]
+    assert _hip.spectrum_flat(s64.cuda(), 48, 0.125, True, 1e-29, rows32=fl).tolist() == [0, 0]
     monkeypatch.setattr(_hipops, "SWEEP_C_ENABLED", False)   # (below: spies on the host loop's per-kernel calls)
 
     torch.manual_seed(3)

@@ -345,8 +345,131 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           (void)run_pass(-1);
         }
       };
+#ifdef TTR_QR_PUSH_KSTEP
+      // Round 6, measured WITHOUT gain and therefore not compiled by default (tools/build_variant.sh kstep ttr_qr.hip
+      // -DTTR_QR_PUSH_KSTEP; profiles/r06_push_variants.txt): the K-STEP pipeline (whole shapes with a multiple of 8 K steps; fp32
+      // 8-wave PAIR blocks -- the metric's).  Hypothesis: since row packing a pass performs half the MFMAs per byte it loads, and
+      // the group pipeline above -- 16 loads, then a burst of 32 MFMAs during which ONE group is in flight -- would run at one
+      // memory round trip per group.  Here the 32 operand registers are EIGHT K-step slots: step t is consumed from slot t mod 8 and
+      // the slot is refilled at once with step t + 8 (of the next pass when this one ends), so two groups' worth of loads stay in
+      // flight through the MFMAs; same MFMAs in the same order: bit-identical (sha256 of R); a block that may turn out absorbed
+      // requests nothing before it knows (the group pipeline fetches and drops 32 KB).  Result: push 41 - 45 k cycles against
+      // 38 - 45 k, the step 24.88 against 24.89 ms.  The depth of the prefetch is not what paces the phase (push_membench: 1, 2 or 4
+      // groups in flight move the same bytes in the same 12.8 k ticks); without ANY MFMA (-DTTR_QR_PUSH_NOMMA) the phase still takes
+      // 24 k cycles alone on a CU and 37 k under load: ~9 k of fixed work (R staged through LDS, the range guard and the block norm:
+      // five block-wide barriers) + 256 KB at the ~17 B/clk one CU's load path sustains on this pattern.
+      auto stream_ks = [&]() {
+        constexpr int NS = 8;
+        T bq[NS][NT];
+        const T* __restrict__ ldp = Cb + (size_t)imode_u * n + loff;   // the loader's position: lane pointer, advanced per K step
+        const size_t kstride = (size_t)4 * cs;
+        auto load_slot = [&](T (&bs)[NT]) {
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) bs[tn] = ldp[tn * PW];
+          ldp += kstride;
+        };
+        const bool may_absorb = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb && absorbed_blk;
+        bool upper = false;
+        auto decide = [&]() {   // after the barrier that publishes Rs and the waves' partial sums
+          T any = pairt[0], sa = Ss[0], sl = Ss[NW];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) { any += pairt[w]; sa += Ss[w]; sl += Ss[NW + w]; }
+          upper = any == T(0);
+          const T ce = T(p.rank_skip_c) * Num<T>::eps();
+          packed = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb &&
+                   lane_get(sl, 0) <= ce * ce * lane_get(sa, 0);
+        };
+        // A block that may be absorbed decides first and requests its slots afterwards; every other block requests them first (in
+        // flight while Rs is staged).  ONE copy of the 32 requests, in slot order (scheduling barriers): the loop's static vmcnt
+        // counts must hold on the entry path too -- with two copies hipcc ordered one of them differently and every first slot of an
+        // iteration waited for all but 4 loads.
+        if (may_absorb) {
+          lds_barrier();
+          decide();
+          if (packed) return;
+        }
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) { load_slot(bq[sl]); __builtin_amdgcn_sched_barrier(0); }
+        if (!may_absorb) {
+          lds_barrier();
+          decide();
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::zero();
+        const int total = packed ? 2 * ksteps : ksteps;   // K steps over both passes (multiples of NS)
+        int t_ld = NS;                                    // next step to request
+        // NS steps: consume slot sl, refill it with step t + NS.  REFILL is a compile-time property of the iteration -- every
+        // iteration but the last refills all its slots -- because hipcc's s_waitcnt insertion only keeps the loads counted
+        // (vmcnt(28) before a slot's first MFMA: seven slots stay in flight) when every path through the loop body issues the same
+        // loads in the same order; with the refill under a branch it waited for vmcnt(0) at every slot.
+        auto steps8 = [&](int t0, auto REFILL) {
+          constexpr bool kRefill = decltype(REFILL)::value != 0;
+          const bool second = t0 >= ksteps;               // packed: the absorbed block's mode index into row tiles 2, 3
+          const int tm_lo = second ? 2 : 0, tm_hi = packed ? tm_lo + 2 : 4, tm_sub = tm_lo;
+          const int ks0 = second ? t0 - ksteps : t0;
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) {
+            const int ks = ks0 + sl, grp = ks >> 2;
+            const int r0 = ks * 4 + g;
+            T av[4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) av[tm] = Rs[(tm * 16 + cl) * RLD + r0];
+#if defined(TTR_QR_PUSH_NOMMA)
+            // (diagnostics build: the push without its MFMAs -- what do the loads and the rest of the phase cost?  wrong results)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) asm volatile("" ::"v"(bq[sl][tn]), "v"(av[tn]));
+#elif defined(TTR_QR_PUSH_ZSKIP)
+            // (-DTTR_QR_PUSH_ZSKIP, measured SLOWER: push 53 - 57 k instead of 42 - 45 k cycles -- the compare + ballot + branch per tile
+            // cost the waves more issue time than the skipped MFMAs free on the pipe.)  Zero operand tiles are not multiplied: the cores of a SUM of trains (tensor.py:445-668: blockdiag(a, b), what rounding
+            // is mostly called on) are half zeros, and a 4 x 16 B tile that is zero in every lane adds nothing to its accumulators
+            // (x + a * 0 = x: bit-identical for finite R).  One compare + ballot per tile, against two MFMAs (64 cycles of the
+            // SIMD's matrix pipe, which BOTH resident blocks' pushes share -- the pipe, not HBM, paces the phase).
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+              if (__ballot(bq[sl][tn] != T(0)) == 0ull) continue;   // wave-uniform
+#pragma unroll
+              for (int tm = 0; tm < 4; ++tm) {
+                if (tm < tm_lo || tm >= tm_hi) continue;       // wave-uniform
+                if (upper && grp < tm - tm_sub) continue;      // wave-uniform (upper-triangular Rm: zero K groups)
+                acc[tm][tn] = M::mma(tm_sub == 0 ? av[tm] : av[tm & 1], bq[sl][tn], acc[tm][tn]);
+              }
+            }
+#else
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+              if (tm < tm_lo || tm >= tm_hi) continue;       // wave-uniform
+              if (upper && grp < tm - tm_sub) continue;      // wave-uniform (upper-triangular Rm: zero K groups)
+#pragma unroll
+              for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = M::mma(tm_sub == 0 ? av[tm] : av[tm & 1], bq[sl][tn], acc[tm][tn]);
+            }
+#endif
+            if constexpr (kRefill) {
+              // (the second pass begins: a select on the pointer, not a branch around the loads)
+              const T* __restrict__ p2 = Cb + (size_t)(NW * partner_blk + wave_id) * n + loff;
+              ldp = (t_ld == ksteps) ? p2 : ldp;
+              load_slot(bq[sl]);
+              ++t_ld;
+            }
+          }
+        };
+        int t0 = 0;
+        for (; t0 + NS < total; t0 += NS) steps8(t0, IC<1>{});
+        steps8(t0, IC<0>{});
+      };
+      if constexpr (NW == 8 && PAIR && sizeof(T) == 4) {
+        if (full && (ksteps & 7) == 0) stream_ks();
+        else if (full) stream(IC<1>{});
+        else stream(IC<0>{});
+      } else {
+        if (full) stream(IC<1>{});
+        else stream(IC<0>{});
+      }
+#else
       if (full) stream(IC<1>{});
       else stream(IC<0>{});
+#endif
       if (packed && absorbed_blk) {
         // an absorbed block: its rows live in its partner block.  The level above reads this block's R: zeros; its reflectors are
         // H = I (zero taus: the apply kernel returns at once for it)

@@ -25,7 +25,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kI = 64, kN = 64, kR = 64;          // core [kR][kI][kN]
 constexpr int kItem = kR * kI * kN;              // floats per item
-constexpr int LDS_PAD = 72 * 1024;               // static LDS per block: exactly two blocks per CU
+constexpr int LDS_PAD = 72 * 1024;               // (mode 2 with SLOTS = 8 uses 64 KB of it)               // static LDS per block: exactly two blocks per CU
 
 __device__ __forceinline__ void spin_kc(int kc) {
   if (kc <= 0) return;
@@ -92,6 +92,31 @@ __global__ __launch_bounds__(512, 4) void push_kernel(const float* cores, float*
         use_group(bvA);
         use_group(bvB);
         asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (MODE == 3) {
+      // mode 0's loads with SLOTS K GROUPS (16 loads per lane each) in flight instead of two
+      const int g = lane >> 4, cl = lane & 15;
+      float bv[SLOTS][4][4];
+      auto sl_of = [&](int pass) { return base + (8 * (b + 4 * pass) + wave) * kN; };
+      auto load_group = [&](int gi, float (&q)[4][4]) {   // gi = 0 .. 7 over both passes
+        const float* sl = sl_of(gi >> 2);
+        const int grp = gi & 3;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) q[kk][tn] = sl[(size_t)((grp * 4 + kk) * 4 + g) * (kI * kN) + tn * 16 + cl];
+      };
+#pragma unroll
+      for (int gi = 0; gi < SLOTS; ++gi) { load_group(gi, bv[gi]); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int gi = 0; gi < 8; ++gi) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) acc += bv[gi % SLOTS][kk][tn];
+        asm volatile("" : "+v"(acc));
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        if (gi + SLOTS < 8) { load_group(gi + SLOTS, bv[gi % SLOTS]); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       }
     } else if constexpr (MODE == 1) {
       const int r = lane >> 4, c = lane & 15;
@@ -170,7 +195,10 @@ __global__ __launch_bounds__(512, 4) void push_kernel(const float* cores, float*
     push_cyc += clock64() - t0;
     spin_kc(spin);
   }
-  out[blockIdx.x * 512 + tid] = acc;
+  // (every mode touches the static LDS array: otherwise hipcc drops it and modes 0 / 1 run four blocks per CU, mode 2 two)
+  lds[LDS_PAD / 4 - 512 + tid] = acc;
+  __syncthreads();
+  out[blockIdx.x * 512 + tid] = lds[LDS_PAD / 4 - 512 + ((tid + 1) & 511)];
   if (tid == 0) cyc[blockIdx.x] = push_cyc;
 }
 
@@ -229,6 +257,15 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("# a 1000 k-tick spin takes %.3f ms -> clock64 ticks at %.1f MHz\n", ms, 1024.0 * 1000 / ms / 1e3);
+  }
+  // in-flight depth (bytes per block in flight = groups x 32 KB), loaded chip and one block per CU on an idle chip
+  for (int nb : {nblocks, 256}) {
+    run<3, 1>("3: dword, 1 group in flight", cores, out, cyc, nb, 68, 0, 1, 2.4);
+    run<3, 2>("3: dword, 2 groups in flight", cores, out, cyc, nb, 68, 0, 1, 2.4);
+    run<3, 4>("3: dword, 4 groups in flight", cores, out, cyc, nb, 68, 0, 1, 2.4);
+    run<3, 8>("3: dword, 8 groups in flight", cores, out, cyc, nb, 68, 0, 1, 2.4);
+    run<2, 4>("2: LDS-DMA ring 4 KB/wave", cores, out, cyc, nb, 68, 0, 1, 2.4);
+    run<2, 8>("2: LDS-DMA ring 8 KB/wave", cores, out, cyc, nb, 68, 0, 1, 2.4);
   }
   const int spins[] = {0, 68};
   for (int spin : spins) {

@@ -28,6 +28,9 @@ for rnd in range(2):   # two rounds: A/B/A/B
         if ref is None:
             ref = f.R.clone()
         same = bool(torch.equal(ref, f.R))
+        if rnd == 0:
+            import hashlib
+            print(f"    sha256(R) {hashlib.sha256(f.R.cpu().numpy().tobytes()).hexdigest()[:16]}  lib {os.environ.get('TTR_LIB_PATH', 'default')}")
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
