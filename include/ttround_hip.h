@@ -642,6 +642,12 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      resident block of every CU under round-robin dispatch) start k x 1024 cycles late, so that a CU's two blocks
  *                      alternate their HBM phase (the push) and their panel chain instead of running them side by side. */
 #define TTR_KNOB_QR_STAGGER 16
+/*   TTR_KNOB_QR_PACK_PRE  1 (default; round 6) = the row-packing decision of a fused push + factor launch (TTR_KNOB_QR_PACK) is
+ *                      taken by a one-wave-per-item kernel AHEAD of the launch and read by its blocks: an absorbed block returns at
+ *                      once instead of staging Rm first (9 k cycles each, 16384 of them at the tail of every level-0 launch of the
+ *                      metric), its partner writes the zero R block and taus for it; 0 = every block derives the decision from Rm
+ *                      itself (round 5; A/B). */
+#define TTR_KNOB_QR_PACK_PRE 17
 /*   TTR_KNOB_EIGH_SMALL  1 = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

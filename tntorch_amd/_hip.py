@@ -1073,6 +1073,7 @@ KNOB_QR_PACK = 7
 KNOB_EIGH_SMALL = 8
 KNOB_RANK_NOISE_FLOOR = 9
 KNOB_QR_STAGGER = 16
+KNOB_QR_PACK_PRE = 17
 KNOB_ORTH_ROUNDS = 10
 KNOB_JACOBI_LIVE_WAVE = 11
 KNOB_ORTH_V2 = 12

@@ -1105,6 +1105,7 @@ extern int g_rank_skip_c;
 extern int g_qr_pack;
 extern int g_qr_interleave;
 extern int g_qr_stagger;
+extern int g_qr_pack_pre;
 extern int g_sweep_stagger;
 extern int g_rank_noise_c;
 extern int g_jacobi_live_wave;
@@ -1815,6 +1816,10 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_SWEEP_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: stagger mode %d outside [0, 2]", value);
       g_sweep_stagger = value;
+      return TTR_OK;
+    case TTR_KNOB_QR_PACK_PRE:
+      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: pack-flag switch %d outside [0, 1]", value);
+      g_qr_pack_pre = value;
       return TTR_OK;
     case TTR_KNOB_QR_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 1024, TTR_E_INVALID, "ttr_debug_set_knob: stagger of %d kilo-cycles outside [0, 1024]", value);

@@ -64,6 +64,11 @@ struct QrLevel {
   // apply kernel in pack_flag[item] (always written when non-null).  pack_ok = 0: never pack.
   int32_t* pack_flag;
   int pack_ok;
+  // (round 6) pack_pre != 0: pack_flag[] was filled BEFORE this launch (pack_flags_kernel, same criterion): the blocks read the
+  // decision instead of deriving it from Rm -- an absorbed block returns at once (it used to stage Rm, request its first K group
+  // and write a zero R first: 9 k cycles, 16384 of them at the tail of every level-0 launch of the metric), its partner writes
+  // the zero R block and the zero taus for it.
+  int pack_pre;
   int grid_swap;
   // PUSHED level 0: the factored matrix is the left unfolding of  P[kk,i,c] = sum_r0 Rm[kk,r0] C[r0,i,c]
   // (tensor.py:1826-1832 fused into the next QR): block b owns rows {(kk, i): i = 4b + wave}
@@ -199,6 +204,13 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // r0) and the A-operand reads below (16 kk x 2 r0 per 32-lane group: words 66 cl + g) touch 32 distinct banks.
     constexpr int RLD = 66;
     T* Rs = Vs;  // 64 x 66 <= 256 x 17
+    int pre_flag = 0;
+    if (p.pack_pre) {
+      pre_flag = p.pack_flag[bt];   // (block-uniform)
+      const int hb = p.nb >> 1;
+      const bool absorbed_early = p.pack_ok == 3 ? (b >= hb) : p.pack_ok == 2 ? ((b & 1) != 0) != ((bt & 1) != 0) : (b >= hb) != ((bt & 1) != 0);
+      if (pre_flag != 0 && absorbed_early) { stamp(); return; }   // absorbed by its partner block, which also writes this block's R and taus
+    }
     const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
     // Rm is the R factor of the previous core's QR in the rounding sweep, i.e. upper triangular: row tile tm of the product
     // then only needs the K steps r0 >= 16 tm (10 of the 16 tile x K-group combinations).  Detected here, not assumed: the
@@ -327,8 +339,10 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           upper = any == T(0);
           if constexpr (kFull && NW == 8 && PAIR) {
             const T ce = T(p.rank_skip_c) * Num<T>::eps();
-            packed = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb &&
-                     lane_get(sl, 0) <= ce * ce * lane_get(sa, 0);
+            if (p.pack_pre) packed = pre_flag != 0;   // (the host only sets pack_pre when the static conditions below hold)
+            else
+              packed = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb &&
+                       lane_get(sl, 0) <= ce * ce * lane_get(sa, 0);
           }
         }
         if (packed && absorbed_blk) return;   // absorbed by its partner block (block-uniform; handled by the caller)
@@ -526,7 +540,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         for (int tn = 0; tn < NT; ++tn) bcur[tn] = bnxt[tn];
       }
     }
-    if (p.pack_flag && b == 0 && tid == 0) p.pack_flag[bt] = packed ? p.pack_ok : 0;
+    if (p.pack_pre) {
+      if (packed) {   // the absorbed block returned at once: its R block (zeros: the level above reads it) and its taus (H = I) are written here
+        T* __restrict__ Rp = p.Rout + bt * p.strideR + (int64_t)partner_blk * n * p.ldr;
+        for (int idx = tid; idx < n * n; idx += NTH) Rp[(int64_t)(idx / n) * p.ldr + idx % n] = T(0);
+        if (tid < NP) p.tau[(bt * p.nb + partner_blk) * (int64_t)NP + tid] = T(0);
+      }
+    } else if (p.pack_flag && b == 0 && tid == 0) {
+      p.pack_flag[bt] = packed ? p.pack_ok : 0;
+    }
     lds_barrier();  // Rs aliases Vs
   } else {
     const T* __restrict__ X = p.X + bt * p.strideX + row0 * p.ldx;
@@ -1565,6 +1587,31 @@ __global__ __launch_bounds__(256) void r_expo_kernel(T* __restrict__ R, int rows
   if (threadIdx.x == 0) expo_acc[bt] += e;
 }
 
+// pack_flag[item] = pack_ok when rows 32 .. 63 of the item's 64 x 64 Rm hold at most (c eps)^2 of its squared Frobenius norm (the
+// packing criterion of the fused push, QrLevel::pack_flag), else 0: one wave per item, ahead of the level-0 launch (QrLevel::pack_pre)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_flags_kernel(const T* __restrict__ Rm, int64_t ldrm, int64_t strideRm, int Rin, int64_t batch,
+                                                         int rank_skip_c, int pack_ok, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t bt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bt >= batch) return;
+  const T* __restrict__ R = Rm + bt * strideRm;
+  T v[64];
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) v[kk] = lane < Rin ? R[(int64_t)kk * ldrm + lane] : T(0);
+  T sq_all = T(0), sq_low = T(0);
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) {
+    sq_all += v[kk] * v[kk];
+    if (kk >= 32) sq_low += v[kk] * v[kk];
+  }
+  wave_sum2(sq_all, sq_low);
+  const T ce = T(rank_skip_c) * Num<T>::eps();
+  if (lane == 0) flag[bt] = (lane_get(sq_low, 0) <= ce * ce * lane_get(sq_all, 0)) ? pack_ok : 0;
+}
+
+int g_qr_pack_pre = 1;   // ttr_debug_set_knob(TTR_KNOB_QR_PACK_PRE): 0 = every block derives the packing decision from Rm itself (round 5)
+
 template <typename T, int NT>
 static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, int64_t strideA, T* R, int64_t ldr,
                       int64_t strideR, T* ws, const QrPlan& pl, const Pushed& pu, hipStream_t stream, int64_t a_cs = 1) {
@@ -1593,8 +1640,16 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     if (p.top) { p.Rout = R; p.ldr = ldr; p.strideR = strideR; }
     else { p.Rout = ws + pl.off_x[l + 1]; p.ldr = n; p.strideR = pl.m[l + 1] * n; }
     const bool pushed = (l == 0 && pu.Rm);
+    // the packing decision ahead of the launch: exactly when the kernel's `packed` path can be taken at all (8-wave PAIR blocks, whole
+    // shapes: every mode index valid, all 16 NT columns, Rin a multiple of 16; a 64-row R; an even number of blocks)
+    p.pack_pre = (pushed && g_qr_pack_pre && p.pack_ok && p.pack_flag && g_rank_skip_c > 0 && pl.nw[l] == 8 && g_qr_variant != 0 &&
+                  pu.k == 64 && pu.Rin <= 64 && (pu.Rin & 15) == 0 && n == PW * NT && (pl.nb[l] & 1) == 0 && pu.I == 8 * pl.nb[l] &&
+                  pu.ldrm >= pu.Rin) ? 1 : 0;
     {
       ProfScope prof(TTR_PROF_QR_FACTOR, stream);
+      if (p.pack_pre)
+        hipLaunchKernelGGL((pack_flags_kernel<T>), dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, stream, (const T*)pu.Rm, pu.ldrm,
+                           pu.strideRm, pu.Rin, batch, g_rank_skip_c, p.pack_ok, p.pack_flag);
       p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? ((g_qr_interleave && (pl.nb[l] & 1) == 0) ? 2 : 1) : 0;
       const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
       if (pl.nw[l] == 8 && g_qr_variant != 0) {
