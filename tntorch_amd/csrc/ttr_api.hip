@@ -1854,7 +1854,7 @@ int ttr_debug_set_knob(int knob, int value) {
       g_rank_skip_c = value;
       return TTR_OK;
     case TTR_KNOB_QR_F64_NW4:
-      TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: 4-wave block switch %d outside [0, 3]", value);
+      TTR_REQUIRE(value >= 0 && value <= 7, TTR_E_INVALID, "ttr_debug_set_knob: 4-wave block switch %d outside [0, 7]", value);
       g_qr_f64_nw4 = value;
       return TTR_OK;
     case TTR_KNOB_GEMM_BIG:

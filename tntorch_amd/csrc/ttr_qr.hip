@@ -568,7 +568,13 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
   // therefore scaled by the exact power of two of its largest entry for the factorisation and R is scaled back
   // on output; reflectors and T factors are scale invariant, so nothing else changes (bit-identical in range).
   int bexp = 0;
-  if constexpr (sizeof(T) == 4) {
+  T rank_thr = T(0);
+  if constexpr (sizeof(T) == 4 && PAIR) {
+    // (round 6) the range guard's block maximum and the block's squared norm -- the threshold of the rank-revealing early exit,
+    // below -- travel through ONE block-wide reduction instead of two (a barrier pair of eight waves costs 1 - 2 k cycles): every
+    // wave sums its squares at the exponent of ITS largest entry (0 when that is O(1), like the block's) and the partial sums are
+    // brought to the block's exponent afterwards -- exact powers of two: the same bits as scaling first and summing then, unless a
+    // wave's entries lie 2^60 below the block's (where the old order lost them in the denormals)
     T mx = T(0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
@@ -578,18 +584,42 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
         for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(acc[tm][tn][r]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-    if (lane == 0) Ss[wave] = mx;
+    int ew = 0;
+    if (mx > T(0) && mx < T(3e38)) {
+      (void)frexpf((float)mx, &ew);
+      if (ew > -8 && ew < 8) ew = 0;
+    }
+    ew = __builtin_amdgcn_readfirstlane(ew);
+    T sq = T(0);
+    if (ew == 0) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq += acc[tm][tn][r] * acc[tm][tn][r];
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const T x = ldexpf((float)acc[tm][tn][r], -ew); sq += x * x; }
+    }
+    sq = wave_sum_dpp(sq);
+    if (lane == 0) { Ss[wave] = mx; Ss[NW + wave] = sq; Ss[2 * NW + wave] = (T)ew; }
     lds_barrier();
     T bm = Ss[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) bm = fmax(bm, Ss[w]);
-    lds_barrier();  // Ss is reused by the panels
     if (bm > T(0) && bm < T(3e38)) {
       (void)frexpf((float)bm, &bexp);
       if (!(!PUSHED && p.top && p.expo_acc) && bexp > -8 && bexp < 8) bexp = 0;  // already O(1): leave the data alone
     }
-    // (QrLevel::expo_acc; not in the PUSHED instances -- the metric's level-0 kernel sits at its register cap, and a pushed
-    // factorisation that is its own top level is a small one: factor_run normalises its R with a launch of its own)
+    T bf2 = ldexpf((float)Ss[NW], 2 * ((int)Ss[2 * NW] - bexp));
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bf2 += ldexpf((float)Ss[NW + w], 2 * ((int)Ss[2 * NW + w] - bexp));
+    lds_barrier();  // Ss is reused by the panels
     if constexpr (!PUSHED) {
       if (p.top && p.expo_acc && tid == 0) p.expo_acc[bt] += bexp;   // (one block per item at the top; R keeps the exponent, see below)
     }
@@ -601,32 +631,70 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[tm][tn][r] = ldexpf((float)acc[tm][tn][r], -bexp);
     }
-  }
-  // Rank-revealing early exit (PAIR blocks, round 4): rounding works on rank-INFLATED trains (sums, products: the metric's
-  // t = g + g has unfoldings of rank 32 in 64 columns), so after the first panels the remaining columns of a block are
-  // rounding noise.  A panel whose remaining part (rows >= j0 of its 16 columns, after the earlier panels' updates) has a
-  // squared Frobenius norm below (8 eps)^2 of the block's is not factored: its reflectors are H = I (tau = 0), what is dropped
-  // below the diagonal is a backward error of 8 eps ||block||_F -- the size of the factorisation's own -- and the apply kernel
-  // skips trailing identity panels altogether.  bf2: the block's squared Frobenius norm (at the factorisation's exponent).
-  T rank_thr = T(0);
-  if constexpr (PAIR) {
-    T sq = T(0);
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sq += acc[tm][tn][r] * acc[tm][tn][r];
-    sq = wave_sum_dpp(sq);
-    if (lane == 0) Ss[wave] = sq;
-    lds_barrier();
-    T bf2 = Ss[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) bf2 += Ss[w];
-    lds_barrier();  // Ss is reused by the panels
+    // Rank-revealing early exit (PAIR blocks, round 4): see below
     const T ce = T(p.rank_skip_c) * Num<T>::eps();
     rank_thr = lane_get(ce * ce * bf2, 0);   // (wave-uniform: lives in SGPRs)
     if (p.rank_skip_c <= 0) rank_thr = T(-1);
+  } else {
+    if constexpr (sizeof(T) == 4) {
+      T mx = T(0);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(acc[tm][tn][r]));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+      if (lane == 0) Ss[wave] = mx;
+      lds_barrier();
+      T bm = Ss[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) bm = fmax(bm, Ss[w]);
+      lds_barrier();  // Ss is reused by the panels
+      if (bm > T(0) && bm < T(3e38)) {
+        (void)frexpf((float)bm, &bexp);
+        if (!(!PUSHED && p.top && p.expo_acc) && bexp > -8 && bexp < 8) bexp = 0;  // already O(1): leave the data alone
+      }
+      // (QrLevel::expo_acc; not in the PUSHED instances -- the metric's level-0 kernel sits at its register cap, and a pushed
+      // factorisation that is its own top level is a small one: factor_run normalises its R with a launch of its own)
+      if constexpr (!PUSHED) {
+        if (p.top && p.expo_acc && tid == 0) p.expo_acc[bt] += bexp;   // (one block per item at the top; R keeps the exponent, see below)
+      }
+      if (bexp != 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][tn][r] = ldexpf((float)acc[tm][tn][r], -bexp);
+      }
+    }
+    // Rank-revealing early exit (PAIR blocks, round 4): rounding works on rank-INFLATED trains (sums, products: the metric's
+    // t = g + g has unfoldings of rank 32 in 64 columns), so after the first panels the remaining columns of a block are
+    // rounding noise.  A panel whose remaining part (rows >= j0 of its 16 columns, after the earlier panels' updates) has a
+    // squared Frobenius norm below (8 eps)^2 of the block's is not factored: its reflectors are H = I (tau = 0), what is dropped
+    // below the diagonal is a backward error of 8 eps ||block||_F -- the size of the factorisation's own -- and the apply kernel
+    // skips trailing identity panels altogether.  bf2: the block's squared Frobenius norm (at the factorisation's exponent).
+    if constexpr (PAIR) {
+      T sq = T(0);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq += acc[tm][tn][r] * acc[tm][tn][r];
+      sq = wave_sum_dpp(sq);
+      if (lane == 0) Ss[wave] = sq;
+      lds_barrier();
+      T bf2 = Ss[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) bf2 += Ss[w];
+      lds_barrier();  // Ss is reused by the panels
+      const T ce = T(p.rank_skip_c) * Num<T>::eps();
+      rank_thr = lane_get(ce * ce * bf2, 0);   // (wave-uniform: lives in SGPRs)
+      if (p.rank_skip_c <= 0) rank_thr = T(-1);
+    }
   }
   stamp();
 #ifdef TTR_QR_WSTAMPS
@@ -1488,7 +1556,8 @@ int g_qr_f64_nw4 = 0;  // ttr_debug_set_knob(TTR_KNOB_QR_F64_NW4): fp64 trees ou
 // the 8-wave block and the shallower tree outweigh the second chain per CU.  Kept as a switch, off.
 // (bit 1 of the switch: the same for fp32 -- round 4's A/B of "256-row leaves x 4 waves, four blocks per CU" on the metric)
 static bool nw4_forced(bool f64) { return f64 ? (g_qr_f64_nw4 & 1) != 0 : (g_qr_f64_nw4 & 2) != 0; }
-static int nw_for(int64_t rows, bool f64) { return (rows > BR4 && !nw4_forced(f64)) ? 8 : 4; }
+// (bit 2 of the knob, A/B: fp32 matrices of <= 256 rows on the 8-wave PAIR kernel too -- its panels are rank-revealing, the 4-wave kernel's are not)
+static int nw_for(int64_t rows, bool f64) { return ((rows > BR4 || (!f64 && (g_qr_f64_nw4 & 4) != 0)) && !nw4_forced(f64)) ? 8 : 4; }
 
 static QrPlan make_plan(int64_t m, int64_t n, int64_t batch, bool f64) {
   QrPlan pl{};
