@@ -15,6 +15,8 @@
 //     k <-> column 4 k + r): no LDS round trip, no transposition, 10 of the 16 tiles (symmetry).
 // Arithmetic per 16 columns and wave: 64 + 40 MFMA 16x16x4 for the rotation + Gram (AI = 64 flop/B: bound by the fp32
 // MFMA rate, which equals the vector rate on gfx950), 32 for the projection to rank 32 (AI = 11 flop/B: HBM-bound).
+#include <type_traits>
+
 #include "ttr_common.h"
 
 namespace ttr {
@@ -306,14 +308,19 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
   // are independent of each other, so the result is bit-identical in any order.  (TTR_KNOB_SWEEP_STAGGER = 0: in order.)
   const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
   const int64_t rot = (p.stagger && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
+  // (round 6) NK = K steps that carry data: a `rows32` item (rows 32.. exactly zero: not loaded) used to multiply its 8 zero K steps
+  // all the same -- half of the kernel's MFMAs (counters: the matrix pipe 43 % busy on the metric's input); skipped products add
+  // a * 0 to their accumulators: bit-identical
+  auto main_loop = [&](auto NKC) {
+  constexpr int NK = decltype(NKC)::value;
   for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
     int64_t sq = sidx + rot;
     if (sq >= nsteps) sq -= nsteps;
     const int64_t c = cb + wave + 4 * sq;
     const int64_t col = c * 32 + 2 * cl;
-    T bm[2][16];
+    T bm[2][NK];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < NK; ++ks) {
       const int k = 4 * ks + g;
       const Pack<T, 2> x = load_pack<T, 2>(Mp + (int64_t)k * p.ldm + col, al, k < Rl ? p.n - col : 0);
       bm[0][ks] = x.v[0];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
       if (t < nt) {
         Acc acc0 = M::zero(), acc1 = M::zero();
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < NK; ++ks) {
           const T af = Ul[urow(4 * ks + g) + 16 * t + cl];
           acc0 = M::mma(af, bm[0][ks], acc0);
           acc1 = M::mma(af, bm[1][ks], acc1);
@@ -350,6 +357,9 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
       }
     }
   }
+  };
+  if (Rl <= 32) main_loop(std::integral_constant<int, 8>{});
+  else main_loop(std::integral_constant<int, 16>{});
 }
 
 // ================================================================ tall matrices (dense TT-SVD steps): M is rows x n, n <= 64
