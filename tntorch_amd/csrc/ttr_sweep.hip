@@ -294,72 +294,96 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? 4 : 1)) void project_ke
       Lo[(int64_t)k * p.ldl + i] = (p.scale_right && sg) ? u * sg[i] : u;
     }
   }
-  // ---- main loop: 32 columns per step as two interleaved 16-column slabs (columns c0 + 2 i + u): 8-byte loads of M
-  // (whole 128-byte lines per 16 lanes) and 8-byte stores of the result
+  // ---- main loop: 16 SL columns per step as SL interleaved 16-column slabs (columns c0 + SL i + u): one 4 SL-byte load of M per
+  // row and lane (whole 128-byte lines per 16 lanes) and 4 SL-byte stores of the result; SL = 2 (see the end of the kernel).
   T* __restrict__ Ro = p.right + b * p.strideR;
-  const bool al = ((p.ldm & 1) == 0) && ((p.ldr & 1) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (2 * sizeof(T) - 1)) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(Ro) & (2 * sizeof(T) - 1)) == 0);
-  int64_t cb, ce;
-  split_range((p.n + 31) / 32, p.nsplit, split, cb, ce);
+  const bool al2 = ((p.ldm & 1) == 0) && ((p.ldr & 1) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (2 * sizeof(T) - 1)) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(Ro) & (2 * sizeof(T) - 1)) == 0);
+  const bool al4 = ((p.ldm & 3) == 0) && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Mp) & (4 * sizeof(T) - 1)) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(Ro) & (4 * sizeof(T) - 1)) == 0);
   const int Rl = (p.rows32 && p.rows32[b] != 0 && R > 32) ? 32 : R;   // (see rotgram_kernel: zero rows are not loaded)
   // Step order: every item's rows lie ldm elements apart (8 KB at the metric's bonds) and every item is aligned alike, so
   // workgroups that walk their columns in step would keep hitting the same HBM channels (address bits 8 .. 12 are the column's;
   // measured on ttr_orth_fixup, profiles/r05_orth_stamps.txt).  Item b starts at step b mod nsteps and wraps around; the columns
   // are independent of each other, so the result is bit-identical in any order.  (TTR_KNOB_SWEEP_STAGGER = 0: in order.)
-  const int64_t nsteps = ce > cb + wave ? (ce - cb - wave + 3) / 4 : 0;
-  const int64_t rot = (p.stagger && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
-  // (round 6) NK = K steps that carry data: a `rows32` item (rows 32.. exactly zero: not loaded) used to multiply its 8 zero K steps
+  // NK = K steps that carry data (round 6): a `rows32` item (rows 32.. exactly zero: not loaded) used to multiply its 8 zero K steps
   // all the same -- half of the kernel's MFMAs (counters: the matrix pipe 43 % busy on the metric's input); skipped products add
   // a * 0 to their accumulators: bit-identical
-  auto main_loop = [&](auto NKC) {
-  constexpr int NK = decltype(NKC)::value;
-  for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
-    int64_t sq = sidx + rot;
-    if (sq >= nsteps) sq -= nsteps;
-    const int64_t c = cb + wave + 4 * sq;
-    const int64_t col = c * 32 + 2 * cl;
-    T bm[2][NK];
+  auto main_loop = [&](auto NKC, auto SLC) {
+    constexpr int NK = decltype(NKC)::value, SL = decltype(SLC)::value;
+    const bool al = SL == 4 ? al4 : al2;
+    // the split (nsplit: pick_split) is defined on 32-column chunks; a wave's steps walk its share SL * 16 columns at a time
+    int64_t cb, ce;
+    split_range((p.n + 31) / 32, p.nsplit, split, cb, ce);
+    const int64_t col_b = cb * 32, col_e = ce * 32 < p.n ? ce * 32 : p.n;
+    const int64_t nch = (col_e - col_b + 16 * SL - 1) / (16 * SL);
+    const int64_t nsteps = nch > wave ? (nch - wave + 3) / 4 : 0;
+    const int64_t rot = (p.stagger && nsteps > 1) ? (int64_t)(b % nsteps) : 0;
+    for (int64_t sidx = 0; sidx < nsteps; ++sidx) {
+      int64_t sq = sidx + rot;
+      if (sq >= nsteps) sq -= nsteps;
+      const int64_t col = col_b + (wave + 4 * sq) * (16 * SL) + SL * cl;
+      const int64_t lim = col_e - col;     // columns of this lane's group inside the split's share
+      T bm[SL][NK];
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const int k = 4 * ks + g;
-      const Pack<T, 2> x = load_pack<T, 2>(Mp + (int64_t)k * p.ldm + col, al, k < Rl ? p.n - col : 0);
-      bm[0][ks] = x.v[0];
-      bm[1][ks] = x.v[1];
-    }
+      for (int ks = 0; ks < NK; ++ks) {
+        const int k = 4 * ks + g;
+        const Pack<T, SL> x = load_pack<T, SL>(Mp + (int64_t)k * p.ldm + col, al, (k < Rl && lim > 0) ? lim : 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < nt) {
-        Acc acc0 = M::zero(), acc1 = M::zero();
+        for (int u = 0; u < SL; ++u) bm[u][ks] = x.v[u];
+      }
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-          const T af = Ul[urow(4 * ks + g) + 16 * t + cl];
-          acc0 = M::mma(af, bm[0][ks], acc0);
-          acc1 = M::mma(af, bm[1][ks], acc1);
-        }
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          Acc acc[SL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * t + M::row(lane, r);
-          if (row < ro && col < p.n) {
-            const T sc = isg[row];
-            T* dst = Ro + (int64_t)row * p.ldr + col;
-            if (al && col + 2 <= p.n) {
-              typedef T VT __attribute__((ext_vector_type(2)));
-              VT o;
-              o[0] = acc0[r] * sc;
-              o[1] = acc1[r] * sc;
-              *reinterpret_cast<VT*>(dst) = o;
-            } else {
-              dst[0] = acc0[r] * sc;
-              if (col + 1 < p.n) dst[1] = acc1[r] * sc;
+          for (int u = 0; u < SL; ++u) acc[u] = M::zero();
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const T af = Ul[urow(4 * ks + g) + 16 * t + cl];
+#pragma unroll
+            for (int u = 0; u < SL; ++u) acc[u] = M::mma(af, bm[u][ks], acc[u]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + M::row(lane, r);
+            if (row < ro && lim > 0) {
+              const T sc = isg[row];
+              T* dst = Ro + (int64_t)row * p.ldr + col;
+              if (al && lim >= SL) {
+                typedef T VT __attribute__((ext_vector_type(SL)));
+                VT o;
+#pragma unroll
+                for (int u = 0; u < SL; ++u) o[u] = acc[u][r] * sc;
+                *reinterpret_cast<VT*>(dst) = o;
+              } else {
+#pragma unroll
+                for (int u = 0; u < SL; ++u)
+                  if (u < lim) dst[u] = acc[u][r] * sc;
+              }
             }
           }
         }
       }
     }
-  }
   };
-  if (Rl <= 32) main_loop(std::integral_constant<int, 8>{});
-  else main_loop(std::integral_constant<int, 16>{});
+  using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  using I16 = std::integral_constant<int, 16>;
+  // SL = 4 (16-byte accesses) is compiled only with -DTTR_PROJECT_WIDE: measured SLOWER on the kind (3.14 against 2.96 - 3.01 ms per
+  // 4096-train step, profiles/r06_project_ab.txt; review item 4's wide accesses), and 16 K steps x 4 slabs spill under the
+  // 128-register cap of four workgroups per CU
+  if (Rl <= 32) {
+#ifdef TTR_PROJECT_WIDE
+    if (al4) main_loop(I8{}, I4{});
+    else
+#endif
+      main_loop(I8{}, I2{});
+  } else {
+    main_loop(I16{}, I2{});
+  }
+  (void)al4;
 }
 
 // ================================================================ tall matrices (dense TT-SVD steps): M is rows x n, n <= 64
