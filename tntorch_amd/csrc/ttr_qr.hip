@@ -1400,13 +1400,48 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     astamp();
   }
 
+  // (round 6) 16-byte stores of whole 128-byte rows for the 32-column results of the sweep (fp32, NTC = 2, ocs = 1): the wave's
+  // tiles go through a wave-private LDS image [32 rows][36] (Vs is free after the last panel; ld 36: conflict-free 4-byte
+  // writes, 16-byte aligned rows) one row-tile PAIR at a time and leave as 8 rows x 128 bytes per instruction -- 8 stores per
+  // lane instead of 32 that each touch four 64-byte pieces 8 KB apart (cycle stamps: the store tail was 9.4 k of a block's 43 k
+  // cycles under load, profiles/r06_apply_stamps.txt).  `orow(kk)`: element offset of result row kk of this wave's mode index.
+  constexpr bool kWideOut = sizeof(T) == 4 && NTC == 2;
+  auto store_pair_wide = [&](int tm0, T* __restrict__ obase, int64_t kstride, int kk0, bool zero_hi) {
+    if constexpr (kWideOut) {
+      constexpr int OLD = 36;
+      T* img = Vs + wave * (32 * OLD);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tc = 0; tc < NTC; ++tc) img[(h * 16 + M::row(lane, r)) * OLD + tc * PW + cl] = C[tm0 + h][tc][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private image: no workgroup barrier)
+      typedef T V4 __attribute__((ext_vector_type(4)));
+      const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rr;
+        const V4 v = *reinterpret_cast<const V4*>(&img[row * OLD + c4]);
+        *reinterpret_cast<V4*>(obase + (int64_t)(kk0 + row) * kstride + c4) = v;
+        if (zero_hi) *reinterpret_cast<V4*>(obase + (int64_t)(kk0 + row + 32) * kstride + c4) = V4{T(0), T(0), T(0), T(0)};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is rewritten by the next pair
+    }
+  };
+  const bool wide_ok = kWideOut && p.ocs == 1 && (p.ldout & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.Out) & 15) == 0) &&
+                       ((p.strideOut & 3) == 0);
+
   if (p.pI > 0 && packed) {
     // packed item (factor kernel: QrLevel::pack_flag): local rows 0..31 of wave w are (kk, i0 = NW b + w), rows 32..63 are
     // (kk, i1 = NW partner + w), kk = 0..31; the rows kk >= 32 of both mode indices were dropped as zeros -- written here
     T* __restrict__ Out = p.Out + bt * p.strideOut;
     const int64_t kstride = (int64_t)p.pI * p.ldout;
     const int i0 = b * NW + wave, i1 = (pmode2 ? (b ^ 1) : (b < half_nb ? b + half_nb : b - half_nb)) * NW + wave;
-    if (kc == NC) {  // every store valid: one lane pointer per mode index, wave-uniform row offsets (as the unpacked fast path)
+    if (kc == NC && wide_ok) {
+      store_pair_wide(0, Out + (int64_t)i0 * p.ldout, kstride, 0, !p.skip_zero_rows);
+      store_pair_wide(2, Out + (int64_t)i1 * p.ldout, kstride, 0, !p.skip_zero_rows);
+    } else if (kc == NC) {  // every store valid: one lane pointer per mode index, wave-uniform row offsets (as the unpacked fast path)
       T* __restrict__ o0 = Out + (int64_t)i0 * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
       T* __restrict__ o1 = Out + (int64_t)i1 * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
 #pragma unroll
@@ -1447,13 +1482,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     if (full_tile) {
       // every store valid: one lane pointer, wave-uniform row offsets (the guarded element-wise loop below costs 3x the cycles)
       const int64_t kstride = (int64_t)p.pI * p.ldout;
-      T* __restrict__ o = Out + (int64_t)imode * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
+      if (wide_ok && !p.Gp) {
+        store_pair_wide(0, Out + (int64_t)imode * p.ldout, kstride, 0, false);
+        store_pair_wide(2, Out + (int64_t)imode * p.ldout, kstride, 32, false);
+      } else {
+        T* __restrict__ o = Out + (int64_t)imode * p.ldout + (int64_t)M::row(lane, 0) * kstride + cl;
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int tc = 0; tc < NTC; ++tc) o[(int64_t)(tm * 16 + M::row(0, r)) * kstride + tc * PW] = C[tm][tc][r];
+            for (int tc = 0; tc < NTC; ++tc) o[(int64_t)(tm * 16 + M::row(0, r)) * kstride + tc * PW] = C[tm][tc][r];
+      }
       if constexpr (sizeof(T) == 4 && NTC == 2 && NW == 8) {
         if (p.Gp) {
           // Row Gram matrix of the block's output while it is still in registers: G_b = sum over the 8 waves (mode indices) of
