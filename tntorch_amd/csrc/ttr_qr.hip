@@ -1296,17 +1296,20 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
 #endif
   astamp();
   // the first panel's reflectors are requested before C is initialised: their HBM latency hides the Top loads
-  const bool packed = p.pack_flag && p.pack_flag[bt] != 0;   // block-uniform
-  const int half_nb = p.nb >> 1;
+  // (round 6: the block's taus are requested TOGETHER with the packing flag -- the flag, the taus and the reflectors were three
+  // dependent memory round trips at the head of every block, 17 - 23 k of its 43 k cycles under load; every block owns a tau slot,
+  // an absorbed one just drops the value)
+  const T* __restrict__ tq = p.tau + blk * (int64_t)NP;
+  const T tv = lane < NP ? tq[lane] : T(0);
   const int pmode = p.pack_flag ? p.pack_flag[bt] : 0;
+  const bool packed = pmode != 0;   // block-uniform
+  const int half_nb = p.nb >> 1;
   const bool pmode2 = pmode == 2;
   if (packed && (pmode == 3 ? (b >= half_nb) : pmode2 ? ((b & 1) != 0) != ((bt & 1) != 0) : ((b >= half_nb) != ((bt & 1) != 0)))) return; // absorbed block: its rows are written by its partner block
   int npanels = (kb + PW - 1) / PW;
   {
     // trailing panels whose taus are all zero are H = I (rank-skipped by the factor kernel, or never factored): they are not
     // loaded at all.  Every wave looks at the block's taus itself (lane = reflector index): wave-uniform without LDS.
-    const T* __restrict__ tq = p.tau + blk * (int64_t)NP;
-    const T tv = lane < NP ? tq[lane] : T(0);
     const unsigned long long livem = __ballot(tv != T(0));
     const int nlive = livem ? (63 - __builtin_clzll(livem)) / PW + 1 : 0;
     npanels = npanels < nlive ? npanels : nlive;
@@ -1562,15 +1565,21 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
         }
   } else {
     T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
+    if (wide_ok && kc == NC && rows == BR) {   // a whole block of a plain level (the sweep's level 1): the wave's 64 rows as two pairs
+      T* __restrict__ ow = Out + (int64_t)(wave * 64) * p.ldout;
+      store_pair_wide(0, ow, p.ldout, 0, false);
+      store_pair_wide(2, ow, p.ldout, 32, false);
+    } else {
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+      for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tc = 0; tc < NTC; ++tc)
+        for (int tc = 0; tc < NTC; ++tc)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rowl(tm, r), col = tc * PW + cl;
-          if (row < rows && col < kc) Out[(int64_t)row * p.ldout + (int64_t)col * p.ocs] = C[tm][tc][r];
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int row = rowl(tm, r), col = tc * PW + cl;
+            if (row < rows && col < kc) Out[(int64_t)row * p.ldout + (int64_t)col * p.ocs] = C[tm][tc][r];
+          }
+    }
   }
   astamp();
 }

@@ -1,9 +1,9 @@
 mkdir -p gpurun_out/r06
-rm -f gpurun_out/r06/applyw_ab.txt
+rm -f gpurun_out/r06/applyw2_ab.txt
 for i in 1 2 3; do
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-configs 2> /dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('applywide', d['ms_per_step'], d['kernel_ms_per_step'], d['parity']['rel_err_vs_oracle_svd'])" >> gpurun_out/r06/applyw_ab.txt
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-configs 2> /dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('applywide2', d['ms_per_step'], d['kernel_ms_per_step'], d['parity']['rel_err_vs_oracle_svd'])" >> gpurun_out/r06/applyw2_ab.txt
 done
-TTR_LIB_PATH=tntorch_amd/libttround_wstamps.so python tools/probes/apply_metric_stamps.py 64 4096 > gpurun_out/r06/apply_stamps_wide.txt 2>&1
-timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -q -m gpu -x > gpurun_out/r06/gputest12.txt 2>&1
-tail -3 gpurun_out/r06/gputest12.txt
-cat gpurun_out/r06/applyw_ab.txt gpurun_out/r06/apply_stamps_wide.txt
+TTR_LIB_PATH=tntorch_amd/libttround_wstamps.so python tools/probes/apply_metric_stamps.py 64 4096 > gpurun_out/r06/apply_stamps_wide2.txt 2>&1
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -q -m gpu -x > gpurun_out/r06/gputest13.txt 2>&1
+tail -3 gpurun_out/r06/gputest13.txt
+cat gpurun_out/r06/applyw2_ab.txt gpurun_out/r06/apply_stamps_wide2.txt
