@@ -204,12 +204,17 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
     // r0) and the A-operand reads below (16 kk x 2 r0 per 32-lane group: words 66 cl + g) touch 32 distinct banks.
     constexpr int RLD = 66;
     T* Rs = Vs;  // 64 x 66 <= 256 x 17
-    int pre_flag = 0;
+    int pre_flag = 0;   // (a VECTOR register until Rm is staged: the scalar copy would make the block wait for the load right here)
     if (p.pack_pre) {
-      pre_flag = p.pack_flag[bt];   // (block-uniform)
       const int hb = p.nb >> 1;
       const bool absorbed_early = p.pack_ok == 3 ? (b >= hb) : p.pack_ok == 2 ? ((b & 1) != 0) != ((bt & 1) != 0) : (b >= hb) != ((bt & 1) != 0);
-      if (pre_flag != 0 && absorbed_early) { stamp(); return; }   // absorbed by its partner block, which also writes this block's R and taus
+      // (only a block that MAY be absorbed waits for the flag here; a working block's flag travels with its Rm loads and is looked
+      // at when Rm is staged -- as one test the flag's round trip stood at the head of every working block)
+      if (absorbed_early) {
+        if (p.pack_flag[bt] != 0) { stamp(); return; }   // absorbed by its partner block, which also writes this block's R and taus
+      } else {
+        pre_flag = p.pack_flag[bt + (lane & 0)];   // block-uniform value, per-lane address: stays in a VGPR
+      }
     }
     const T* __restrict__ Rm = p.Rm + bt * p.strideRm;
     // Rm is the R factor of the previous core's QR in the rounding sweep, i.e. upper triangular: row tile tm of the product
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 ? 4 : 1)) void qr_factor_k
           upper = any == T(0);
           if constexpr (kFull && NW == 8 && PAIR) {
             const T ce = T(p.rank_skip_c) * Num<T>::eps();
-            if (p.pack_pre) packed = pre_flag != 0;   // (the host only sets pack_pre when the static conditions below hold)
+            if (p.pack_pre) packed = __builtin_amdgcn_readfirstlane(pre_flag) != 0;   // (the host only sets pack_pre when the static conditions below hold)
             else
               packed = p.pack_ok && p.rank_skip_c > 0 && p.pk == 64 && (p.nb & 1) == 0 && p.pI == NW * p.nb &&
                        lane_get(sl, 0) <= ce * ce * lane_get(sa, 0);
