@@ -1849,6 +1849,26 @@ def test_from_dense_consuming_with_a_long_last_mode_completes_with_a_warning():
         assert torch.equal(a, b)
 
 
+def test_free_function_round_tt_does_not_copy_the_train_but_never_aliases_it():
+    """`tn.round_tt(t)` (round.py:7-19: clone, then round in place): on the device the clone is shallow -- the rounding rebinds the
+    cores, it never writes into them -- so the input is bit-for-bit unchanged, the result equals the method's, and no core of the
+    result shares storage with the input (a one-core tensor is copied after all)."""
+    g = oracle.tt_randn([12] * 5, 6, dtype=torch.float32)
+    inp = oracle.tt_add(g, g)
+    t = gpu_tensor(inp)
+    before = [c.clone() for c in t.cores]
+    r = tn.round_tt(t, rmax=6)
+    assert all(torch.equal(a, b) for a, b in zip(t.cores, before)) and list(t.ranks_tt) == [1, 12, 12, 12, 12, 1]
+    m = gpu_tensor(inp)
+    m.round_tt(rmax=6)
+    assert list(r.ranks_tt) == list(m.ranks_tt) and all(torch.equal(a, b) for a, b in zip(r.cores, m.cores))
+    held = {c.untyped_storage().data_ptr() for c in t.cores}
+    assert all(c.untyped_storage().data_ptr() not in held for c in r.cores)
+    one = tn.Tensor([torch.randn(1, 7, 1).cuda()])
+    r1 = tn.round_tt(one)
+    assert torch.equal(r1.cores[0], one.cores[0]) and r1.cores[0].untyped_storage().data_ptr() != one.cores[0].untyped_storage().data_ptr()
+
+
 def test_verbose_prints_the_reference_stage_lines_on_device(capsys):
     t = gpu_tensor(oracle.tt_randn([16, 16, 16, 16], 8, dtype=torch.float32))
     t.round_tt(rmax=3, verbose=True)

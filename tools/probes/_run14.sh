@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/r06
+rm -f gpurun_out/r06/esum_ab.txt
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x > gpurun_out/r06/gputest15a.txt 2>&1
+tail -3 gpurun_out/r06/gputest15a.txt
+for i in 1 2 3; do
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-configs 2> /dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('esum', d['ms_per_step'], d['kernel_ms_per_step'], d['parity']['rel_err_vs_oracle_svd'])" >> gpurun_out/r06/esum_ab.txt
+done
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -x > gpurun_out/r06/gputest15.txt 2>&1
+tail -3 gpurun_out/r06/gputest15.txt
+cat gpurun_out/r06/esum_ab.txt
