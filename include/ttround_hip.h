@@ -646,7 +646,8 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      taken by a one-wave-per-item kernel AHEAD of the launch and read by its blocks: an absorbed block returns at
  *                      once instead of staging Rm first (9 k cycles each, 16384 of them at the tail of every level-0 launch of the
  *                      metric), its partner writes the zero R block and taus for it; 0 = every block derives the decision from Rm
- *                      itself (round 5; A/B). */
+ *                      itself (round 5; A/B).  + 2: the level-1 launch of ttr_qr_apply_pushed does NOT idle the waves that hold the
+ *                      absorbed leaves' (exactly zero) rows of a packed item (A/B; default: they load, multiply and store nothing). */
 #define TTR_KNOB_QR_PACK_PRE 17
 /*   TTR_KNOB_EIGH_SMALL  1 = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed

@@ -1106,6 +1106,7 @@ extern int g_qr_pack;
 extern int g_qr_interleave;
 extern int g_qr_stagger;
 extern int g_qr_pack_pre;
+extern int g_qr_l1_idle;
 extern int g_sweep_stagger;
 extern int g_rank_noise_c;
 extern int g_jacobi_live_wave;
@@ -1818,8 +1819,9 @@ int ttr_debug_set_knob(int knob, int value) {
       g_sweep_stagger = value;
       return TTR_OK;
     case TTR_KNOB_QR_PACK_PRE:
-      TTR_REQUIRE(value >= 0 && value <= 1, TTR_E_INVALID, "ttr_debug_set_knob: pack-flag switch %d outside [0, 1]", value);
-      g_qr_pack_pre = value;
+      TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: pack-flag switch %d outside [0, 3]", value);
+      g_qr_pack_pre = value & 1;
+      g_qr_l1_idle = (value & 2) ? 0 : 1;
       return TTR_OK;
     case TTR_KNOB_QR_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 1024, TTR_E_INVALID, "ttr_debug_set_knob: stagger of %d kilo-cycles outside [0, 1024]", value);

@@ -1255,6 +1255,9 @@ struct QrApply {
   long long* dbg;  // optional: cycle stamps of block (0, 0) (diagnostics)
   const int32_t* pack_flag;  // level 0 of a PUSHED factorisation: != 0 for items the factor kernel packed (see QrLevel)
   int grid_swap;             // grid (batch, nb) instead of (nb, batch): block-major launch order (see QrLevel)
+  const int32_t* half_zero;  // (round 6) level 1 above a PACKED pushed level 0 (TTR_KNOB_QR_PACK = 3, 8 leaf blocks): the leaf flags -- rows
+                             // >= m / 2 of a flagged item are the absorbed leaves' R blocks, exactly zero, and so are its reflectors'
+                             // rows there and the result's: waves 4 .. 7 of its block load, multiply and store nothing
   int skip_zero_rows;        // != 0: the exactly-zero rows kk >= 32 of a packed item's output are NOT written (the caller only reads
                              // the result through kernels that take the item's rows32 flag: ttr_rowgram / ttr_rotgram / ttr_project)
 };
@@ -1320,10 +1323,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     npanels = npanels < nlive ? npanels : nlive;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  const bool idle_wave = NW == 8 && p.half_zero && p.half_zero[bt] == 3 && wave_u >= NW / 2;   // (wave-uniform; see QrApply::half_zero)
   T vreg[PW], treg = T(0);
   if (npanels > 0) {
 #pragma unroll
-    for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
+    for (int j = 0; j < PW; ++j) vreg[j] = idle_wave ? T(0) : Vt[(int64_t)((npanels - 1) * PW + j) * BR + tid];
     if (tid < PW * PW) treg = Tg[(npanels - 1) * PW * PW + tid];
   }
   Acc C[4][NTC];
@@ -1351,15 +1355,17 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
     for (int j = 0; j < PW; ++j) Vs[tid * AVLD + j] = vreg[j];
     if (tid < PW * PW) Ts[(tid >> 4) * VLD + (tid & 15)] = treg;
     if (pnl > 0) {
+      if (!idle_wave) {
 #pragma unroll
-      for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((pnl - 1) * PW + j) * BR + tid];
+        for (int j = 0; j < PW; ++j) vreg[j] = Vt[(int64_t)((pnl - 1) * PW + j) * BR + tid];
+      }
       if (tid < PW * PW) treg = Tg[(pnl - 1) * PW * PW + tid];
     }
     lds_barrier();
     astamp();
     // W = V^T C (per-wave partial over its 64 rows).  Before the first panel is applied C is [Top; 0]: a wave whose 64 rows
     // lie below the n rows of Top contributes exactly zero and skips its MFMAs (7 of the 8 waves of a 512-row block).
-    const bool c_is_zero = pnl == npanels - 1 && wave_u * 64 >= n;  // wave-uniform
+    const bool c_is_zero = idle_wave || (pnl == npanels - 1 && wave_u * 64 >= n);  // wave-uniform
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc) {
       Acc wa = M::zero();
@@ -1392,16 +1398,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
       T ta[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) ta[ks] = -Ts[cl * VLD + ks * 4 + g];
+      if (!idle_wave) {   // (an idle wave's reflector rows are zero: its rows of the product stay zero)
 #pragma unroll
-      for (int tc = 0; tc < NTC; ++tc) {
-        Acc w2 = M::zero();
+        for (int tc = 0; tc < NTC; ++tc) {
+          Acc w2 = M::zero();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) w2 = M::mma(ta[ks], Wp[0][ks * 4 + g][tc * PW + cl], w2);
+          for (int ks = 0; ks < 4; ++ks) w2 = M::mma(ta[ks], Wp[0][ks * 4 + g][tc * PW + cl], w2);
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+          for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int sI = 0; sI < 4; ++sI)
-            C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * AVLD + M::row(lane, sI)], w2[sI], C[tm][tc]);
+            for (int sI = 0; sI < 4; ++sI)
+              C[tm][tc] = M::mma(Vs[(wave * 64 + tm * 16 + cl) * AVLD + M::row(lane, sI)], w2[sI], C[tm][tc]);
+        }
       }
     }
     lds_barrier();  // Vs / Ts / Wp are rewritten by the next panel
@@ -1570,7 +1578,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && NW == 8 ? 4 : 1)) void 
         }
   } else {
     T* __restrict__ Out = p.Out + bt * p.strideOut + row0 * p.ldout;
-    if (wide_ok && kc == NC && rows == BR) {   // a whole block of a plain level (the sweep's level 1): the wave's 64 rows as two pairs
+    if (idle_wave) {
+      // (rows of absorbed leaves: the level below never reads them)
+    } else if (wide_ok && kc == NC && rows == BR) {   // a whole block of a plain level (the sweep's level 1): the wave's 64 rows as two pairs
       T* __restrict__ ow = Out + (int64_t)(wave * 64) * p.ldout;
       store_pair_wide(0, ow, p.ldout, 0, false);
       store_pair_wide(2, ow, p.ldout, 32, false);
@@ -1733,6 +1743,7 @@ __global__ __launch_bounds__(256) void pack_flags_kernel(const T* __restrict__ R
   if (lane == 0) flag[bt] = (lane_get(sq_low, 0) <= ce * ce * lane_get(sq_all, 0)) ? pack_ok : 0;
 }
 
+int g_qr_l1_idle = 1;     // (round 6) level-1 apply of packed items: waves 4 .. 7 idle (QrApply::half_zero); 0 with TTR_KNOB_QR_PACK_PRE = 2 (A/B)
 int g_qr_pack_pre = 1;   // ttr_debug_set_knob(TTR_KNOB_QR_PACK_PRE): 0 = every block derives the packing decision from Rm itself (round 5)
 
 template <typename T, int NT>
@@ -1832,6 +1843,8 @@ static int apply_run(int64_t m, int n, int64_t batch, const T* ws, T* wsw, const
     p.pk = (l == 0) ? pk : 0; p.pI = (l == 0) ? pI : 0;
     p.Gp = (l == 0) ? Gp : nullptr;
     p.pack_flag = (l == 0 && pk > 0) ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
+    p.half_zero = (l == 1 && L == 2 && pk > 0 && g_qr_pack == 3 && g_qr_l1_idle && pl.nb[0] == 8 && pl.nw[1] == 8 && n == 64 && pl.m[1] == 512)
+                      ? reinterpret_cast<const int32_t*>(ws + pl.off_flag) : nullptr;
     p.skip_zero_rows = (l == 0) ? skipz : 0;
     p.dbg = (l == 0) ? g_qr_dbg : nullptr;
     {
