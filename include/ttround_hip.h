@@ -649,6 +649,10 @@ int ttr_debug_set_qr_stamps(void* device_buffer);
  *                      itself (round 5; A/B).  + 2: the level-1 launch of ttr_qr_apply_pushed does NOT idle the waves that hold the
  *                      absorbed leaves' (exactly zero) rows of a packed item (A/B; default: they load, multiply and store nothing). */
 #define TTR_KNOB_QR_PACK_PRE 17
+/*   TTR_KNOB_EIGH_BIG_OCC  0 (default) / 3 / 2 = waves per SIMD the 64-row instance of ttr_eigh_top is built for in fp32 launches of
+ *                      >= 1024 matrices (0: four waves, 128 registers, 106 spilled; 3: 168 registers; 2: 256 registers, none
+ *                      spilled); bit-identical results (A/B, round 6). */
+#define TTR_KNOB_EIGH_BIG_OCC 18
 /*   TTR_KNOB_EIGH_SMALL  1 = ttr_eigh_top and the tridiagonal solver of ttr_eigh_trunc (TTR_EIG_RAW / REF) on 64 x 64
  *                      matrices first run the 32-row instance of their kernel over the zero-tail items (Gram matrices of packed
  *                      bonds) and then the 64-row one over the rest; 0 = one launch, the 64-row instance shrinks such items

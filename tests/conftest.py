@@ -40,7 +40,7 @@ def _restore_library_knobs(request):
         return
     _hip.set_knob(_hip.KNOB_QR_RANK_SKIP, 8)
     _hip.set_knob(_hip.KNOB_QR_PACK, 0 if _hipops._FUSE_APPLY_GRAM else 3)
-    for knob, default in ((_hip.KNOB_RANK_NOISE_FLOOR, 0 if os.environ.get("TTR_STRICT_RANKS", "1") == "0" else 1), (_hip.KNOB_ORTH_ROUNDS, 4), (_hip.KNOB_QR_PACK_PRE, 1), (_hip.KNOB_QR_STAGGER, 0), (_hip.KNOB_JACOBI_LIVE_WAVE, 0),
+    for knob, default in ((_hip.KNOB_RANK_NOISE_FLOOR, 0 if os.environ.get("TTR_STRICT_RANKS", "1") == "0" else 1), (_hip.KNOB_ORTH_ROUNDS, 4), (_hip.KNOB_QR_PACK_PRE, 1), (_hip.KNOB_EIGH_BIG_OCC, 0), (_hip.KNOB_QR_STAGGER, 0), (_hip.KNOB_JACOBI_LIVE_WAVE, 0),
                           (_hip.KNOB_ORTH_V2, 2), (_hip.KNOB_EIGH_SMALL, 2), (_hip.KNOB_QR_INTERLEAVE, 1), (_hip.KNOB_SWEEP_STAGGER, 1), (_hip.KNOB_ORTH_SPLIT, int(os.environ.get("TTR_ORTH_SPLIT", "2048") or 2048))):
         _hip.set_knob(knob, default)
     _hipops.SWEEP_C_ENABLED = os.environ.get("TTR_SWEEP_C", "1") != "0"

@@ -1074,6 +1074,7 @@ KNOB_EIGH_SMALL = 8
 KNOB_RANK_NOISE_FLOOR = 9
 KNOB_QR_STAGGER = 16
 KNOB_QR_PACK_PRE = 17
+KNOB_EIGH_BIG_OCC = 18
 KNOB_ORTH_ROUNDS = 10
 KNOB_JACOBI_LIVE_WAVE = 11
 KNOB_ORTH_V2 = 12

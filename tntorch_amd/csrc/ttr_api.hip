@@ -1107,6 +1107,7 @@ extern int g_qr_interleave;
 extern int g_qr_stagger;
 extern int g_qr_pack_pre;
 extern int g_qr_l1_idle;
+extern int g_eigh_big_occ;
 extern int g_sweep_stagger;
 extern int g_rank_noise_c;
 extern int g_jacobi_live_wave;
@@ -1817,6 +1818,10 @@ int ttr_debug_set_knob(int knob, int value) {
     case TTR_KNOB_SWEEP_STAGGER:
       TTR_REQUIRE(value >= 0 && value <= 2, TTR_E_INVALID, "ttr_debug_set_knob: stagger mode %d outside [0, 2]", value);
       g_sweep_stagger = value;
+      return TTR_OK;
+    case TTR_KNOB_EIGH_BIG_OCC:
+      TTR_REQUIRE(value == 0 || value == 2 || value == 3, TTR_E_INVALID, "ttr_debug_set_knob: eigensolver occupancy %d not in {0, 2, 3}", value);
+      g_eigh_big_occ = value;
       return TTR_OK;
     case TTR_KNOB_QR_PACK_PRE:
       TTR_REQUIRE(value >= 0 && value <= 3, TTR_E_INVALID, "ttr_debug_set_knob: pack-flag switch %d outside [0, 3]", value);

@@ -1594,6 +1594,7 @@ int g_rank_noise_c = 1;  // ttr_debug_set_knob(TTR_KNOB_RANK_NOISE_FLOOR, c): se
 // per step), 0.38 instead of 0.26 ms at n_live = 18 -- a round of the parallel-order Jacobi is ~7000 scattered LDS accesses, not
 // synchronisation: a quarter of the lanes take longer over them than the barriers of four waves cost.  Kept for the A/B.
 int g_jacobi_live_wave = 0;
+int g_eigh_big_occ = 0;   // ttr_debug_set_knob(TTR_KNOB_EIGH_BIG_OCC): waves per SIMD the 64-row top-r instance is built for (0 = 4)
 int g_eigh_small = 2;   // ttr_debug_set_knob(TTR_KNOB_EIGH_SMALL): 0 = no separate 32-row launch, 1 = the 32-row instance, 2 (default) / 3 = and its
                         // large fp32 top-r launches at three / four waves per SIMD (A/B)
 template <typename T>
@@ -1715,7 +1716,14 @@ static int eigh_top_typed(int64_t n, int64_t batch, const void* G, int64_t ldg, 
     TTR_HIP_CHECK(hipGetLastError());
     p.top_pre = 1;
   }
-  hipLaunchKernelGGL((eigh_tridiag_kernel<T, true>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
+  // (round 6, TTR_KNOB_EIGH_BIG_OCC: the 64-row instance needs ~230 registers and carries 106 spilled ones under the 128-register cap of
+  // four waves per SIMD; 3 / 2 = builds at three / two waves per SIMD for large fp32 launches, A/B)
+  if (sizeof(T) == 4 && g_eigh_big_occ == 3 && batch >= 1024)
+    hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 64, 3>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
+  else if (sizeof(T) == 4 && g_eigh_big_occ == 2 && batch >= 1024)
+    hipLaunchKernelGGL((eigh_tridiag_kernel<T, true, 64, 2>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
+  else
+    hipLaunchKernelGGL((eigh_tridiag_kernel<T, true>), dim3((unsigned)batch), dim3(2 * kWave), eigh_tridiag_lds_bytes(sizeof(T), n), stream, p);
   TTR_HIP_CHECK(hipGetLastError());
   return TTR_OK;
 }
