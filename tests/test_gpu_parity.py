@@ -977,6 +977,39 @@ def test_decaying_spectrum_metric_shape(dt, decay):
             assert ((a - b).abs().max() / b.max()).item() <= (4e-6 if f32 else 1e-13)
 
 
+def test_orth_fixup_split_rounds_at_their_real_batch_size_vs_oracle(monkeypatch):
+    """ttr_orth_fixup's three-launch rounds are what a launch of >= TTR_KNOB_ORTH_SPLIT = 2048 items takes by default (smaller
+    launches: the single-workgroup kernel -- the same train may round to different BITS in the directions below the input's
+    resolution depending on the batch it travels in).  Here at the real size: 2048 trains of 64^4, rank 64 -> 32,
+    bond sigma_j ~ 2^-j (15 of the 32 kept directions of every bond are dead), one launch per kernel, against the float64 oracle
+    on the first, a middle and the last item -- the bounds of test_decaying_spectrum_metric_shape."""
+    from tntorch_amd import _hipops
+    monkeypatch.setattr(_hipops, "STREAM_CHUNKS_ENABLED", False)   # (one sub-batch: 2048 items per launch)
+    B, N, I, R = 2048, 4, 64, 64
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    r = [1] + [R] * (N - 1) + [1]
+    inp = []
+    for k in range(N):
+        c = torch.randn((B, r[k], I, r[k + 1]), generator=gen, device="cuda", dtype=torch.float32) / math.sqrt(r[k] * I)
+        if k < N - 1:
+            c = c * (2.0 ** (-1.0 * torch.arange(r[k + 1], device="cuda", dtype=torch.float32)))
+        inp.append(c)
+    t = tn.Tensor(inp, batch=True)
+    t.round_tt(rmax=32)
+    assert list(t.ranks_tt) == [1, 32, 32, 32, 1]
+    for i in (0, B // 2 + 1, B - 1):
+        one = [c[i].cpu() for c in inp]
+        ref = oracle.round_tt([c.double() for c in one], rmax=32, algorithm="svd")
+        ours = to_list(t.cores, i)
+        assert ranks(ours) == ranks(ref)
+        e_o, e_r = tt_rel_err(ours, one), tt_rel_err(ref, one)
+        assert abs(e_o - e_r) <= 1e-5 + 1e-2 * e_r, (i, e_o, e_r)
+        assert _right_orth_err(ours) <= 5e-5, (i, _right_orth_err(ours))
+        so, sr = oracle.bond_singular_values(ours), oracle.bond_singular_values(ref)
+        for a, b in zip(so, sr):
+            assert ((a - b).abs().max() / b.max()).item() <= 4e-6
+
+
 def test_null_directions_kept_are_orthonormal():
     """g + g (exactly rank deficient) rounded with a cap ABOVE the true rank: the reference keeps the null directions
     with noise-level sigma and orthonormal rows (LAPACK); so do we (ttr_orth_fixup), and the train is unchanged."""

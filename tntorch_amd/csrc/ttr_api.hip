@@ -230,15 +230,19 @@ __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, cons
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   // `rows32` items (the carry of a packed bond: rows 32.. are exactly zero, ttr_rowgram): sigma[32..] are STRUCTURAL zeros -- exact
-  // in pass 1 and in pass 2 alike -- so the rule's decision about them is certain and only the 32 computed values carry pass 1's
-  // error.  (With the noise floor of TTR_KNOB_RANK_NOISE_FLOOR they count as c eps sigma_0 and are treated like any other value.)
-  if (rows32 && rows32[b] != 0 && noise_c <= 0 && n > 32) n = 32;
-  if (keep > n) keep = n;
+  // in pass 1 and in pass 2 alike -- so what the rule decides about them is certain and only the 32 computed values carry pass 1's
+  // error.  The rule sees them at the noise floor c eps sigma_0 (TTR_KNOB_RANK_NOISE_FLOOR, rank_rule in ttr_common.h; 0 when the
+  // floor is off): a fixed, known tail energy nstruct (c eps sigma_0)^2 that enters the sums below without an error bar.
+  // (Round 6: with the floor on by default the 32 zeros used to be treated like computed values "within E of delta^2" -- no
+  // rows32 item of an fp32 eps-mode sweep took the one-pass shortcut any more, 1.63 -> 1.85 ms for round_tt(eps=1e-4) of one 64^8 train.)
+  const int nstruct = (rows32 && rows32[b] != 0 && n > 32) ? n - 32 : 0;
+  n -= nstruct;                      // computed values: sigma[0 .. n)
+  if (keep > n + nstruct) keep = n + nstruct;
   const T* __restrict__ sgr = sigma + b * stride_sigma;
   const T s0 = sgr[0];
   // (the rank rule's view of the spectrum: rank_rule in ttr_common.h -- with TTR_KNOB_RANK_NOISE_FLOOR nothing lies below c eps sigma_0)
   const T nfl = noise_c > 0 ? T(noise_c) * Num<T>::eps() * s0 : T(0);
-  auto sg = [&](int k) { const T v = sgr[k]; return v < nfl ? nfl : v; };
+  auto sg = [&](int k) { const T v = k < n ? sgr[k] : T(0); return v < nfl ? nfl : v; };   // (k >= n: a structural zero at the floor)
   int kp = keep;
   bool ok = s0 > T(0);
   const double d2 = use_delta ? (delta2_dev ? *delta2_dev : delta2) : 0.0;
@@ -246,25 +250,29 @@ __global__ void spectrum_flat_kernel(int64_t batch, int n, int keep, T thr, cons
     // eps mode: the rank comes from the tail energies of pass 1's sigma, which carry an absolute error of up to E = 64 n eps sigma_1^2
     // (n values, each c eps sigma_1^2 off); the item only qualifies when the rule's decision is the same for every spectrum within E
     // of this one -- tail(r) <= delta^2 - E and tail(r - 1) > delta^2 + E at the selected rank r (rank cap binding: only the latter)
+    const int nt = n + nstruct;
     const double E = 64.0 * n_full * (double)Num<T>::eps() * (double)s0 * (double)s0;
     double acc = 0.0, tail_r = 0.0;
     int tail = 0;
-    for (int k = n - 1; k >= 0; --k) {
+    for (int k = nt - 1; k >= 0; --k) {
       acc += (double)sg(k) * (double)sg(k);
-      if (acc <= d2) { tail = n - k; tail_r = acc; } else break;
+      if (acc <= d2) { tail = nt - k; tail_r = acc; } else break;
     }
-    int r = n - tail;
+    int r = nt - tail;
     if (r < 1) r = 1;
     if (r > keep) {  // the cap decides as long as the rule cannot cut the keep-th value: tail(keep - 1) > delta^2 + E
       double tc = 0.0;
-      for (int k = n - 1; k >= keep - 1; --k) tc += (double)sg(k) * (double)sg(k);
-      ok = tc > d2 + E;
+      for (int k = nt - 1; k >= keep - 1; --k) tc += (double)sg(k) * (double)sg(k);
+      // (a keep-th value that is itself structural is known exactly: no error bar)
+      ok = keep - 1 >= n ? tc > d2 : tc > d2 + E;
       kp = keep;
     } else {
-      const int rr = n - tail;  // the rule's rank before the ">= 1" clamp
-      const bool cut_safe = tail == 0 || tail_r <= d2 - E;  // what is cut stays cut
+      const int rr = nt - tail;  // the rule's rank before the ">= 1" clamp
+      // what is cut stays cut: nothing computed is cut (only structural zeros: certain), or the computed tail keeps its distance
+      const bool cut_safe = tail <= nstruct || tail_r <= d2 - E;
       bool keep_safe = true;                                 // the last kept value cannot be cut as well (rr = 0: rank 1 either way)
-      if (rr >= 1) keep_safe = tail_r + (double)sg(rr - 1) * (double)sg(rr - 1) > d2 + E;
+      if (rr >= 1) keep_safe = rr - 1 >= n ? (tail_r + (double)sg(rr - 1) * (double)sg(rr - 1) > d2)
+                                           : (tail_r + (double)sg(rr - 1) * (double)sg(rr - 1) > d2 + E);
       ok = cut_safe && keep_safe;
       kp = r;
     }
