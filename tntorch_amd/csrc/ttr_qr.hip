@@ -1723,27 +1723,37 @@ __global__ __launch_bounds__(256) void r_expo_kernel(T* __restrict__ R, int rows
 // pack_flag[item] = pack_ok when rows 32 .. 63 of the item's 64 x 64 Rm hold at most (c eps)^2 of its squared Frobenius norm (the
 // packing criterion of the fused push, QrLevel::pack_flag), else 0: one wave per item, ahead of the level-0 launch (QrLevel::pack_pre)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_flags_kernel(const T* __restrict__ Rm, int64_t ldrm, int64_t strideRm, int Rin, int64_t batch,
+__global__ __launch_bounds__(512) void pack_flags_kernel(const T* __restrict__ Rm, int64_t ldrm, int64_t strideRm, int Rin, int64_t batch,
                                                          int rank_skip_c, int pack_ok, int32_t* __restrict__ flag) {
-  const int lane = threadIdx.x & 63;
-  const int64_t bt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bt >= batch) return;
+  // one 512-thread workgroup per item, summing in EXACTLY the order of the factor kernel's own test (thread (wave w, lane l): rows
+  // w + 8 e of column l, e ascending; wave_sum2; the waves' sums added in wave order): a train takes the same decision whether it
+  // travels in a batch that decides ahead of the launch or in a small one whose blocks decide for themselves
+  __shared__ T sa_w[8], sl_w[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t bt = blockIdx.x;
   const T* __restrict__ R = Rm + bt * strideRm;
-  T v[64];
-#pragma unroll
-  for (int kk = 0; kk < 64; ++kk) v[kk] = lane < Rin ? R[(int64_t)kk * ldrm + lane] : T(0);
   T sq_all = T(0), sq_low = T(0);
 #pragma unroll
-  for (int kk = 0; kk < 64; ++kk) {
-    sq_all += v[kk] * v[kk];
-    if (kk >= 32) sq_low += v[kk] * v[kk];
+  for (int e = 0; e < 8; ++e) {
+    const int kk = w + 8 * e;
+    const T rv = lane < Rin ? R[(int64_t)kk * ldrm + lane] : T(0);
+    sq_all += rv * rv;
+    if (kk >= 32) sq_low += rv * rv;
   }
   wave_sum2(sq_all, sq_low);
-  const T ce = T(rank_skip_c) * Num<T>::eps();
-  if (lane == 0) flag[bt] = (lane_get(sq_low, 0) <= ce * ce * lane_get(sq_all, 0)) ? pack_ok : 0;
+  if (lane == 0) { sa_w[w] = sq_all; sl_w[w] = sq_low; }
+  __syncthreads();
+  if (tid == 0) {
+    T sa = sa_w[0], sl = sl_w[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { sa += sa_w[k]; sl += sl_w[k]; }
+    const T ce = T(rank_skip_c) * Num<T>::eps();
+    flag[bt] = (sl <= ce * ce * sa) ? pack_ok : 0;
+  }
 }
 
 int g_qr_l1_idle = 1;     // (round 6) level-1 apply of packed items: waves 4 .. 7 idle (QrApply::half_zero); 0 with TTR_KNOB_QR_PACK_PRE = 2 (A/B)
+int g_qr_pack_pre_min = 256;   // smallest batch that takes the packing decision ahead of the launch
 int g_qr_pack_pre = 1;   // ttr_debug_set_knob(TTR_KNOB_QR_PACK_PRE): 0 = every block derives the packing decision from Rm itself (round 5)
 
 template <typename T, int NT>
@@ -1776,13 +1786,15 @@ static int factor_run(int64_t m, int n, int64_t batch, const T* A, int64_t lda, 
     const bool pushed = (l == 0 && pu.Rm);
     // the packing decision ahead of the launch: exactly when the kernel's `packed` path can be taken at all (8-wave PAIR blocks, whole
     // shapes: every mode index valid, all 16 NT columns, Rin a multiple of 16; a 64-row R; an even number of blocks)
-    p.pack_pre = (pushed && g_qr_pack_pre && p.pack_ok && p.pack_flag && g_rank_skip_c > 0 && pl.nw[l] == 8 && g_qr_variant != 0 &&
+    // (from 256 items on: below, the absorbed blocks of a launch run beside its working blocks -- no tail to save -- and the extra
+    // launch costs a latency-bound small-batch sweep 5 us per core)
+    p.pack_pre = (pushed && g_qr_pack_pre && batch >= g_qr_pack_pre_min && p.pack_ok && p.pack_flag && g_rank_skip_c > 0 && pl.nw[l] == 8 && g_qr_variant != 0 &&
                   pu.k == 64 && pu.Rin <= 64 && (pu.Rin & 15) == 0 && n == PW * NT && (pl.nb[l] & 1) == 0 && pu.I == 8 * pl.nb[l] &&
                   pu.ldrm >= pu.Rin) ? 1 : 0;
     {
       ProfScope prof(TTR_PROF_QR_FACTOR, stream);
       if (p.pack_pre)
-        hipLaunchKernelGGL((pack_flags_kernel<T>), dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, stream, (const T*)pu.Rm, pu.ldrm,
+        hipLaunchKernelGGL((pack_flags_kernel<T>), dim3((unsigned)batch), dim3(512), 0, stream, (const T*)pu.Rm, pu.ldrm,
                            pu.strideRm, pu.Rin, batch, g_rank_skip_c, p.pack_ok, p.pack_flag);
       p.grid_swap = (p.pack_ok == 3 && l == 0 && pu.Rm) ? ((g_qr_interleave && (pl.nb[l] & 1) == 0) ? 2 : 1) : 0;
       const dim3 grid = p.grid_swap ? dim3((unsigned)batch, (unsigned)pl.nb[l]) : dim3((unsigned)pl.nb[l], (unsigned)batch);
