@@ -538,8 +538,11 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
  *              0 = never); use_eigh_top != 0: batch-mode first passes through ttr_eigh_top where ttr_eigh_top_ok
  *   cores_out  cores_out[mu] = contiguous [batch][q_mu][I][q_{mu+1}], q_0 = r0 of core 0, q_N = r1 of the last core,
  *              q_mu = max(1, min(rcap[mu - 1], rows of bond mu)) -- the ranks batch mode produces (fixed by the shapes)
- *   zero_flag_dev  optional device int32 [1] (eps_mode 0): receives the largest rank-rule result of the FIRST truncation over the
- *              batch; 0 = every item hit the zero guard (round.py:137-141) and the caller returns the rank-1 zero train
+ *   zero_flag_dev  optional device-ACCESSIBLE int32 [1] (eps_mode 0): receives the largest rank-rule result of the FIRST truncation
+ *              over the batch; 0 = every item hit the zero guard (round.py:137-141) and the caller returns the rank-1 zero train.
+ *              Written by a one-workgroup kernel right after that truncation (with a system-scope fence): device memory, or --
+ *              what tntorch_amd passes since round 6 -- a pinned host word the caller initialises to a sentinel and polls, so
+ *              that it need not wait for the rest of the sweep before it returns
  *   workspace  ttr_round_tt_workspace_bytes(...) bytes, caller-owned; the call may be repeated with the same workspace once the
  *              previous one has completed on the stream
  * Envelope: every TT rank <= ttr_qr_max_cols, every core inside the fused push (k, Rin <= 64, k I >= n), every bond a

@@ -490,6 +490,28 @@ class Truncation:
         return _hip.scale_cols(self.left, self.colscale, _hip.SCALE_MUL)
 
 
+_ZF_PENDING = -(2 ** 31)   # (never a rank-rule result: those are >= 0)
+
+
+def _pinned_flag_wait(host: torch.Tensor):
+    """Callable that waits until the device has written the pinned host word ``host`` (initialised to ``_ZF_PENDING``; written by a
+    kernel of the current stream) and hands the tensor back.  Polls the word; after 2 s without a write it synchronises the
+    stream instead (the kernel's write is visible at the latest when the kernel has completed)."""
+    stream = torch.cuda.current_stream()
+
+    def wait() -> torch.Tensor:
+        import time
+
+        t0 = time.perf_counter()
+        while int(host[0]) == _ZF_PENDING:
+            if time.perf_counter() - t0 > 2.0:
+                stream.synchronize()
+                break
+        return host
+
+    return wait
+
+
 def _deferred_readback(x: torch.Tensor):
     """Start an asynchronous copy of a small device tensor to pinned host memory on the current stream and return a
     callable that waits for THAT copy (an event -- not a stream or device synchronisation) and hands back the host
@@ -1223,7 +1245,14 @@ def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> O
         outs = [torch.empty((Bt,) + tuple(tails[mu]), dtype=dt, device=dev) for mu in range(N)]
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ranks_dev = torch.empty(N - 1, dtype=torch.int32, device=dev) if eps_mode else None
-    zf = torch.empty(1, dtype=torch.int32, device=dev) if (zflags is not None and not eps_mode) else None
+    # the zero-guard flag (round.py:138-141 for the whole batch): the sweep's reduction kernel writes it STRAIGHT into pinned host
+    # memory right after the first truncation (ttr_round_tt accepts any device-accessible address), the host polls the word.  As a
+    # device word copied back after the call (rounds 5: a copy + event at the END of the stream) the caller waited for the whole
+    # sweep before it could return -- one 64^8 train: 1.27 ms per call where the host loop, whose flag travels early, took 1.18.
+    zf = None
+    if zflags is not None and not eps_mode:
+        zf = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        zf[0] = _ZF_PENDING
     use_top = EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0
     try:
         _hip.round_tt_sweep([x.contiguous() for x in c], rcap, algorithm, eps_mode, eps if eps is not None else 0.0,
@@ -1234,7 +1263,7 @@ def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> O
         return None
     SWEEP_C_CALLS += 1
     if zf is not None:
-        zflags.append(_deferred_readback(zf))
+        zflags.append(_pinned_flag_wait(zf))
     out = [outs[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
     if eps_mode:
         # the ONE host synchronisation of the sweep: the selected ranks; the cores -- computed at their caps, zero beyond the

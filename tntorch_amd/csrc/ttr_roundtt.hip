@@ -12,6 +12,9 @@
 // <= 64-row matrix with at least as many columns (the fused row-Gram / projection kernels).
 #include <math.h>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "ttr_common.h"
 
 namespace ttr {
@@ -164,6 +167,7 @@ __global__ void imax_kernel(const int32_t* __restrict__ x, int64_t n, int32_t* _
   if (threadIdx.x == 0) {
     for (int w = 1; w < kThreads / kWave; ++w) m = red[w] > m ? red[w] : m;
     out[0] = m;
+    __threadfence_system();   // (`out` may be pinned host memory that the caller polls: ttr_round_tt's zero_flag_dev)
   }
 }
 
@@ -182,10 +186,25 @@ int norm_one(int dt, int64_t count, const void* x, void* out, void* scratch, hip
   return ttr_norm(dt, count, 1, x, count, out, st);
 }
 
+// (TTR_SWEEP_PACE, diagnostics: 1 = hipStreamQuery after every library call, n > 1 = busy-wait n microseconds -- does the depth of the
+// queue cost the device time?)
+static int sweep_pace() {
+  static const int v = [] { const char* e = getenv("TTR_SWEEP_PACE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static void pace(hipStream_t st) {
+  const int v = sweep_pace();
+  if (v == 1) (void)hipStreamQuery(st);
+  else if (v > 1) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < (double)v) {}
+  }
+}
 #define TTR_TRY(expr)                \
   do {                               \
     const int _rc = (expr);          \
     if (_rc != TTR_OK) return _rc;   \
+    if (sweep_pace()) pace(st);      \
   } while (0)
 
 }  // namespace
@@ -208,13 +227,13 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
   TTR_REQUIRE(shapes && cores_in && cores_out, TTR_E_INVALID, "ttr_round_tt: null pointer");
   TTR_REQUIRE(algorithm == TTR_ALG_SVD || algorithm == TTR_ALG_EIG, TTR_E_INVALID, "ttr_round_tt: algorithm %d", algorithm);
   SweepPlan p;
+  hipStream_t st = (hipStream_t)stream;
   TTR_TRY(make_sweep_plan(dtype, N, shapes, rcap, batch, eps_mode, p));
   TTR_REQUIRE(workspace && workspace_bytes >= p.total, TTR_E_WORKSPACE, "ttr_round_tt: workspace %lld < %lld bytes",
               (long long)workspace_bytes, (long long)p.total);
   TTR_REQUIRE(!eps_mode || ranks_dev, TTR_E_INVALID, "ttr_round_tt: the eps-mode sweep needs ranks_dev[N - 1]");
   for (int64_t mu = 0; mu < N; ++mu)
     TTR_REQUIRE(cores_in[mu] && cores_out[mu], TTR_E_INVALID, "ttr_round_tt: null core %lld", (long long)mu);
-  hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const int dt = dtype;
   const int64_t es = p.es, B = batch;
