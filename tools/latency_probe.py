@@ -36,6 +36,8 @@ for on in (True, False):
 
         def f():
             t = tn.Tensor(inp, batch=True); t.round_tt(rmax=32); return t
+        f(); torch.cuda.synchronize()   # (untimed: a kernel's first launch in a process loads its code object and sizes the queue's scratch -- the 7 ms of
+        # "event-timed kernel time" at B = 1 in r05_latency.txt / the first r06 runs were that, not kernel time)
         _hip.prof_enable(True); f(); torch.cuda.synchronize(); prof = _hip.prof_collect(); _hip.prof_enable(False)
         nl = sum(v["launches"] for v in prof.values()); kms = sum(v["ms"] for v in prof.values())
         t0 = time.perf_counter(); f(); host = (time.perf_counter() - t0) * 1e3; torch.cuda.synchronize()
