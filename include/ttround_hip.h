@@ -542,7 +542,10 @@ int ttr_orth_fixup(int dtype, int64_t r, int64_t n, int64_t batch, void* X, int6
  *              over the batch; 0 = every item hit the zero guard (round.py:137-141) and the caller returns the rank-1 zero train.
  *              Written by a one-workgroup kernel right after that truncation (with a system-scope fence): device memory, or --
  *              what tntorch_amd passes since round 6 -- a pinned host word the caller initialises to a sentinel and polls, so
- *              that it need not wait for the rest of the sweep before it returns
+ *              that it need not wait for the rest of the sweep before it returns.  eps_mode 1 (round 6): when given, an int32
+ *              [N - 1] device-accessible array that receives a COPY of ranks_dev as soon as the last bond is decided (N - 1 <= 64),
+ *              i.e. before the last projection and the first core are formed -- the same polling pattern for the reference's
+ *              non-batch call
  *   workspace  ttr_round_tt_workspace_bytes(...) bytes, caller-owned; the call may be repeated with the same workspace once the
  *              previous one has completed on the stream
  * Envelope: every TT rank <= ttr_qr_max_cols, every core inside the fused push (k, Rin <= 64, k I >= n), every bond a

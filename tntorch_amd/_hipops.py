@@ -503,7 +503,7 @@ def _pinned_flag_wait(host: torch.Tensor):
         import time
 
         t0 = time.perf_counter()
-        while int(host[0]) == _ZF_PENDING:
+        while int(host.min()) == _ZF_PENDING:      # (every word: the device's stores become visible in no particular order)
             if time.perf_counter() - t0 > 2.0:
                 stream.synchronize()
                 break
@@ -1253,6 +1253,9 @@ def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> O
     if zflags is not None and not eps_mode:
         zf = torch.empty(1, dtype=torch.int32, pin_memory=True)
         zf[0] = _ZF_PENDING
+    elif eps_mode and N - 1 <= 64:
+        # (eps mode: the same word pattern for the selected ranks -- an early copy of ranks_dev in pinned host memory)
+        zf = torch.full((N - 1,), _ZF_PENDING, dtype=torch.int32).pin_memory()
     use_top = EIGH_TOP_ENABLED and FLAT_SPECTRUM_THR > 0
     try:
         _hip.round_tt_sweep([x.contiguous() for x in c], rcap, algorithm, eps_mode, eps if eps is not None else 0.0,
@@ -1262,13 +1265,18 @@ def _round_tt_sweep_c(c, eps, rmax, algorithm, batch, arena, chunk, zflags) -> O
         # inputs, so the loop over the per-kernel entries -- which asks every kernel's own predicate -- starts from the same state
         return None
     SWEEP_C_CALLS += 1
-    if zf is not None:
+    if zf is not None and not eps_mode:
         zflags.append(_pinned_flag_wait(zf))
     out = [outs[mu].view(Bt, out_r[mu], shapes[mu][1], out_r[mu + 1]) for mu in range(N)]
     if eps_mode:
         # the ONE host synchronisation of the sweep: the selected ranks; the cores -- computed at their caps, zero beyond the
         # selected ranks -- are cut to size (layout copies)
-        ranks = ranks_dev.tolist()                      # ranks[mu - 1] = rank of bond mu
+        # (polled from the pinned copy: available before the sweep's last kernels have run)
+        if zf is not None:
+            _pinned_flag_wait(zf)()
+            ranks = zf.tolist()                         # ranks[mu - 1] = rank of bond mu
+        else:
+            ranks = ranks_dev.tolist()
         if min(ranks) == 0:  # zero guard (round.py:137-145): the carry was zero from the first bond on
             return [torch.zeros((1, shapes[0][0] if mu == 0 else 1, shapes[mu][1], shapes[N - 1][2] if mu == N - 1 else 1),
                                 dtype=dt, device=dev) for mu in range(N)]

@@ -154,6 +154,12 @@ __global__ void izero_kernel(int32_t* __restrict__ x, int64_t n) {
   if (i < n) x[i] = 0;
 }
 
+// eps mode: the selected ranks, copied to a second (device-accessible, typically pinned host) array as soon as the last bond is decided
+__global__ void icopy_sys_kernel(const int32_t* __restrict__ x, int n, int32_t* __restrict__ out) {
+  if ((int)threadIdx.x < n) out[threadIdx.x] = x[threadIdx.x];
+  __threadfence_system();
+}
+
 __global__ void imax_kernel(const int32_t* __restrict__ x, int64_t n, int32_t* __restrict__ out) {
   __shared__ int red[kThreads / kWave];
   int m = -2147483647 - 1;
@@ -357,6 +363,10 @@ int ttr_round_tt(int dtype, int64_t N, const int64_t* shapes, int64_t batch, con
     } else {
       TTR_TRY(ttr_eigh_trunc(dt, R, B, G, R, parts * R * R, parts, R * R, V, R, R * R, sig, R, info, TTR_EIG_REF, eps_mode ? 1 : 0, 0.0,
                              d2dev, rmax_rule, TTR_SOLVER_TRIDIAG, nullptr, nullptr, nullptr, 0, eigws, p.eig_wsb, st));
+    }
+    if (eps_mode && mu == 1 && zero_flag_dev && N - 1 <= 64) {   // every bond is decided: the caller's early copy of the ranks (see the header)
+      hipLaunchKernelGGL(icopy_sys_kernel, dim3(1), dim3(64), 0, st, (const int32_t*)ranks_dev, (int)(N - 1), zero_flag_dev);
+      TTR_HIP_CHECK(hipGetLastError());
     }
     if (!eps_mode && mu == N - 1 && zero_flag_dev) {   // zero guard of round.py:137-141 for the whole batch (read by the caller, later)
       hipLaunchKernelGGL(imax_kernel, dim3(1), dim3(kThreads), 0, st, (const int32_t*)info, B, zero_flag_dev);
