@@ -1165,7 +1165,10 @@ def round_tt(
     shapes = [tuple(x.shape[1:]) for x in c]
 
     def all_zero_batch() -> bool:
-        return bool(zflags) and all(int(w().item()) == 0 for w in zflags)
+        # (every flag is waited for, also when the first one already decides: a pinned word must not be handed back to the
+        # allocator before the device has written it)
+        vals = [int(w().reshape(-1)[0].item()) for w in zflags]
+        return bool(vals) and all(v == 0 for v in vals)
 
     def zero_train():
         return [torch.zeros((Bt, shapes[0][0] if mu == 0 else 1, shapes[mu][1], shapes[N - 1][2] if mu == N - 1 else 1),
