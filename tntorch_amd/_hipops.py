@@ -1167,7 +1167,7 @@ def round_tt(
     def all_zero_batch() -> bool:
         # (every flag is waited for, also when the first one already decides: a pinned word must not be handed back to the
         # allocator before the device has written it)
-        vals = [int(w().reshape(-1)[0].item()) for w in zflags]
+        vals = [int(w().reshape(-1)[0].item()) for w in (zflags or ())]   # (non-batch calls: no flags at all)
         return bool(vals) and all(v == 0 for v in vals)
 
     def zero_train():
